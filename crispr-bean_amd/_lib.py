@@ -1,0 +1,141 @@
+"""ctypes binding of ``libbean_hip.so`` (the C ABI in ``include/bean_hip.h``).
+
+The library is built in-tree by ``build_library()`` (``hipcc
+--offload-arch=gfx950``); ``load()`` fails loudly when it is missing - there is
+no CPU fallback for the product path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from ctypes import POINTER, c_char_p, c_double, c_int32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libbean_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "bean_hip.h")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-shared",
+    "-fPIC",
+    "-munsafe-fp-atomics",
+]
+
+
+class bean_hip_shape(ctypes.Structure):
+    _fields_ = [
+        ("family", c_int32),
+        ("selection", c_int32),
+        ("flags", c_int32),
+        ("n_reps", c_int32),
+        ("n_condits", c_int32),
+        ("n_guides", c_int32),
+        ("n_targets", c_int32),
+        ("n_max_alleles", c_int32),
+        ("n_edits", c_int32),
+        ("n_ctrl", c_int32),
+        ("mask_thres", c_int32),
+        ("reserved", c_int32),
+        ("sd_prior_scale", c_double),
+        ("initial_lr", c_double),
+        ("lrd", c_double),
+        ("clip_norm", c_double),
+    ]
+
+
+# enum bean_hip_family / flags / buffer slots (include/bean_hip.h)
+FAMILY = {"Normal": 0, "ControlNormal": 1, "MixtureNormal": 2, "MultiMixtureNormal": 3}
+FLAG_USE_BCMATCH, FLAG_SCALE_BY_ACC, FLAG_FIT_NOISE, FLAG_PRIOR_NORMAL_MU, FLAG_DUMP_PI = 1, 2, 4, 8, 16
+BUF = {
+    "X": 0, "X_BC": 1, "ALLELE_CTRL": 2, "REPGUIDE": 3, "SIZE_FACTOR": 4, "SIZE_FACTOR_BC": 5,
+    "SAMPLE_MASK": 6, "A0": 7, "A0_BC": 8, "PI_A0": 9, "Z_HI": 10, "Z_LO": 11,
+    "TARGET_OFFSETS": 12, "GUIDE_TO_TARGET": 13, "ACCESSIBILITY": 14,
+    "PRIOR_MU_LOC": 15, "PRIOR_MU_SCALE": 16, "PRIOR_SD_LOC": 17, "PRIOR_SD_SCALE": 18,
+    "P": 32, "G": 48, "M": 64, "V": 80,
+    "EPS_MU_IN": 96, "EPS_SD_IN": 97, "PI_IN": 98, "EPS_NOISE_IN": 99,
+    "EPS_MU_OUT": 100, "EPS_SD_OUT": 101, "PI_OUT": 102, "EPS_NOISE_OUT": 103,
+    "LOSS_HIST": 112,
+}
+PARAM_ORDER = ("mu_loc", "mu_scale", "sd_loc", "sd_scale", "alpha_pi", "noise_loc", "noise_scale")
+
+# every symbol include/bean_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("bean_hip_version", c_char_p, []),
+    ("bean_hip_last_error", c_char_p, []),
+    ("bean_hip_create", c_int32, [POINTER(bean_hip_shape), POINTER(c_void_p)]),
+    ("bean_hip_destroy", c_int32, [c_void_p]),
+    ("bean_hip_bind", c_int32, [c_void_p, c_int32, c_void_p, c_uint64]),
+    ("bean_hip_prepare", c_int32, [c_void_p, c_void_p]),
+    ("bean_hip_elbo_grad", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_void_p]),
+    ("bean_hip_adam", c_int32, [c_void_p, c_uint64, c_void_p]),
+    ("bean_hip_svi_run", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_int32, c_void_p]),
+    ("bean_hip_step_bytes", c_uint64, [c_void_p]),
+    ("bean_hip_dominant_kernel", c_char_p, [c_void_p]),
+    ("bean_hip_set_profile", c_int32, [c_void_p, c_int32]),
+    ("bean_hip_get_profile", c_int32, [c_void_p, POINTER(c_double), POINTER(c_uint64)]),
+    ("bean_hip_test_special", c_int32,
+     [c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+]
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [INCLUDE]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in sources())
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile ``csrc/bean_hip.hip`` for gfx950 into ``lib/libbean_hip.so``."""
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libbean_hip.so")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "bean_hip.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the in-tree library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "crispr-bean_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().bean_hip_last_error().decode()
+        raise RuntimeError(f"libbean_hip {what} failed: {msg}")

@@ -1,0 +1,474 @@
+// libbean_hip.so: C ABI over the BEAN SVI kernels (see include/bean_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/bean_hip.h"
+#include "bean_kernels.hpp"
+
+using namespace bean;
+
+static thread_local std::string g_err;
+static int fail(const std::string& msg) {
+    g_err = msg;
+    return -1;
+}
+#define HIP_OK(expr)                                                                 \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess)                                                        \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct bean_hip_ctx {
+    bean_hip_shape shape;
+    DevArgs d;
+    void* slot_ptr[BEAN_BUF_COUNT];
+    uint64_t slot_bytes[BEAN_BUF_COUNT];
+    void* workspace;
+    uint64_t workspace_bytes;
+    uint64_t loss_capacity;
+    bool prepared;
+    // graph cache
+    hipGraphExec_t graph_exec;
+    int graph_chunk;
+    unsigned long long graph_seed;
+    // profiling of the dominant kernel
+    bool profile;
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+};
+
+extern "C" const char* bean_hip_version(void) { return "bean_hip 0.1.0 (gfx950)"; }
+extern "C" const char* bean_hip_last_error(void) { return g_err.c_str(); }
+
+static bool is_mixture(const bean_hip_shape& s) { return s.family == BEAN_FAMILY_MIXTURE_NORMAL; }
+
+// Bytes the shape implies for a slot (0 = slot not used by this shape).
+static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
+    const uint64_t R = s.n_reps, B = s.n_condits, G = s.n_guides, T = s.n_targets;
+    const uint64_t A = s.n_max_alleles, C = s.n_ctrl;
+    auto param_elems = [&](int i) -> uint64_t {
+        switch (i) {
+            case 0: case 1: case 2: case 3: return T;
+            case 4: return is_mixture(s) ? G * A : 0;
+            case 5: case 6: return (is_mixture(s) && (s.flags & BEAN_FLAG_SCALE_BY_ACC) && (s.flags & BEAN_FLAG_FIT_NOISE)) ? G : 0;
+        }
+        return 0;
+    };
+    if (slot >= BEAN_BUF_P_MU_LOC && slot < BEAN_BUF_P_MU_LOC + 7) return 4 * param_elems(slot - BEAN_BUF_P_MU_LOC);
+    if (slot >= BEAN_BUF_G_MU_LOC && slot < BEAN_BUF_G_MU_LOC + 7) return 4 * param_elems(slot - BEAN_BUF_G_MU_LOC);
+    if (slot >= BEAN_BUF_M_MU_LOC && slot < BEAN_BUF_M_MU_LOC + 7) return 4 * param_elems(slot - BEAN_BUF_M_MU_LOC);
+    if (slot >= BEAN_BUF_V_MU_LOC && slot < BEAN_BUF_V_MU_LOC + 7) return 4 * param_elems(slot - BEAN_BUF_V_MU_LOC);
+    switch (slot) {
+        case BEAN_BUF_X: return 4 * R * B * G;
+        case BEAN_BUF_X_BC: return (s.flags & BEAN_FLAG_USE_BCMATCH) ? 4 * R * B * G : 0;
+        case BEAN_BUF_ALLELE_CTRL: return is_mixture(s) ? 4 * R * C * G * A : 0;
+        case BEAN_BUF_REPGUIDE: return R * G;
+        case BEAN_BUF_SIZE_FACTOR: return 8 * R * B;
+        case BEAN_BUF_SIZE_FACTOR_BC: return (s.flags & BEAN_FLAG_USE_BCMATCH) ? 8 * R * B : 0;
+        case BEAN_BUF_SAMPLE_MASK: return 8 * R * B;
+        case BEAN_BUF_A0: return 8 * G;
+        case BEAN_BUF_A0_BC: return (s.flags & BEAN_FLAG_USE_BCMATCH) ? 8 * G : 0;
+        case BEAN_BUF_PI_A0: return is_mixture(s) ? 8 * G : 0;
+        case BEAN_BUF_Z_HI: case BEAN_BUF_Z_LO: return 8 * B;
+        case BEAN_BUF_TARGET_OFFSETS: return 4 * (T + 1);
+        case BEAN_BUF_GUIDE_TO_TARGET: return 4 * G;
+        case BEAN_BUF_ACCESSIBILITY: return (s.flags & BEAN_FLAG_SCALE_BY_ACC) ? 8 * G : 0;
+        case BEAN_BUF_PRIOR_MU_LOC: case BEAN_BUF_PRIOR_MU_SCALE:
+        case BEAN_BUF_PRIOR_SD_LOC: case BEAN_BUF_PRIOR_SD_SCALE: return 8 * T;
+        case BEAN_BUF_EPS_MU_IN: case BEAN_BUF_EPS_SD_IN:
+        case BEAN_BUF_EPS_MU_OUT: case BEAN_BUF_EPS_SD_OUT: return 8 * T;
+        case BEAN_BUF_PI_IN: case BEAN_BUF_PI_OUT: return is_mixture(s) ? 8 * R * G * A : 0;
+        case BEAN_BUF_EPS_NOISE_IN: case BEAN_BUF_EPS_NOISE_OUT:
+            return (s.flags & BEAN_FLAG_SCALE_BY_ACC) ? 8 * G : 0;
+        case BEAN_BUF_LOSS_HIST: return 8;  // minimum; any multiple of 8 accepted
+    }
+    return 0;
+}
+
+static void sync_devargs(bean_hip_ctx* c) {
+    DevArgs& d = c->d;
+    auto P = [&](int s) { return c->slot_ptr[s]; };
+    d.X = (const float*)P(BEAN_BUF_X);
+    d.Xbc = (const float*)P(BEAN_BUF_X_BC);
+    d.allele = (const float*)P(BEAN_BUF_ALLELE_CTRL);
+    d.rg = (const uint8_t*)P(BEAN_BUF_REPGUIDE);
+    d.sf = (const double*)P(BEAN_BUF_SIZE_FACTOR);
+    d.sf_bc = (const double*)(P(BEAN_BUF_SIZE_FACTOR_BC) ? P(BEAN_BUF_SIZE_FACTOR_BC) : P(BEAN_BUF_SIZE_FACTOR));
+    d.smask = (const double*)P(BEAN_BUF_SAMPLE_MASK);
+    d.a0 = (const double*)P(BEAN_BUF_A0);
+    d.a0_bc = (const double*)P(BEAN_BUF_A0_BC);
+    d.pi_a0 = (const double*)P(BEAN_BUF_PI_A0);
+    d.z_hi = (const double*)P(BEAN_BUF_Z_HI);
+    d.z_lo = (const double*)P(BEAN_BUF_Z_LO);
+    d.acc = (const double*)P(BEAN_BUF_ACCESSIBILITY);
+    d.toff = (const int*)P(BEAN_BUF_TARGET_OFFSETS);
+    d.g2t = (const int*)P(BEAN_BUF_GUIDE_TO_TARGET);
+    d.pr_mu_loc = (const double*)P(BEAN_BUF_PRIOR_MU_LOC);
+    d.pr_mu_scale = (const double*)P(BEAN_BUF_PRIOR_MU_SCALE);
+    d.pr_sd_loc = (const double*)P(BEAN_BUF_PRIOR_SD_LOC);
+    d.pr_sd_scale = (const double*)P(BEAN_BUF_PRIOR_SD_SCALE);
+    for (int i = 0; i < 7; ++i) {
+        d.p[i] = (float*)P(BEAN_BUF_P_MU_LOC + i);
+        d.g[i] = (float*)P(BEAN_BUF_G_MU_LOC + i);
+        d.m[i] = (float*)P(BEAN_BUF_M_MU_LOC + i);
+        d.v[i] = (float*)P(BEAN_BUF_V_MU_LOC + i);
+    }
+    d.eps_mu_in = (const double*)P(BEAN_BUF_EPS_MU_IN);
+    d.eps_sd_in = (const double*)P(BEAN_BUF_EPS_SD_IN);
+    d.pi_in = (const double*)P(BEAN_BUF_PI_IN);
+    d.eps_noise_in = (const double*)P(BEAN_BUF_EPS_NOISE_IN);
+    d.eps_mu_out = (double*)P(BEAN_BUF_EPS_MU_OUT);
+    d.eps_sd_out = (double*)P(BEAN_BUF_EPS_SD_OUT);
+    d.pi_out = (double*)P(BEAN_BUF_PI_OUT);
+    d.eps_noise_out = (double*)P(BEAN_BUF_EPS_NOISE_OUT);
+    d.loss_hist = (double*)P(BEAN_BUF_LOSS_HIST);
+    d.flags = c->shape.flags & ~kDumpPi;
+    if (d.pi_out && (c->shape.flags & BEAN_FLAG_DUMP_PI)) d.flags |= kDumpPi;
+}
+
+static void drop_graph(bean_hip_ctx* c) {
+    if (c->graph_exec) {
+        (void)hipGraphExecDestroy(c->graph_exec);
+        c->graph_exec = nullptr;
+    }
+    c->graph_chunk = 0;
+}
+
+extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
+    if (!s || !out) return fail("bean_hip_create: null argument");
+    if (s->selection != BEAN_SELECTION_SORTING)
+        return fail("bean_hip_create: only sorting screens are implemented in this build");
+    if (s->family != BEAN_FAMILY_NORMAL && s->family != BEAN_FAMILY_CONTROL_NORMAL &&
+        s->family != BEAN_FAMILY_MIXTURE_NORMAL)
+        return fail("bean_hip_create: family not implemented in this build");
+    if (s->n_reps < 1 || s->n_guides < 1 || s->n_targets < 1)
+        return fail("bean_hip_create: R, G, T must be >= 1");
+    if (s->n_condits < 1 || s->n_condits > 8)
+        return fail("bean_hip_create: n_condits must be in [1, 8]");
+    if (is_mixture(*s) && s->n_max_alleles != 2)
+        return fail("bean_hip_create: MixtureNormal requires n_max_alleles == 2");
+    if (is_mixture(*s) && s->n_ctrl < 1) return fail("bean_hip_create: MixtureNormal requires n_ctrl >= 1");
+    if (s->family == BEAN_FAMILY_CONTROL_NORMAL && s->n_targets != 1)
+        return fail("bean_hip_create: ControlNormal requires n_targets == 1");
+    if (!(s->lrd > 0.0) || !(s->initial_lr > 0.0)) return fail("bean_hip_create: lr and lrd must be > 0");
+
+    bean_hip_ctx* c = new bean_hip_ctx();
+    memset(&c->d, 0, sizeof(DevArgs));
+    memset(c->slot_ptr, 0, sizeof(c->slot_ptr));
+    memset(c->slot_bytes, 0, sizeof(c->slot_bytes));
+    c->shape = *s;
+    c->prepared = false;
+    c->graph_exec = nullptr;
+    c->graph_chunk = 0;
+    c->graph_seed = 0;
+    c->profile = false;
+    c->loss_capacity = 0;
+    DevArgs& d = c->d;
+    d.R = s->n_reps; d.B = s->n_condits; d.G = s->n_guides; d.T = s->n_targets;
+    d.A = s->n_max_alleles; d.C = s->n_ctrl;
+    d.family = s->family; d.flags = s->flags; d.mask_thres = s->mask_thres;
+    // reserved carries the longest target (guides per target); few very long
+    // targets are reduced by one block each
+    d.wide_targets = (s->n_targets < 64 || s->reserved > 256) ? 1 : 0;
+    d.sd_prior_scale = s->sd_prior_scale; d.lr0 = s->initial_lr; d.log_lrd = log(s->lrd);
+    d.clip = s->clip_norm;
+
+    const uint64_t B = d.B, T = d.T, G = d.G;
+    const uint64_t n_dbl = 3 * B * T + B + 4 * T + (uint64_t)kNumPart * G + 2 * G + 1 + 8;
+    c->workspace_bytes = n_dbl * 8;
+    hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(std::string("hipMalloc workspace: ") + hipGetErrorString(e));
+    }
+    e = hipMemset(c->workspace, 0, c->workspace_bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(c->workspace);
+        delete c;
+        return fail(std::string("hipMemset workspace: ") + hipGetErrorString(e));
+    }
+    double* w = (double*)c->workspace;
+    d.tabP = w; w += B * T;
+    d.tabPmu = w; w += B * T;
+    d.tabPy = w; w += B * T;
+    d.P0 = w; w += B;
+    d.mu_t = w; w += T;
+    d.y_t = w; w += T;
+    d.eps_mu = w; w += T;
+    d.eps_sd = w; w += T;
+    d.part = w; w += (uint64_t)kNumPart * G;
+    d.lpn = w; w += G;
+    d.eps_noise = w; w += G;
+    d.loss_const = w; w += 1;
+    d.ctrA = (StepCtr*)w; w += 2;
+    d.ctrB = (StepCtr*)w; w += 2;
+    *out = c;
+    return 0;
+}
+
+extern "C" int bean_hip_destroy(bean_hip_ctx* c) {
+    if (!c) return 0;
+    drop_graph(c);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->workspace) (void)hipFree(c->workspace);
+    delete c;
+    return 0;
+}
+
+extern "C" int bean_hip_bind(bean_hip_ctx* c, int slot, void* ptr, uint64_t nbytes) {
+    if (!c) return fail("bean_hip_bind: null handle");
+    if (slot < 0 || slot >= BEAN_BUF_COUNT) return fail("bean_hip_bind: slot out of range");
+    if (ptr) {
+        const uint64_t want = expected_bytes(c->shape, slot);
+        if (want == 0)
+            return fail("bean_hip_bind: slot " + std::to_string(slot) + " is not used by this shape");
+        if (slot == BEAN_BUF_LOSS_HIST) {
+            if (nbytes < 8 || nbytes % 8) return fail("bean_hip_bind: loss_hist must hold >= 1 double");
+            c->loss_capacity = nbytes / 8;
+        } else if (nbytes != want) {
+            return fail("bean_hip_bind: slot " + std::to_string(slot) + " expects " + std::to_string(want) +
+                        " bytes, got " + std::to_string(nbytes));
+        }
+    }
+    c->slot_ptr[slot] = ptr;
+    c->slot_bytes[slot] = ptr ? nbytes : 0;
+    sync_devargs(c);
+    drop_graph(c);
+    if (slot < BEAN_BUF_P_MU_LOC) c->prepared = false;
+    return 0;
+}
+
+static int require(bean_hip_ctx* c, int slot, const char* what) {
+    if (!c->slot_ptr[slot]) return fail(std::string("required buffer not bound: ") + what);
+    return 0;
+}
+
+static int check_bound(bean_hip_ctx* c, bool need_grads, bool need_moments) {
+    const bean_hip_shape& s = c->shape;
+#define REQ(slot) if (require(c, slot, #slot)) return -1
+    REQ(BEAN_BUF_X); REQ(BEAN_BUF_REPGUIDE); REQ(BEAN_BUF_SIZE_FACTOR); REQ(BEAN_BUF_SAMPLE_MASK);
+    REQ(BEAN_BUF_A0); REQ(BEAN_BUF_Z_HI); REQ(BEAN_BUF_Z_LO); REQ(BEAN_BUF_TARGET_OFFSETS);
+    REQ(BEAN_BUF_GUIDE_TO_TARGET); REQ(BEAN_BUF_LOSS_HIST);
+    if (s.flags & BEAN_FLAG_USE_BCMATCH) { REQ(BEAN_BUF_X_BC); REQ(BEAN_BUF_SIZE_FACTOR_BC); REQ(BEAN_BUF_A0_BC); }
+    if (is_mixture(s)) { REQ(BEAN_BUF_ALLELE_CTRL); REQ(BEAN_BUF_PI_A0); }
+    if (s.flags & BEAN_FLAG_SCALE_BY_ACC) REQ(BEAN_BUF_ACCESSIBILITY);
+    for (int i = 0; i < 7; ++i) {
+        if (expected_bytes(s, BEAN_BUF_P_MU_LOC + i) == 0) continue;
+        REQ(BEAN_BUF_P_MU_LOC + i);
+        if (need_grads) REQ(BEAN_BUF_G_MU_LOC + i);
+        if (need_moments) { REQ(BEAN_BUF_M_MU_LOC + i); REQ(BEAN_BUF_V_MU_LOC + i); }
+    }
+#undef REQ
+    return 0;
+}
+
+extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
+    if (!c) return fail("bean_hip_prepare: null handle");
+    if (check_bound(c, false, false)) return -1;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_OK(hipMemsetAsync(c->d.loss_const, 0, 8, stream));
+    const long n = (long)c->d.R * c->d.G;
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c->d);
+    HIP_OK(hipGetLastError());
+    c->prepared = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------ launches
+static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_blocks) {
+    const DevArgs& d = c->d;
+    n_target_blocks = d.wide_targets ? d.T : (d.T + 255) / 256;
+    n_blocks = n_target_blocks + (d.family == kMixture ? (d.G + 255) / 256 : 0);
+}
+
+template <bool FINISH, bool ADAM, bool PREP>
+static void launch_param(bean_hip_ctx* c, hipStream_t stream) {
+    int ntb, nb;
+    grid_param(c, ntb, nb);
+    hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP>), dim3(nb), dim3(256), 0, stream, c->d, ntb);
+}
+
+template <int B>
+static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 block, size_t lds) {
+    const DevArgs& d = c->d;
+    if (d.family == kMixture) {
+        if (d.flags & kAcc)
+            hipLaunchKernelGGL((k_guide<B, kMixture, true>), grid, block, lds, stream, d);
+        else
+            hipLaunchKernelGGL((k_guide<B, kMixture, false>), grid, block, lds, stream, d);
+    } else {
+        hipLaunchKernelGGL((k_guide<B, kNormal, false>), grid, block, lds, stream, d);
+    }
+}
+
+static int waves_per_block(const bean_hip_ctx* c) { return c->d.R < 8 ? c->d.R : 8; }
+
+static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
+    const DevArgs& d = c->d;
+    const int nw = waves_per_block(c);
+    const dim3 grid((d.G + 63) / 64), block(64 * nw);
+    const size_t lds = ((size_t)nw * kNumPart * 64 + 16) * sizeof(double);
+    const bool prof = c->profile && c->ev.size() < 8192;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, stream);
+    }
+    switch (d.B) {
+        case 1: launch_guide_b<1>(c, stream, grid, block, lds); break;
+        case 2: launch_guide_b<2>(c, stream, grid, block, lds); break;
+        case 3: launch_guide_b<3>(c, stream, grid, block, lds); break;
+        case 4: launch_guide_b<4>(c, stream, grid, block, lds); break;
+        case 5: launch_guide_b<5>(c, stream, grid, block, lds); break;
+        case 6: launch_guide_b<6>(c, stream, grid, block, lds); break;
+        case 7: launch_guide_b<7>(c, stream, grid, block, lds); break;
+        default: launch_guide_b<8>(c, stream, grid, block, lds); break;
+    }
+    if (prof) {
+        (void)hipEventRecord(e1, stream);
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+    }
+}
+
+extern "C" int bean_hip_elbo_grad(bean_hip_ctx* c, uint64_t seed, uint64_t step, uint64_t loss_index,
+                                  void* stream_) {
+    if (!c) return fail("bean_hip_elbo_grad: null handle");
+    if (!c->prepared) return fail("bean_hip_elbo_grad: call bean_hip_prepare first");
+    if (check_bound(c, true, false)) return -1;
+    if (loss_index >= c->loss_capacity) return fail("bean_hip_elbo_grad: loss_index beyond loss_hist");
+    hipStream_t stream = (hipStream_t)stream_;
+    c->d.seed = seed;
+    HIP_OK(hipMemsetAsync(c->d.loss_hist + loss_index, 0, 8, stream));
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d.ctrA, c->d.ctrB,
+                       (unsigned long long)step, (unsigned long long)loss_index);
+    launch_param<false, false, true>(c, stream);
+    launch_guide(c, stream);
+    launch_param<true, false, false>(c, stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bean_hip_adam(bean_hip_ctx* c, uint64_t t, void* stream_) {
+    if (!c) return fail("bean_hip_adam: null handle");
+    if (check_bound(c, true, true)) return -1;
+    if (t < 1) return fail("bean_hip_adam: t is 1-based");
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int i = 0; i < 7; ++i) {
+        const uint64_t bytes = expected_bytes(c->shape, BEAN_BUF_P_MU_LOC + i);
+        if (!bytes) continue;
+        const long n = (long)(bytes / 4);
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c->d.p[i],
+                           (const float*)c->d.g[i], c->d.m[i], c->d.v[i], n, c->d, (unsigned long long)t);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static void enqueue_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i) {
+        launch_param<true, true, true>(c, stream);
+        launch_guide(c, stream);
+    }
+}
+
+extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
+                                int32_t graph_chunk, void* stream_) {
+    if (!c) return fail("bean_hip_svi_run: null handle");
+    if (!c->prepared) return fail("bean_hip_svi_run: call bean_hip_prepare first");
+    if (check_bound(c, false, true)) return -1;
+    if (n_steps == 0) return 0;
+    if (first_step + n_steps > c->loss_capacity)
+        return fail("bean_hip_svi_run: loss_hist too small for first_step + n_steps");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (c->graph_exec && (c->graph_seed != seed)) drop_graph(c);
+    c->d.seed = seed;
+    HIP_OK(hipMemsetAsync(c->d.loss_hist + first_step, 0, 8 * n_steps, stream));
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d.ctrA, c->d.ctrB,
+                       (unsigned long long)first_step, (unsigned long long)first_step);
+    launch_param<false, false, true>(c, stream);
+    launch_guide(c, stream);
+    uint64_t pairs = n_steps - 1;
+    const bool use_graph = graph_chunk > 0 && stream != nullptr && !c->profile;
+    if (use_graph) {
+        if (c->graph_exec && c->graph_chunk != graph_chunk) drop_graph(c);
+        if (!c->graph_exec && pairs >= (uint64_t)graph_chunk) {
+            hipGraph_t graph = nullptr;
+            HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            enqueue_pairs(c, stream, (uint64_t)graph_chunk);
+            hipError_t e = hipStreamEndCapture(stream, &graph);
+            if (e != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) {
+                c->graph_exec = nullptr;
+                return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            }
+            c->graph_chunk = graph_chunk;
+            c->graph_seed = seed;
+        }
+        while (c->graph_exec && pairs >= (uint64_t)graph_chunk) {
+            HIP_OK(hipGraphLaunch(c->graph_exec, stream));
+            pairs -= (uint64_t)graph_chunk;
+        }
+    }
+    enqueue_pairs(c, stream, pairs);
+    launch_param<true, true, false>(c, stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
+    if (!c) return 0;
+    const bean_hip_shape& s = c->shape;
+    const uint64_t R = s.n_reps, B = s.n_condits, G = s.n_guides, T = s.n_targets, A = s.n_max_alleles;
+    const bool bc = s.flags & BEAN_FLAG_USE_BCMATCH;
+    // counts (f32) once per likelihood, repguide mask, per-guide a0 / a0_bc / g2t
+    uint64_t bytes = G * (4 * R * B * (bc ? 2 : 1) + R + 8 * (bc ? 2 : 1) + 4);
+    if (is_mixture(s)) bytes += G * (4 * R * s.n_ctrl * A + 8 /*pi_a0*/ + 3 * 4 * A * 2 /*alpha_pi, m, v r+w*/);
+    if (s.flags & BEAN_FLAG_SCALE_BY_ACC) bytes += G * (8 + ((s.flags & BEAN_FLAG_FIT_NOISE) ? 2 * 3 * 4 * 2 : 0));
+    bytes += T * (4 * 3 * 4 * 2);  // four per-target params with moments, read + written
+    return bytes;
+}
+
+extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx*) { return "k_guide"; }
+
+extern "C" int bean_hip_set_profile(bean_hip_ctx* c, int32_t enable) {
+    if (!c) return fail("bean_hip_set_profile: null handle");
+    c->profile = enable != 0;
+    if (c->profile) drop_graph(c);
+    return 0;
+}
+
+extern "C" int bean_hip_get_profile(bean_hip_ctx* c, double* avg_ms, uint64_t* launches) {
+    if (!c || !avg_ms || !launches) return fail("bean_hip_get_profile: null argument");
+    double total = 0.0;
+    uint64_t n = 0;
+    for (size_t i = 0; i + 1 < c->ev.size(); i += 2) {
+        HIP_OK(hipEventSynchronize(c->ev[i + 1]));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        total += ms;
+        ++n;
+    }
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    c->ev.clear();
+    *avg_ms = n ? total / (double)n : 0.0;
+    *launches = n;
+    return 0;
+}
+
+extern "C" int bean_hip_test_special(int32_t op, uint64_t n, const double* a, const double* x,
+                                     const double* b, double* out0, double* out1, void* stream_) {
+    if (op < 0 || op > 4) return fail("bean_hip_test_special: unknown op");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_test_special, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                       (int)op, (long)n, a, x, b, out0, out1);
+    HIP_OK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,713 @@
+// HIP kernels of the BEAN SVI step for gfx950 (MI355X).
+//
+// One SVI step of the variant sorting families is two kernels:
+//
+//   k_param  (per target + per guide, light)
+//       FINISH: reduce the previous step's per-guide partials into parameter
+//               gradients (guide -> target segmented reduce; priors and
+//               entropies; Dirichlet normalisers), then ClippedAdam in place;
+//       PREP:   draw eps for the next step, mu_t / sd_t, and tabulate the
+//               edited-component bin probabilities P[b, t] and their
+//               derivatives (the Normal-CDF work depends only on the target).
+//
+//   k_guide  (per (rep, guide), heavy: >95 % of the time)
+//       one wave = 64 consecutive guides of one replicate (coalesced reads of
+//       the (R, B, G) count tensors); the waves of a block cover the R
+//       replicates of the same 64 guides, so the reduction over replicates is
+//       an LDS reduction.  Per thread: Dirichlet draw, mixture, both
+//       Dirichlet-Multinomial likelihoods with analytic gradients, Multinomial
+//       on control allele counts, implicit-reparameterisation gradient.
+//
+// Reference semantics: bean/model/model.py (models/guides), bean/model/utils.py
+// (get_alpha, get_std_normal_prob), SURVEY.md Appendix A/D for the algebra.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bean_special.hpp"
+
+namespace bean {
+
+constexpr double kEps = 1e-5;         // epsilon of get_alpha (utils.py:11)
+constexpr double kPiNoiseSd = 0.655;  // utils.py:133
+constexpr double kAccA = 0.2513;      // utils.py:82
+constexpr float kAccBf = -1.9458f;    // utils.py:83 (exp taken in float32 there)
+constexpr double kHalfLog2PiC = 0.91893853320467274178;
+constexpr double kLog2 = 0.69314718055994530942;
+constexpr double kDblMin = 2.2250738585072014e-308;
+constexpr double kOneMinus = 0.99999999999999988898;  // nextafter(1, 0)
+constexpr double kProbEps = 2.220446049250313e-16;    // torch clamp_probs eps (f64)
+
+enum Family { kNormal = 0, kControlNormal = 1, kMixture = 2, kMultiMixture = 3 };
+enum Flags { kUseBc = 1, kAcc = 2, kFitNoise = 4, kPriorNormalMu = 8, kDumpPi = 16 };
+
+struct StepCtr {
+    unsigned long long step;  // SVI step (RNG offset, Adam t = step + 1)
+    unsigned long long slot;  // index into loss_hist
+};
+
+// partial-sum rows written by k_guide, (kNumPart, G) doubles
+enum Part { kPGmu = 0, kPGy = 1, kPGnoise = 2, kPNrg = 3, kPPath = 4, kPLp = 6, kPLq = 8, kNumPart = 10 };
+
+struct DevArgs {
+    int R, B, G, T, A, C;
+    int family, flags, mask_thres, wide_targets;
+    double sd_prior_scale, lr0, log_lrd, clip;
+    unsigned long long seed;
+    // data
+    const float* X;
+    const float* Xbc;
+    const float* allele;
+    const uint8_t* rg;
+    const double *sf, *sf_bc, *smask, *a0, *a0_bc, *pi_a0, *z_hi, *z_lo, *acc;
+    const int *toff, *g2t;
+    const double *pr_mu_loc, *pr_mu_scale, *pr_sd_loc, *pr_sd_scale;
+    // parameters / grads / moments: mu_loc, mu_scale, sd_loc, sd_scale, alpha_pi, noise_loc, noise_scale
+    float* p[7];
+    float* g[7];
+    float* m[7];
+    float* v[7];
+    // noise
+    const double *eps_mu_in, *eps_sd_in, *pi_in, *eps_noise_in;
+    double *eps_mu_out, *eps_sd_out, *pi_out, *eps_noise_out;
+    double* loss_hist;
+    // workspace
+    double *tabP, *tabPmu, *tabPy;     // (B, T)
+    double* P0;                        // (B)
+    double *mu_t, *y_t, *eps_mu, *eps_sd;  // (T)
+    double* part;                      // (kNumPart, G)
+    double *lpn, *eps_noise;           // (G)
+    double* loss_const;                // (1)
+    StepCtr *ctrA, *ctrB;
+};
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over the block; result valid in thread 0.  `scratch` holds >= 16 doubles.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) tot += scratch[i];
+    return tot;
+}
+
+// ------------------------------------------------------------- ClippedAdam
+// pyro.optim.ClippedAdam on one float32 element.
+struct AdamCoef {
+    float step_size, clip;
+};
+__device__ __forceinline__ AdamCoef adam_coef(const DevArgs& c, unsigned long long t) {
+    const double td = (double)t;
+    const double lr = c.lr0 * exp(td * c.log_lrd);
+    const double bc1 = 1.0 - pow(0.9, td), bc2 = 1.0 - pow(0.999, td);
+    AdamCoef k;
+    k.step_size = (float)(lr * sqrt(bc2) / bc1);
+    k.clip = (float)c.clip;
+    return k;
+}
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float grad, AdamCoef k) {
+    const float gc = fminf(fmaxf(grad, -k.clip), k.clip);
+    m = m * 0.9f + gc * 0.1f;
+    v = v * 0.999f + (gc * gc) * 0.001f;
+    const float denom = sqrtf(v) + 1e-8f;
+    p = p - k.step_size * (m / denom);
+}
+
+template <bool ADAM>
+__device__ __forceinline__ void emit_grad(const DevArgs& c, int which, long idx, double grad, AdamCoef k) {
+    const float gf = (float)grad;
+    if (ADAM) {
+        float p = c.p[which][idx], m = c.m[which][idx], v = c.v[which][idx];
+        adam_update(p, m, v, gf, k);
+        c.p[which][idx] = p;
+        c.m[which][idx] = m;
+        c.v[which][idx] = v;
+    } else {
+        c.g[which][idx] = gf;
+    }
+}
+
+// -------------------------------------------------------------------- k_param
+// grid = n_target_blocks + n_guide_blocks, 256 threads.
+template <bool FINISH, bool ADAM, bool PREP>
+__global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
+    __shared__ double scratch[16];
+    const StepCtr ctr = *c.ctrA;
+    const unsigned long long s_fin = ctr.step;
+    const unsigned long long s_prep = FINISH ? ctr.step + 1 : ctr.step;
+    const unsigned long long slot_prep = FINISH ? ctr.slot + 1 : ctr.slot;
+    AdamCoef ak;
+    ak.step_size = 0.f;
+    ak.clip = 0.f;
+    if (FINISH && ADAM) ak = adam_coef(c, s_fin + 1);
+    double loss_fin = 0.0, loss_prep = 0.0;
+    const bool mixture = c.family == kMixture;
+
+    if ((int)blockIdx.x < n_target_blocks) {
+        // ------------------------------------------------ target part
+        int t;
+        bool active;
+        double gmu = 0.0, gy = 0.0;
+        if (c.wide_targets) {
+            t = blockIdx.x;
+            active = threadIdx.x == 0;
+            if (FINISH) {
+                const int g0 = c.toff[t], g1 = c.toff[t + 1];
+                double a = 0.0, b = 0.0;
+                for (int g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+                    a += c.part[(long)kPGmu * c.G + g];
+                    b += c.part[(long)kPGy * c.G + g];
+                }
+                gmu = block_sum(a, scratch);
+                gy = block_sum(b, scratch);
+            }
+        } else {
+            t = blockIdx.x * blockDim.x + threadIdx.x;
+            active = t < c.T;
+            if (FINISH && active) {
+                const int g0 = c.toff[t], g1 = c.toff[t + 1];
+                for (int g = g0; g < g1; ++g) {
+                    gmu += c.part[(long)kPGmu * c.G + g];
+                    gy += c.part[(long)kPGy * c.G + g];
+                }
+            }
+        }
+        if (active) {
+            float pf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[i] = c.p[i][t];
+            const double l0 = c.pr_sd_loc ? c.pr_sd_loc[t] : 0.0;
+            const double s0 = c.pr_sd_scale ? c.pr_sd_scale[t] : c.sd_prior_scale;
+            if (FINISH) {
+                const double eps1 = c.eps_mu[t], eps2 = c.eps_sd[t];
+                const double mu = c.mu_t[t], y = c.y_t[t];
+                const double s_mu = exp((double)pf[1]), s_sd = exp((double)pf[3]);
+                double logp_mu, dlogp_mu;
+                if (c.flags & kPriorNormalMu) {
+                    const double pl = c.pr_mu_loc ? c.pr_mu_loc[t] : 0.0;
+                    const double ps = c.pr_mu_scale ? c.pr_mu_scale[t] : 1.0;
+                    const double zz = (mu - pl) / ps;
+                    logp_mu = -0.5 * zz * zz - log(ps) - kHalfLog2PiC;
+                    dlogp_mu = -zz / ps;
+                } else {
+                    logp_mu = -kLog2 - fabs(mu);
+                    dlogp_mu = mu > 0.0 ? -1.0 : (mu < 0.0 ? 1.0 : 0.0);
+                }
+                const double zz = (y - l0) / s0;
+                const double logp_sd = -y - log(s0) - kHalfLog2PiC - 0.5 * zz * zz;
+                const double dlogp_dy = -1.0 - zz / s0;
+                const double logq_mu = -0.5 * eps1 * eps1 - (double)pf[1] - kHalfLog2PiC;
+                const double logq_sd = -y - 0.5 * eps2 * eps2 - (double)pf[3] - kHalfLog2PiC;
+                loss_fin = -logp_mu - logp_sd + logq_mu + logq_sd;
+                const double Gmu = gmu - dlogp_mu;
+                const double Gy = gy - dlogp_dy;
+                emit_grad<ADAM>(c, 0, t, Gmu, ak);
+                emit_grad<ADAM>(c, 1, t, Gmu * eps1 * s_mu - 1.0, ak);
+                emit_grad<ADAM>(c, 2, t, Gy - 1.0, ak);
+                emit_grad<ADAM>(c, 3, t, Gy * eps2 * s_sd - 1.0 - eps2 * s_sd, ak);
+                if (ADAM)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pf[i] = c.p[i][t];
+            }
+            if (PREP) {
+                double eps1, eps2;
+                if (c.eps_mu_in) {
+                    eps1 = c.eps_mu_in[t];
+                    eps2 = c.eps_sd_in[t];
+                } else {
+                    rocrand_state_philox4x32_10 st;
+                    rocrand_init(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)t,
+                                 s_prep * 4ull, &st);
+                    const float2 n = rocrand_normal2(&st);
+                    eps1 = (double)n.x;
+                    eps2 = (double)n.y;
+                }
+                const double mu = (double)pf[0] + eps1 * exp((double)pf[1]);
+                const double y = (double)pf[2] + eps2 * exp((double)pf[3]);
+                c.eps_mu[t] = eps1;
+                c.eps_sd[t] = eps2;
+                c.mu_t[t] = mu;
+                c.y_t[t] = y;
+                if (c.eps_mu_out) {
+                    c.eps_mu_out[t] = eps1;
+                    c.eps_sd_out[t] = eps2;
+                }
+                // NormalModel uses sqrt(sd) as the scale (model.py:92-98)
+                const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
+                const double dsig_dy = c.family == kNormal ? 0.5 * sigma : sigma;
+                const double inv = 1.0 / sigma;
+                for (int b = 0; b < c.B; ++b) {
+                    const double zh = c.z_hi[b], zl = c.z_lo[b];
+                    double ch = 1.0, cl = 0.0, fh = 0.0, fl = 0.0, ufh = 0.0, ufl = 0.0;
+                    if (!isinf(zh)) {
+                        const double u = (zh - mu) * inv;
+                        ch = norm_cdf(u);
+                        fh = norm_pdf(u);
+                        ufh = u * fh;
+                    }
+                    if (!isinf(zl)) {
+                        const double u = (zl - mu) * inv;
+                        cl = norm_cdf(u);
+                        fl = norm_pdf(u);
+                        ufl = u * fl;
+                    }
+                    const long o = (long)b * c.T + t;
+                    c.tabP[o] = ch - cl;
+                    c.tabPmu[o] = -(fh - fl) * inv;
+                    c.tabPy[o] = -(ufh - ufl) * inv * dsig_dy;
+                }
+            }
+        }
+    } else if (mixture) {
+        // ------------------------------------------------- guide part
+        const int g = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
+        const bool acc_on = (c.flags & kAcc) != 0;
+        const bool fit_noise = acc_on && (c.flags & kFitNoise);
+        if (g < c.G) {
+            float nl = 0.f, ns_u = 0.f;
+            if (fit_noise) {
+                nl = c.p[5][g];
+                ns_u = c.p[6][g];
+            }
+            if (FINISH) {
+                const float u0 = c.p[4][2 * g], u1 = c.p[4][2 * g + 1];
+                const double al0 = (double)expf(u0), al1 = (double)expf(u1);
+                const double s = al0 + al1, pa0 = c.pi_a0[g];
+                const double cp[2] = {al0 / s * pa0, al1 / s * pa0};
+                const bool cl[2] = {cp[0] < 1e-5, cp[1] < 1e-5};
+                const double cq[2] = {cl[0] ? 1e-5 : cp[0], cl[1] ? 1e-5 : cp[1]};
+                double lgS_p, dgS_p, lg_p[2], dg_p[2];
+                lgamma_digamma(cp[0] + cp[1], lgS_p, dgS_p);
+                lgamma_digamma(cp[0], lg_p[0], dg_p[0]);
+                lgamma_digamma(cp[1], lg_p[1], dg_p[1]);
+                double lgS_q = lgS_p, dgS_q = dgS_p, lg_q[2] = {lg_p[0], lg_p[1]}, dg_q[2] = {dg_p[0], dg_p[1]};
+                if (cl[0] || cl[1]) {
+                    lgamma_digamma(cq[0] + cq[1], lgS_q, dgS_q);
+                    lgamma_digamma(cq[0], lg_q[0], dg_q[0]);
+                    lgamma_digamma(cq[1], lg_q[1], dg_q[1]);
+                }
+                const double nrg = c.part[(long)kPNrg * c.G + g];
+                const double Rf = (double)c.R;
+                double gc[2];
+                double lp = nrg * (lgS_p - lg_p[0] - lg_p[1]);
+                double lq = Rf * (lgS_q - lg_q[0] - lg_q[1]);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const double Lp = c.part[(long)(kPLp + a) * c.G + g];
+                    const double Lq = c.part[(long)(kPLq + a) * c.G + g];
+                    const double gpath = c.part[(long)(kPPath + a) * c.G + g];
+                    lp += (cp[a] - 1.0) * Lp;
+                    lq += (cq[a] - 1.0) * Lq;
+                    const double g_cp = -(Lp + nrg * (dgS_p - dg_p[a]));
+                    const double g_cq = cl[a] ? 0.0 : (Lq + Rf * (dgS_q - dg_q[a]) + gpath);
+                    gc[a] = g_cp + g_cq;
+                }
+                loss_fin = -lp + lq;
+                const double dot = (gc[0] * al0 + gc[1] * al1) / s;
+                emit_grad<ADAM>(c, 4, 2 * g, pa0 / s * (gc[0] - dot) * al0, ak);
+                emit_grad<ADAM>(c, 4, 2 * g + 1, pa0 / s * (gc[1] - dot) * al1, ak);
+                if (acc_on) {
+                    const double lpn = c.lpn[g], eps = c.eps_noise[g];
+                    const double gl = c.part[(long)kPGnoise * c.G + g];
+                    const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
+                    const double zp = lpn / kPiNoiseSd;
+                    const double logp = -0.5 * zp * zp - log(kPiNoiseSd) - kHalfLog2PiC;
+                    const double logq = -0.5 * eps * eps - log(ns) - kHalfLog2PiC;
+                    loss_fin += -logp + logq;
+                    if (fit_noise) {
+                        const double Gl = gl + lpn / (kPiNoiseSd * kPiNoiseSd);
+                        emit_grad<ADAM>(c, 5, g, Gl, ak);
+                        emit_grad<ADAM>(c, 6, g, Gl * eps * ns - 1.0, ak);
+                        if (ADAM) {
+                            nl = c.p[5][g];
+                            ns_u = c.p[6][g];
+                        }
+                    }
+                }
+            }
+            if (PREP && acc_on) {
+                double eps;
+                if (c.eps_noise_in) {
+                    eps = c.eps_noise_in[g];
+                } else {
+                    rocrand_state_philox4x32_10 st;
+                    rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)g,
+                                 s_prep * 4ull, &st);
+                    eps = (double)rocrand_normal(&st);
+                }
+                const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
+                c.eps_noise[g] = eps;
+                c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
+                if (c.eps_noise_out) c.eps_noise_out[g] = eps;
+            }
+        }
+    }
+    if (FINISH) {
+        const double tot = block_sum(loss_fin, scratch);
+        if (threadIdx.x == 0) {
+            double add = tot;
+            if (blockIdx.x == 0) add += *c.loss_const;
+            atomicAdd(&c.loss_hist[ctr.slot], add);
+        }
+    }
+    (void)loss_prep;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        StepCtr nxt;
+        nxt.step = s_prep;
+        nxt.slot = slot_prep;
+        *c.ctrB = nxt;
+    }
+}
+
+// --------------------------------------------------------------------- k_guide
+// Dirichlet-Multinomial observation term of one (rep, guide):
+// returns -log p and accumulates d(-log p)/d e[b] into ge.
+template <int B>
+__device__ __forceinline__ double dirmult_nll(const float (&x)[B], const double* __restrict__ sf,
+                                              const double* __restrict__ sm, double a0,
+                                              const double (&e)[B], double (&ge)[B]) {
+    double p[B], araw[B], S = 0.0, n = 0.0;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        p[b] = e[b] * sf[b];
+        S += p[b];
+        n += (double)x[b];
+    }
+    const double inv = 1.0 / (S + kEps);
+    double A0 = 0.0;
+    bool clamped[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        araw[b] = (p[b] + kEps / B) * inv * a0 * sm[b];
+        clamped[b] = araw[b] < kEps;
+        A0 += clamped[b] ? kEps : araw[b];
+    }
+    const DD d0 = lgamma_digamma_diff(A0, n);
+    double nll = d0.d, W = 0.0, ga[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const DD db = lgamma_digamma_diff(clamped[b] ? kEps : araw[b], (double)x[b]);
+        nll -= db.d;
+        ga[b] = clamped[b] ? 0.0 : (d0.dp - db.dp);  // d nll / d alpha_b
+        W += ga[b] * araw[b];
+    }
+    W *= inv;
+#pragma unroll
+    for (int b = 0; b < B; ++b) ge[b] += (ga[b] * a0 * sm[b] * inv - W) * sf[b];
+    return nll;
+}
+
+// blockDim.x = 64 * nw (nw waves cover the replicates of 64 guides); dynamic
+// LDS = nw * kNumPart * 64 doubles + 16.
+template <int B, int FAM, bool ACC>
+__global__ __launch_bounds__(512) void k_guide(DevArgs c) {
+    extern __shared__ double lds[];
+    constexpr bool MIX = FAM == kMixture;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int g = blockIdx.x * 64 + lane;
+    const bool valid = g < c.G;
+    const StepCtr ctr = *c.ctrB;
+    const int G = c.G, T = c.T;
+
+    double acc[kNumPart];
+#pragma unroll
+    for (int q = 0; q < kNumPart; ++q) acc[q] = 0.0;
+    double loss = 0.0;
+
+    if (valid) {
+        const int t = c.g2t[g];
+        double P1[B], Pmu[B], Py[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const long o = (long)b * T + t;
+            P1[b] = c.tabP[o];
+            Pmu[b] = c.tabPmu[o];
+            Py[b] = c.tabPy[o];
+        }
+        const double a0 = c.a0[g];
+        const bool use_bc = (c.flags & kUseBc) != 0;
+        const double a0bc = use_bc ? c.a0_bc[g] : 1.0;
+        double cp[2] = {1.0, 1.0}, cq[2] = {1.0, 1.0};
+        bool cl[2] = {false, false};
+        double kacc = 0.0, lpn = 0.0;
+        if (MIX) {
+            const double al0 = (double)expf(c.p[4][2 * g]), al1 = (double)expf(c.p[4][2 * g + 1]);
+            const double s = al0 + al1, pa0 = c.pi_a0[g];
+            cp[0] = al0 / s * pa0;
+            cp[1] = al1 / s * pa0;
+            cl[0] = cp[0] < 1e-5;
+            cl[1] = cp[1] < 1e-5;
+            cq[0] = cl[0] ? 1e-5 : cp[0];
+            cq[1] = cl[1] ? 1e-5 : cp[1];
+            if (ACC) {
+                kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                lpn = c.lpn[g];
+            }
+        }
+        for (int r = w; r < c.R; r += nw) {
+            const double* sf = c.sf + r * B;
+            const double* sfb = c.sf_bc + r * B;
+            const double* sm = c.smask + r * B;
+            const bool rgm = c.rg[(long)r * G + g] != 0;
+            float x[B], xb[B];
+            float n = 0.f, nb = 0.f;
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                x[b] = c.X[((long)r * B + b) * G + g];
+                n += x[b];
+            }
+            if (use_bc) {
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    xb[b] = c.Xbc[((long)r * B + b) * G + g];
+                    nb += xb[b];
+                }
+            }
+            const bool obs = rgm && n > (float)c.mask_thres;
+            const bool obs_bc = use_bc && rgm && nb > (float)c.mask_thres;
+
+            double pi[2] = {0.0, 1.0}, pe1 = 1.0;  // pe1: effective weight of the edited component
+            double dpe1_dpi1 = 0.0;                // ACC: d pe1 / d pi1 (0 when clamped)
+            double dpe1_dl = 0.0;                  // ACC: d pe1 / d logit noise
+            if (MIX) {
+                if (c.pi_in) {
+                    pi[0] = c.pi_in[((long)r * G + g) * 2];
+                    pi[1] = c.pi_in[((long)r * G + g) * 2 + 1];
+                } else {
+                    Rng rng(c.seed, kSitePi, (unsigned long long)r * G + g, ctr.step * 256ull);
+                    double g0 = sample_gamma(cq[0], rng), g1 = sample_gamma(cq[1], rng);
+                    g0 = fmax(g0, kDblMin);
+                    g1 = fmax(g1, kDblMin);
+                    const double s = g0 + g1;
+                    pi[0] = fmin(fmax(g0 / s, kDblMin), kOneMinus);
+                    pi[1] = fmin(fmax(g1 / s, kDblMin), kOneMinus);
+                }
+                if (c.flags & kDumpPi) {
+                    c.pi_out[((long)r * G + g) * 2] = pi[0];
+                    c.pi_out[((long)r * G + g) * 2 + 1] = pi[1];
+                }
+                pe1 = pi[1];
+                if (ACC) {
+                    // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
+                    const double s1 = pi[1] * kacc;
+                    const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+                    const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+                    const double l = log(p1c / (1.0 - p1c)) + lpn;
+                    const double el = exp(l);
+                    const double pn = el / (1.0 + el);
+                    const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+                    pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+                    dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
+                    dpe1_dpi1 = in1 ? dpe1_dl / (p1c * (1.0 - p1c)) * kacc : 0.0;
+                }
+            }
+            double e[B], ge[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                e[b] = MIX ? (1.0 - pe1) * c.P0[b] + pe1 * P1[b] : P1[b];
+                ge[b] = 0.0;
+            }
+            double nll = 0.0;
+            if (obs) nll += dirmult_nll<B>(x, sf, sm, a0, e, ge);
+            if (obs_bc) nll += dirmult_nll<B>(xb, sfb, sm, a0bc, e, ge);
+            // likelihood gradient w.r.t. the table entries of this guide's target
+            double dmu = 0.0, dy = 0.0, gpe1 = 0.0;
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                dmu += ge[b] * Pmu[b];
+                dy += ge[b] * Py[b];
+                gpe1 += ge[b] * (P1[b] - c.P0[b]);
+            }
+            acc[kPGmu] += pe1 * dmu;
+            acc[kPGy] += pe1 * dy;
+            if (MIX) {
+                // d loss / d pi through the likelihood
+                double gpi[2] = {0.0, 0.0};
+                if (ACC) {
+                    gpi[1] = gpe1 * dpe1_dpi1;
+                    acc[kPGnoise] += gpe1 * dpe1_dl;
+                } else {
+                    // e = pi0 P0 + pi1 P1 with both components free
+                    double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        g0 += ge[b] * c.P0[b];
+                        g1 += ge[b] * P1[b];
+                    }
+                    gpi[0] = g0;
+                    gpi[1] = g1;
+                }
+                const double lpi[2] = {log(pi[0]), log(pi[1])};
+                if (rgm) {
+                    // Multinomial(probs = pi) on control allele counts (model.py:470-474)
+                    const double s = pi[0] + pi[1];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const double pr = pi[a] / s;
+                        const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+                        const double lg = log(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                        double cnt = 0.0;
+                        for (int cc = 0; cc < c.C; ++cc)
+                            cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * 2 + a];
+                        nll -= cnt * lg;
+                        if (inside) gpi[a] -= cnt / pi[a];
+                    }
+                    acc[kPNrg] += 1.0;
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    if (rgm) {
+                        acc[kPLp + a] += lpi[a];
+                        gpi[a] -= (cp[a] - 1.0) / pi[a];
+                    }
+                    acc[kPLq + a] += lpi[a];
+                    gpi[a] += (cq[a] - 1.0) / pi[a];
+                }
+                const double proj = pi[0] * gpi[0] + pi[1] * gpi[1];
+                const double total = cq[0] + cq[1];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    if (!cl[a]) acc[kPPath + a] += dirichlet_grad_one(pi[a], cq[a], total) * (gpi[a] - proj);
+            }
+            loss += nll;
+        }
+    }
+
+    // ---- reduce over the block's waves (replicates) and write per-guide rows
+    double* red = lds;  // [nw][kNumPart][64]
+    if (nw > 1) {
+#pragma unroll
+        for (int q = 0; q < kNumPart; ++q) red[((long)w * kNumPart + q) * 64 + lane] = acc[q];
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int q = 0; q < kNumPart; ++q) {
+                double s = acc[q];
+                for (int ww = 1; ww < nw; ++ww) s += red[((long)ww * kNumPart + q) * 64 + lane];
+                acc[q] = s;
+            }
+        }
+    }
+    if (w == 0 && valid) {
+#pragma unroll
+        for (int q = 0; q < kNumPart; ++q)
+            if (MIX || q < 2) c.part[(long)q * G + g] = acc[q];
+    }
+    double* scratch = lds + (long)nw * kNumPart * 64;
+    const double tot = block_sum(loss, scratch);
+    if (threadIdx.x == 0) {
+        atomicAdd(&c.loss_hist[ctr.slot], tot);
+        if (blockIdx.x == 0) *c.ctrA = ctr;
+    }
+}
+
+// ------------------------------------------------------------------ one-offs
+// Data-only constants: P0[b] and the log-factorial terms of the three observed
+// sites (they are part of the reported loss and carry no gradient).
+__global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
+    __shared__ double scratch[16];
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n_rg = (long)c.R * c.G;
+    double v = 0.0;
+    if (idx < n_rg) {
+        const int r = (int)(idx / c.G), g = (int)(idx % c.G);
+        const bool rgm = c.rg[idx] != 0;
+        double n = 0.0, lf = 0.0, nb = 0.0, lfb = 0.0;
+        for (int b = 0; b < c.B; ++b) {
+            const double x = (double)c.X[((long)r * c.B + b) * c.G + g];
+            n += x;
+            lf += lgamma(1.0 + x);
+            if (c.flags & kUseBc) {
+                const double y = (double)c.Xbc[((long)r * c.B + b) * c.G + g];
+                nb += y;
+                lfb += lgamma(1.0 + y);
+            }
+        }
+        if (rgm && n > (double)c.mask_thres) v -= lgamma(1.0 + n) - lf;
+        if ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) v -= lgamma(1.0 + nb) - lfb;
+        if (c.family == kMixture && rgm) {
+            for (int cc = 0; cc < c.C; ++cc) {
+                double tot = 0.0, l = 0.0;
+                for (int a = 0; a < c.A; ++a) {
+                    const double y = (double)c.allele[(((long)r * c.C + cc) * c.G + g) * c.A + a];
+                    tot += y;
+                    l += lgamma(1.0 + y);
+                }
+                v -= lgamma(1.0 + tot) - l;
+            }
+        }
+    }
+    const double tot = block_sum(v, scratch);
+    if (threadIdx.x == 0) atomicAdd(c.loss_const, tot);
+    if (blockIdx.x == 0 && (int)threadIdx.x < c.B) {
+        const double zh = c.z_hi[threadIdx.x], zl = c.z_lo[threadIdx.x];
+        const double ch = isinf(zh) ? 1.0 : norm_cdf(zh);
+        const double cl = isinf(zl) ? 0.0 : norm_cdf(zl);
+        c.P0[threadIdx.x] = ch - cl;
+    }
+}
+
+__global__ void k_set_step(StepCtr* a, StepCtr* b, unsigned long long step, unsigned long long slot) {
+    StepCtr s;
+    s.step = step;
+    s.slot = slot;
+    *a = s;
+    *b = s;
+}
+
+// Stand-alone ClippedAdam over one parameter array (bean_hip_adam).
+__global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m, float* v, long n,
+                                              DevArgs c, unsigned long long t) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AdamCoef k = adam_coef(c, t);
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update(pp, mm, vv, g[i], k);
+    p[i] = pp;
+    m[i] = mm;
+    v[i] = vv;
+}
+
+// Unit-test hook for the special functions (bean_hip_test_special).
+__global__ __launch_bounds__(256) void k_test_special(int op, long n, const double* a, const double* x,
+                                                      const double* b, double* o0, double* o1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (op == 0) {
+        const DD d = lgamma_digamma_diff(a[i], x[i]);
+        o0[i] = d.d;
+        o1[i] = d.dp;
+    } else if (op == 1) {
+        double lg, dg;
+        lgamma_digamma(a[i], lg, dg);
+        o0[i] = lg;
+        o1[i] = dg;
+    } else if (op == 2) {
+        o0[i] = dirichlet_grad_one(x[i], a[i], b[i]);
+    } else if (op == 3) {
+        o0[i] = norm_cdf(a[i]);
+    } else if (op == 4) {
+        unsigned long long seed;
+        memcpy(&seed, &x[0], 8);
+        Rng rng(seed, kSiteAux, (unsigned long long)i, 0ull);
+        double g0 = fmax(sample_gamma(a[i], rng), kDblMin);
+        double g1 = fmax(sample_gamma(b[i], rng), kDblMin);
+        const double s = g0 + g1;
+        o0[i] = fmin(fmax(g0 / s, kDblMin), kOneMinus);
+        o1[i] = fmin(fmax(g1 / s, kDblMin), kOneMinus);
+    }
+}
+
+}  // namespace bean

@@ -1,0 +1,301 @@
+// Device special functions and samplers for the BEAN ELBO kernels (gfx950).
+//
+// All arithmetic is float64: the reference's likelihood runs in float64 through
+// dtype promotion and MI355X issues v_fma_f64 at the same rate as
+// non-packed f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+
+namespace bean {
+
+struct DD {
+    double d;   // lgamma(a + x) - lgamma(a)
+    double dp;  // digamma(a + x) - digamma(a)
+};
+
+// Stirling tails, valid to ~1e-14 absolute for z >= 10 (r = 1/z, w = r*r).
+__device__ __forceinline__ double stirling_lgamma_tail(double r, double w) {
+    // 1/(12 z) - 1/(360 z^3) + 1/(1260 z^5) - 1/(1680 z^7) + 1/(1188 z^9)
+    return r * (8.3333333333333333e-2 +
+                w * (-2.7777777777777778e-3 +
+                     w * (7.9365079365079365e-4 +
+                          w * (-5.9523809523809524e-4 + w * 8.4175084175084175e-4))));
+}
+__device__ __forceinline__ double stirling_digamma_tail(double w) {
+    // 1/(12 z^2) - 1/(120 z^4) + 1/(252 z^6) - 1/(240 z^8) + 1/(132 z^10) - 691/(32760 z^12)
+    return w * (8.3333333333333333e-2 +
+                w * (-8.3333333333333333e-3 +
+                     w * (3.9682539682539683e-3 +
+                          w * (-4.1666666666666667e-3 +
+                               w * (7.5757575757575758e-3 + w * -2.1092796092796093e-2)))));
+}
+
+constexpr double kShift = 10.0;
+constexpr double kHalfLog2Pi = 0.91893853320467274178;
+
+// Raise z to >= kShift, accumulating P = prod(z+i) and Q = dP/dz, so that
+// lgamma(z) = lgamma(z') - log P and digamma(z) = digamma(z') - Q / P.
+__device__ __forceinline__ void shift_up(double& z, double& P, double& Q) {
+    P = 1.0;
+    Q = 0.0;
+    while (z < kShift) {
+        Q = fma(Q, z, P);
+        P *= z;
+        z += 1.0;
+    }
+}
+
+// lgamma(z) and digamma(z) for z > 0.
+__device__ __forceinline__ void lgamma_digamma(double z, double& lg, double& dg) {
+    double P, Q;
+    shift_up(z, P, Q);
+    const double l = log(z), r = 1.0 / z, w = r * r;
+    lg = (z - 0.5) * l - z + kHalfLog2Pi + stirling_lgamma_tail(r, w);
+    dg = l - 0.5 * r - stirling_digamma_tail(w);
+    if (P != 1.0) {
+        lg -= log(P);
+        dg -= Q / P;
+    }
+}
+
+__device__ __forceinline__ double digamma(double z) {
+    double lg, dg;
+    lgamma_digamma(z, lg, dg);
+    return dg;
+}
+
+// D(a, x) = lgamma(a + x) - lgamma(a) and its derivative in a, for a > 0 and
+// x >= 0.  Counts are integer-valued, so small x uses the exact product form
+// prod_{i<x}(a + i); everything else is a difference of Stirling series, with
+// both arguments first raised to >= kShift.
+__device__ __forceinline__ DD lgamma_digamma_diff(double a, double x) {
+    DD out;
+    if (x == 0.0) {
+        out.d = 0.0;
+        out.dp = 0.0;
+        return out;
+    }
+    if (x <= 12.0 && x == floor(x)) {
+        double P = 1.0, Q = 0.0, t = a;
+        const int n = (int)x;
+        for (int i = 0; i < n; ++i) {
+            Q = fma(Q, t, P);
+            P *= t;
+            t += 1.0;
+        }
+        out.d = log(P);
+        out.dp = Q / P;
+        return out;
+    }
+    double z1 = a, z2 = a + x, P1, Q1, P2, Q2;
+    shift_up(z1, P1, Q1);
+    shift_up(z2, P2, Q2);
+    const double l1 = log(z1), l2 = log(z2);
+    const double r1 = 1.0 / z1, r2 = 1.0 / z2;
+    const double w1 = r1 * r1, w2 = r2 * r2;
+    double d = (z2 - 0.5) * l2 - (z1 - 0.5) * l1 - (z2 - z1) +
+               (stirling_lgamma_tail(r2, w2) - stirling_lgamma_tail(r1, w1));
+    double dp = (l2 - l1) - 0.5 * (r2 - r1) -
+                (stirling_digamma_tail(w2) - stirling_digamma_tail(w1));
+    if (P1 != 1.0) {
+        d += log(P1);
+        dp += Q1 / P1;
+    }
+    if (P2 != 1.0) {
+        d -= log(P2);
+        dp -= Q2 / P2;
+    }
+    out.d = d;
+    out.dp = dp;
+    return out;
+}
+
+// Standard normal cdf / pdf as torch.distributions.Normal computes them
+// (torch/distributions/normal.py:105-113): 0.5 * (1 + erf(u / sqrt 2)).
+__device__ __forceinline__ double norm_cdf(double u) {
+    return 0.5 * (1.0 + erf(u * 0.70710678118654752440));
+}
+__device__ __forceinline__ double norm_pdf(double u) {
+    return 0.39894228040143267794 * exp(-0.5 * u * u);
+}
+
+// ---------------------------------------------------------------------------
+// Implicit reparameterisation gradient of a Dirichlet component,
+// -(d cdf/d alpha) / pdf / (1 - x) for x ~ Beta(alpha, total - alpha): the
+// piecewise approximation published in torch (ATen/native/Distributions.h,
+// dirichlet_grad_one and helpers; torch 2.10).  The reference reaches it through
+// pyro.distributions.Dirichlet.rsample -> torch._dirichlet_grad; parity with the
+// reference's alpha_pi gradient requires the same approximation, so the region
+// boundaries and fitted coefficients below are torch's.
+// ---------------------------------------------------------------------------
+__device__ inline double beta_grad_alpha_small(double x, double alpha, double beta) {
+    const double factor = digamma(alpha) - digamma(alpha + beta) - log(x);
+    double numer = 1.0;
+    double series = numer / alpha * (factor + 1.0 / alpha);
+    for (int i = 1; i <= 10; ++i) {
+        const double ci = (double)i;
+        numer *= (ci - beta) * x / ci;
+        const double denom = alpha + ci;
+        series += numer / denom * (factor + 1.0 / denom);
+    }
+    const double result = x * pow(1.0 - x, -beta) * series;
+    return isnan(result) ? 0.0 : result;
+}
+
+__device__ inline double beta_grad_beta_small(double x, double alpha, double beta) {
+    const double factor = digamma(alpha + beta) - digamma(beta);
+    double numer = 1.0, betas = 1.0, dbetas = 0.0, series = factor / alpha;
+    for (int i = 1; i <= 8; ++i) {
+        const double ci = (double)i;
+        numer *= -x / ci;
+        dbetas = dbetas * (beta - ci) + betas;
+        betas = betas * (beta - ci);
+        series += numer / (alpha + ci) * (dbetas + factor * betas);
+    }
+    const double result = -pow(1.0 - x, 1.0 - beta) * series;
+    return isnan(result) ? 0.0 : result;
+}
+
+__device__ inline double beta_grad_alpha_mid(double x, double alpha, double beta) {
+    const double total = alpha + beta;
+    const double mean = alpha / total;
+    const double sd = sqrt(alpha * beta / (total + 1.0)) / total;
+    if (mean - 0.1 * sd <= x && x <= mean + 0.1 * sd) {
+        const double b2 = beta * beta;
+        const double poly =
+            47.0 * x * b2 * b2 +
+            alpha * ((43.0 + 20.0 * (16.0 + 27.0 * beta) * x) * b2 * beta +
+                     alpha * (3.0 * (59.0 + 180.0 * beta - 90.0 * x) * b2 +
+                              alpha * ((453.0 + 1620.0 * beta * (1.0 - x) - 455.0 * x) * beta +
+                                       alpha * (8.0 * (1.0 - x) * (135.0 * beta - 11.0)))));
+        const double pre_num = (1.0 + 12.0 * alpha) * (1.0 + 12.0 * beta) / (total * total);
+        const double pre_den =
+            12960.0 * alpha * alpha * alpha * beta * beta * (1.0 + 12.0 * total);
+        return pre_num / (1.0 - x) * poly / pre_den;
+    }
+    const double prefactor = -x / sqrt(2.0 * alpha * beta / total);
+    const double stirling = (1.0 + 1.0 / (12.0 * alpha) + 1.0 / (288.0 * alpha * alpha)) *
+                            (1.0 + 1.0 / (12.0 * beta) + 1.0 / (288.0 * beta * beta)) /
+                            (1.0 + 1.0 / (12.0 * total) + 1.0 / (288.0 * total * total));
+    const double term1_num =
+        2.0 * (alpha * alpha) * (x - 1.0) + alpha * beta * (x - 1.0) - x * (beta * beta);
+    const double axbx = alpha * (x - 1.0) + beta * x;
+    const double term1_den = sqrt(2.0 * alpha / beta) * pow(total, 1.5) * axbx * axbx;
+    const double term1 = term1_num / term1_den;
+    const double term2 = 0.5 * log(alpha / (total * x));
+    const double term3 = sqrt(8.0 * alpha * beta / total) / (beta * x + alpha * (x - 1.0));
+    const double term4_base =
+        beta * log(beta / (total * (1.0 - x))) + alpha * log(alpha / (total * x));
+    const double term4 = pow(term4_base, -1.5);
+    const double term1234 = term1 + term2 * (term3 + (x < mean ? term4 : -term4));
+    return stirling * prefactor * term1234;
+}
+
+// c[num/den][u^i][a^j][b^k] of the rational correction in dirichlet_grad_one
+__device__ __constant__ const double kDirGradC[2][3][3][4] = {
+    {{{1.003668233, -0.01061107488, -0.0657888334, 0.01201642863},
+      {0.6336835991, -0.3557432599, 0.05486251648, -0.001465281033},
+      {-0.03276231906, 0.004474107445, 0.002429354597, -0.0001557569013}},
+     {{0.221950385, -0.3187676331, 0.01799915743, 0.01074823814},
+      {-0.2951249643, 0.06219954479, 0.01535556598, 0.001550077057},
+      {0.02155310298, 0.004170831599, 0.001292462449, 6.976601077e-05}},
+     {{-0.05980841433, 0.008441916499, 0.01085618172, 0.002319392565},
+      {0.02911413504, 0.01400243777, -0.002721828457, 0.000751041181},
+      {0.005900514878, -0.001936558688, -9.495446725e-06, 5.385558597e-05}}},
+    {{{1, -0.02924021934, -0.04438342661, 0.007285809825},
+      {0.6357567472, -0.3473456711, 0.05454656494, -0.002407477521},
+      {-0.03301322327, 0.004845219414, 0.00231480583, -0.0002307248149}},
+     {{0.5925320577, -0.1757678135, 0.01505928619, 0.000564515273},
+      {0.1014815858, -0.06589186703, 0.01272886114, -0.0007316646956},
+      {-0.007258481865, 0.001096195486, 0.0003934994223, -4.12701925e-05}},
+     {{0.06469649321, -0.0236701437, 0.002902096474, -5.896963079e-05},
+      {0.001925008108, -0.002869809258, 0.0008000589141, -6.063713228e-05},
+      {-0.0003477407336, 6.959756487e-05, 1.097287507e-05, -1.650964693e-06}}},
+};
+
+__device__ inline double dirichlet_grad_one(double x, double alpha, double total) {
+    const double beta = total - alpha;
+    const double boundary = total * x * (1.0 - x);
+    if (x <= 0.5 && boundary < 2.5) return beta_grad_alpha_small(x, alpha, beta);
+    if (x >= 0.5 && boundary < 0.75) return -beta_grad_beta_small(1.0 - x, beta, alpha);
+    if (alpha > 6.0 && beta > 6.0) return beta_grad_alpha_mid(x, alpha, beta);
+    // rational correction to an analytic approximation (kDirGradC below)
+    const auto& c = kDirGradC;
+    const double u = log(x);
+    const double a = log(alpha) - u;
+    const double b = log(total) - a;
+    const double pow_u[3] = {1.0, u, u * u};
+    const double pow_a[3] = {1.0, a, a * a};
+    double p = 0.0, q = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double ua = pow_u[i] * pow_a[j];
+            p += ua * (c[0][i][j][0] + b * (c[0][i][j][1] + b * (c[0][i][j][2] + b * c[0][i][j][3])));
+            q += ua * (c[1][i][j][0] + b * (c[1][i][j][1] + b * (c[1][i][j][2] + b * c[1][i][j][3])));
+        }
+    }
+    const double approx = x * (digamma(total) - digamma(alpha)) / beta;
+    return p / q * approx;
+}
+
+// ---------------------------------------------------------------------------
+// Counter-based RNG: rocRAND Philox4x32-10 device API, keyed by
+// (seed, site, element) through the subsequence and by the SVI step through the
+// offset, so draws do not depend on grid shape or on the number of GPUs.
+// ---------------------------------------------------------------------------
+enum RngSite : unsigned long long { kSiteTarget = 1, kSitePi = 2, kSiteNoise = 3, kSiteAux = 4 };
+
+struct Rng {
+    rocrand_state_philox4x32_10 st;
+    double spare;
+    bool has_spare;
+    __device__ __forceinline__ Rng(unsigned long long seed, RngSite site,
+                                   unsigned long long element, unsigned long long offset) {
+        rocrand_init(seed, ((unsigned long long)site << 48) + element, offset, &st);
+        has_spare = false;
+        spare = 0.0;
+    }
+    __device__ __forceinline__ double normal() {
+        if (has_spare) {
+            has_spare = false;
+            return spare;
+        }
+        const double2 n = rocrand_normal_double2(&st);
+        spare = n.y;
+        has_spare = true;
+        return n.x;
+    }
+    // uniform on (0, 1]
+    __device__ __forceinline__ double uniform() { return rocrand_uniform_double(&st); }
+};
+
+// Gamma(alpha, 1) by Marsaglia & Tsang (2000) with the alpha < 1 boost
+// (the method torch's sample_gamma uses for Dirichlet draws).
+__device__ inline double sample_gamma(double alpha, Rng& rng) {
+    double scale = 1.0;
+    if (alpha < 1.0) {
+        if (alpha == 0.0) return 0.0;
+        scale = pow(rng.uniform(), 1.0 / alpha);
+        alpha += 1.0;
+    }
+    const double d = alpha - 1.0 / 3.0;
+    const double c = 1.0 / sqrt(9.0 * d);
+    for (int it = 0; it < 64; ++it) {  // acceptance >= 95 % per round; bounded for safety
+        double x, y;
+        do {
+            x = rng.normal();
+            y = 1.0 + c * x;
+        } while (y <= 0.0);
+        const double v = y * y * y;
+        const double u = rng.uniform();
+        const double xx = x * x;
+        if (u < 1.0 - 0.0331 * xx * xx) return scale * d * v;
+        if (log(u) < 0.5 * xx + d * (1.0 - v + log(v))) return scale * d * v;
+    }
+    return scale * d;  // unreachable in practice (p < 1e-80)
+}
+
+}  // namespace bean

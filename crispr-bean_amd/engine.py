@@ -1,0 +1,351 @@
+"""Host-side driver of the HIP SVI step.
+
+Owns the torch tensors (parameters, ClippedAdam moments, gradients, loss
+history) whose device pointers are bound into a ``libbean_hip`` handle, and
+exposes the three operations the reference gets from Pyro
+(``bean/model/run.py:366-396``): one ELBO+gradient evaluation, one ClippedAdam
+update, and the fused ``for t in range(num_steps): svi.step(data)`` loop.
+
+PyTorch is used for device memory and streams only; all arithmetic of the step
+happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PI_NOISE_SD = 0.655  # bean/model/utils.py:133
+POSITIVE = ("mu_scale", "sd_scale", "alpha_pi", "noise_scale")
+
+
+def _quantile_edges(upper: torch.Tensor, lower: torch.Tensor):
+    """z-scores of the bin edges; quantiles exactly 1.0 / 0.0 are open edges
+    (``bean/model/utils.py:48-54``)."""
+    std = torch.distributions.Normal(0.0, 1.0)
+    uq, lq = upper.detach().cpu().double(), lower.detach().cpu().double()
+    z_hi = torch.full_like(uq, float("inf"))
+    z_lo = torch.full_like(lq, float("-inf"))
+    z_hi[uq != 1.0] = std.icdf(uq[uq != 1.0])
+    z_lo[lq != 0.0] = std.icdf(lq[lq != 0.0])
+    return z_hi, z_lo
+
+
+class HipSVI:
+    """One model family bound to one screen on one GPU."""
+
+    def __init__(
+        self,
+        family: str,
+        data,
+        *,
+        use_bcmatch: bool = True,
+        scale_by_accessibility: bool = False,
+        fit_noise: bool = True,
+        sd_scale: float = 0.01,
+        prior_params: Optional[dict] = None,
+        initial_lr: float = 0.01,
+        gamma: float = 0.1,
+        num_steps: int = 2000,
+        loss_capacity: Optional[int] = None,
+        mask_thres: int = 10,
+        dump_noise: bool = False,
+        device=None,
+    ):
+        if family not in _lib.FAMILY:
+            raise ValueError(f"unknown model family {family!r}")
+        if getattr(data, "selection", "sorting") != "sorting":
+            raise NotImplementedError("survival screens are not implemented in the HIP engine yet")
+        if family == "MultiMixtureNormal":
+            raise NotImplementedError("tiling (MultiMixtureNormal) is not implemented in the HIP engine yet")
+        if not torch.cuda.is_available():
+            raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.family = family
+        self.data = data
+        data.validate()
+        dev = self.device
+        R, B, G = data.n_reps, data.n_condits, data.n_guides
+        mixture = family == "MixtureNormal"
+        acc = bool(scale_by_accessibility) and mixture
+        self.scale_by_accessibility = acc
+        self.fit_noise = bool(fit_noise) and acc
+        has_bc = getattr(data, "X_bcmatch_masked", None) is not None
+        self.use_bcmatch = bool(use_bcmatch) and has_bc
+        if mixture and not has_bc:
+            raise ValueError("MixtureNormal needs barcode-matched counts (X_bcmatch)")
+        T = 1 if family == "ControlNormal" else data.n_targets
+        self.T = T
+        if family == "ControlNormal":
+            toff = torch.tensor([0, G], dtype=torch.int32)
+            g2t = torch.zeros(G, dtype=torch.int32)
+            max_len = G
+        else:
+            off64 = data.target_offsets.cpu()
+            toff = off64.to(torch.int32)
+            g2t = data.guide_to_target.cpu()
+            max_len = int(data.target_lengths.max())
+        flags = 0
+        if self.use_bcmatch:
+            flags |= _lib.FLAG_USE_BCMATCH
+        if acc:
+            flags |= _lib.FLAG_SCALE_BY_ACC
+        if self.fit_noise:
+            flags |= _lib.FLAG_FIT_NOISE
+        if dump_noise:
+            flags |= _lib.FLAG_DUMP_PI
+        self.prior_params = prior_params
+        if prior_params is not None and ("mu_loc" in prior_params or "mu_scale" in prior_params):
+            flags |= _lib.FLAG_PRIOR_NORMAL_MU
+        self.num_steps = int(num_steps)
+        self.lrd = float(gamma) ** (1.0 / self.num_steps)
+        self.initial_lr = float(initial_lr)
+        n_ctrl = int(data.allele_counts_control.shape[1]) if mixture else 0
+        shape = _lib.bean_hip_shape(
+            family=_lib.FAMILY[family], selection=0, flags=flags, n_reps=R, n_condits=B, n_guides=G,
+            n_targets=T, n_max_alleles=2, n_edits=0, n_ctrl=n_ctrl, mask_thres=int(mask_thres),
+            reserved=max_len, sd_prior_scale=1.0 if family == "ControlNormal" else float(sd_scale),
+            initial_lr=self.initial_lr, lrd=self.lrd, clip_norm=10.0,
+        )
+        self._shape = shape
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.bean_hip_create(ctypes.byref(shape), ctypes.byref(handle)), "create")
+        self._h = handle
+        self._keep: Dict[str, torch.Tensor] = {}
+        self.stream = torch.cuda.Stream(device=dev)
+
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+        f64 = lambda t: t.to(dev, torch.float64).contiguous()
+        z_hi, z_lo = _quantile_edges(data.upper_bounds, data.lower_bounds)
+        self._bind("X", f32(data.X_masked))
+        self._bind("REPGUIDE", data.repguide_mask.to(dev, torch.uint8).contiguous())
+        self._bind("SIZE_FACTOR", f64(data.size_factor))
+        self._bind("SAMPLE_MASK", f64(data.sample_mask))
+        self._bind("A0", f64(data.a0))
+        self._bind("Z_HI", f64(z_hi))
+        self._bind("Z_LO", f64(z_lo))
+        self._bind("TARGET_OFFSETS", toff.to(dev).contiguous())
+        self._bind("GUIDE_TO_TARGET", g2t.to(dev).contiguous())
+        if self.use_bcmatch:
+            self._bind("X_BC", f32(data.X_bcmatch_masked))
+            self._bind("SIZE_FACTOR_BC", f64(data.size_factor_bcmatch))
+            self._bind("A0_BC", f64(data.a0_bcmatch))
+        if mixture:
+            self._bind("ALLELE_CTRL", f32(data.allele_counts_control))
+            self._bind("PI_A0", f64(data.pi_a0))
+        if acc:
+            if data.guide_accessibility is None:
+                raise ValueError("scale_by_accessibility needs data.guide_accessibility")
+            self._bind("ACCESSIBILITY", f64(data.guide_accessibility))
+        if prior_params is not None:
+            for key, slot in (("mu_loc", "PRIOR_MU_LOC"), ("mu_scale", "PRIOR_MU_SCALE"),
+                              ("sd_loc", "PRIOR_SD_LOC"), ("sd_scale", "PRIOR_SD_SCALE")):
+                if key in prior_params:
+                    v = torch.as_tensor(prior_params[key], dtype=torch.float64).reshape(-1)
+                    if v.numel() == 1:
+                        v = v.expand(T)
+                    self._bind(slot, f64(v))
+
+        # ---- parameters (unconstrained), as pyro.param initialises them
+        pshape = () if family == "ControlNormal" else (T, 1)
+        init = {
+            "mu_loc": torch.zeros(pshape), "mu_scale": torch.zeros(pshape),
+            "sd_loc": torch.zeros(pshape), "sd_scale": torch.zeros(pshape),
+        }
+        if mixture:
+            init["alpha_pi"] = torch.zeros((G, 2))
+        if self.fit_noise:
+            init["noise_loc"] = torch.zeros(G)
+            init["noise_scale"] = torch.full((G,), float(np.log(PI_NOISE_SD)))
+        self.unconstrained: Dict[str, torch.Tensor] = {}
+        self.grads: Dict[str, torch.Tensor] = {}
+        self._m: Dict[str, torch.Tensor] = {}
+        self._v: Dict[str, torch.Tensor] = {}
+        for i, name in enumerate(_lib.PARAM_ORDER):
+            if name not in init:
+                continue
+            p = init[name].to(dev, torch.float32).contiguous()
+            self.unconstrained[name] = p
+            self.grads[name] = torch.zeros_like(p)
+            self._m[name] = torch.zeros_like(p)
+            self._v[name] = torch.zeros_like(p)
+            self._bind_slot(_lib.BUF["P"] + i, p, f"P.{name}")
+            self._bind_slot(_lib.BUF["G"] + i, self.grads[name], f"G.{name}")
+            self._bind_slot(_lib.BUF["M"] + i, self._m[name], f"M.{name}")
+            self._bind_slot(_lib.BUF["V"] + i, self._v[name], f"V.{name}")
+        cap = int(loss_capacity) if loss_capacity is not None else self.num_steps + 8
+        self.loss_hist = torch.zeros(max(cap, 1), dtype=torch.float64, device=dev)
+        self._bind("LOSS_HIST", self.loss_hist)
+        self._noise_out: Dict[str, torch.Tensor] = {}
+        if dump_noise:
+            self._noise_out["eps_mu"] = torch.zeros(T, dtype=torch.float64, device=dev)
+            self._noise_out["eps_sd"] = torch.zeros(T, dtype=torch.float64, device=dev)
+            self._bind("EPS_MU_OUT", self._noise_out["eps_mu"])
+            self._bind("EPS_SD_OUT", self._noise_out["eps_sd"])
+            if mixture:
+                self._noise_out["pi"] = torch.zeros((R, G, 2), dtype=torch.float64, device=dev)
+                self._bind("PI_OUT", self._noise_out["pi"])
+            if acc:
+                self._noise_out["eps_noise"] = torch.zeros(G, dtype=torch.float64, device=dev)
+                self._bind("EPS_NOISE_OUT", self._noise_out["eps_noise"])
+        self.steps_done = 0
+        with self._on_stream():
+            _lib.check(self.lib.bean_hip_prepare(self._h, self._sptr()), "prepare")
+
+    # -------------------------------------------------------------- plumbing
+    def _bind(self, slot_name: str, t: torch.Tensor):
+        self._bind_slot(_lib.BUF[slot_name], t, slot_name)
+
+    def _bind_slot(self, slot: int, t: Optional[torch.Tensor], key: str):
+        if t is None:
+            self._keep.pop(key, None)
+            _lib.check(self.lib.bean_hip_bind(self._h, slot, None, 0), f"bind {key}")
+            return
+        assert t.is_cuda and t.is_contiguous(), key
+        self._keep[key] = t
+        _lib.check(
+            self.lib.bean_hip_bind(self._h, slot, ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size()),
+            f"bind {key}",
+        )
+
+    def _sptr(self):
+        return ctypes.c_void_p(self.stream.cuda_stream)
+
+    class _StreamScope:
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            self.eng.stream.wait_stream(torch.cuda.current_stream(self.eng.device))
+            return self
+
+        def __exit__(self, *exc):
+            torch.cuda.current_stream(self.eng.device).wait_stream(self.eng.stream)
+            return False
+
+    def _on_stream(self):
+        return HipSVI._StreamScope(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.bean_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ operations
+    def set_noise(self, noise: Optional[dict]):
+        """Inject the draws of the next evaluation(s) (parity tests);
+        ``None`` returns to the in-kernel generator."""
+        dev = self.device
+        names = {"eps_mu": "EPS_MU_IN", "eps_sd": "EPS_SD_IN", "pi": "PI_IN", "eps_noise": "EPS_NOISE_IN"}
+        for key, slot in names.items():
+            t = None if noise is None else noise.get(key)
+            if t is None:
+                if slot in self._keep:
+                    self._bind_slot(_lib.BUF[slot], None, slot)
+                continue
+            t = torch.as_tensor(t).to(dev, torch.float64)
+            if key == "pi":
+                t = t.reshape(self.data.n_reps, self.data.n_guides, 2)
+            else:
+                t = t.reshape(-1)
+            self._bind(slot, t.contiguous())
+
+    def elbo_grad(self, step: int = 0, seed: int = 101, loss_index: int = 0):
+        """One ELBO evaluation: returns ``(loss, {name: grad})`` w.r.t. the
+        unconstrained parameters; parameters are not modified."""
+        with self._on_stream():
+            _lib.check(
+                self.lib.bean_hip_elbo_grad(self._h, int(seed), int(step), int(loss_index), self._sptr()),
+                "elbo_grad",
+            )
+        torch.cuda.synchronize(self.device)
+        return float(self.loss_hist[loss_index]), {k: v.clone() for k, v in self.grads.items()}
+
+    def drawn_noise(self) -> Dict[str, torch.Tensor]:
+        """Draws used by the last evaluation (needs ``dump_noise=True``)."""
+        out = {k: v.clone() for k, v in self._noise_out.items()}
+        if "pi" in out:
+            out["pi"] = out["pi"].unsqueeze(1)  # (R, 1, G, A) as the reference shapes it
+        if self.family != "ControlNormal":
+            for k in ("eps_mu", "eps_sd"):
+                if k in out:
+                    out[k] = out[k].reshape(self.T, 1)
+        else:
+            for k in ("eps_mu", "eps_sd"):
+                out[k] = out[k].reshape(())
+        return out
+
+    def adam(self, t: int):
+        with self._on_stream():
+            _lib.check(self.lib.bean_hip_adam(self._h, int(t), self._sptr()), "adam")
+
+    def run(self, n_steps: int, seed: int = 101, graph_chunk: int = 50, first_step: Optional[int] = None):
+        """Enqueue ``n_steps`` fused SVI steps (no host synchronisation)."""
+        first = self.steps_done if first_step is None else int(first_step)
+        if first + n_steps > self.loss_hist.numel():
+            raise ValueError("loss history too small: raise num_steps / loss_capacity")
+        with self._on_stream():
+            _lib.check(
+                self.lib.bean_hip_svi_run(self._h, int(seed), first, int(n_steps), int(graph_chunk), self._sptr()),
+                "svi_run",
+            )
+        self.steps_done = first + n_steps
+
+    def losses(self):
+        torch.cuda.synchronize(self.device)
+        return self.loss_hist[: self.steps_done].cpu().tolist()
+
+    def set_profile(self, enable: bool):
+        _lib.check(self.lib.bean_hip_set_profile(self._h, int(bool(enable))), "set_profile")
+
+    def get_profile(self):
+        avg, n = ctypes.c_double(0.0), ctypes.c_uint64(0)
+        _lib.check(self.lib.bean_hip_get_profile(self._h, ctypes.byref(avg), ctypes.byref(n)), "get_profile")
+        return avg.value, n.value
+
+    @property
+    def step_bytes(self) -> int:
+        return int(self.lib.bean_hip_step_bytes(self._h))
+
+    @property
+    def dominant_kernel(self) -> str:
+        return self.lib.bean_hip_dominant_kernel(self._h).decode()
+
+    def constrained(self) -> Dict[str, torch.Tensor]:
+        """Constrained parameter values, as ``pyro.get_param_store()[name]``."""
+        torch.cuda.synchronize(self.device)
+        return {k: (v.exp() if k in POSITIVE else v.clone()) for k, v in self.unconstrained.items()}
+
+
+def test_special(op: int, a, x=None, b=None, device="cuda:0"):
+    """Evaluate the device special functions (``bean_hip_test_special``)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    a = torch.as_tensor(a, dtype=torch.float64, device=dev).contiguous()
+    x = torch.zeros_like(a) if x is None else torch.as_tensor(x, dtype=torch.float64, device=dev).contiguous()
+    b = torch.zeros_like(a) if b is None else torch.as_tensor(b, dtype=torch.float64, device=dev).contiguous()
+    o0, o1 = torch.zeros_like(a), torch.zeros_like(a)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(
+        lib.bean_hip_test_special(
+            int(op), a.numel(), ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(x.data_ptr()),
+            ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(o0.data_ptr()), ctypes.c_void_p(o1.data_ptr()),
+            ctypes.c_void_p(s),
+        ),
+        "test_special",
+    )
+    torch.cuda.synchronize(dev)
+    return o0, o1

@@ -1,0 +1,188 @@
+"""Deterministic synthetic screens of the BASELINE.json shapes.
+
+There is no network for datasets, so ``bench.py`` and the parity tests draw
+screens from the generative model itself: guides grouped
+``guides_per_target`` per target, true effects ``mu ~ 0.9*delta_0 + 0.1*N(0,1)``,
+editing rate ``pi ~ Beta(2,5)``, Dirichlet-Multinomial counts with the
+reference's fallback precision trend ``a0 = exp(-1.510 + 0.7861 log n)``
+(``bean/preprocessing/get_alpha0.py:105``).  The derived tensors (size factors,
+``a0``, ``a0_bcmatch``, ``pi_a0``, masks) are then computed from the counts with
+the same preprocessing the reference applies to a real screen, so the object
+returned honours the full ``ScreenData`` attribute contract.
+
+Sorting screens contain ``n_bins`` sorted samples plus one control ("bulk",
+quantiles (0, 1)) sample per replicate, and - as in the reference, where the
+control sample always stays inside ``screen_selected`` (``bean/cli/run.py:114``,
+SURVEY.md F4) - the control is one of the ``n_condits = n_bins + 1`` conditions
+of ``X``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+from scipy.special import ndtr, ndtri
+
+from .alpha0 import fitted_alpha0, fitted_pi_alpha0, pred_alpha0
+from .data_class import ScreenTensors
+
+BASE_SEED = 20240501
+DEFAULT_BINS = ((0.0, 0.2), (0.2, 0.4), (0.6, 0.8), (0.8, 1.0))
+
+
+def _size_factor(X_gs: np.ndarray) -> np.ndarray:
+    """Normalised column means (data_class.py:237-251). X_gs is (G, n_samples)."""
+    sf = X_gs.mean(axis=0)
+    return sf / sf.mean()
+
+
+def _dirmult_counts(rng, n_total, alpha):
+    """Counts (..., K) ~ DirMult(n_total (...,), alpha (..., K))."""
+    g = rng.standard_gamma(alpha)
+    g = np.maximum(g, 1e-300)
+    p = g / g.sum(-1, keepdims=True)
+    flat_p = p.reshape(-1, p.shape[-1])
+    flat_n = n_total.reshape(-1)
+    out = rng.multinomial(flat_n, flat_p)
+    return out.reshape(p.shape)
+
+
+def _target_layout(n_guides: int, guides_per_target: int):
+    n_targets = -(-n_guides // guides_per_target)
+    lengths = np.full(n_targets, guides_per_target, dtype=np.int64)
+    lengths[-1] = n_guides - guides_per_target * (n_targets - 1)
+    g2t = np.repeat(np.arange(n_targets), lengths)
+    return n_targets, lengths, g2t
+
+
+def make_sorting_variant_screen(
+    n_guides: int = 50_000,
+    n_reps: int = 5,
+    bins=DEFAULT_BINS,
+    guides_per_target: int = 5,
+    depth_per_guide: float = 500.0,
+    seed: int = BASE_SEED,
+    with_accessibility: bool = False,
+    frac_effect: float = 0.1,
+    mask_fraction: float = 0.0,
+) -> ScreenTensors:
+    """Variant sorting screen (BASELINE configs 2/4 and the metric shape).
+
+    Returns CPU tensors; call ``.to("cuda")`` to move them.
+    ``mask_fraction`` > 0 knocks out that fraction of (rep, guide) pairs through
+    ``repguide_mask`` and zeroes one sample via ``sample_mask`` to exercise the
+    masking paths in tests.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    R, G = n_reps, n_guides
+    lo = np.array([b[0] for b in bins] + [0.0])
+    hi = np.array([b[1] for b in bins] + [1.0])
+    # conditions sorted by (upper, lower) as data_class.py:948-964 does
+    order = np.lexsort((lo, hi))
+    lo, hi = lo[order], hi[order]
+    B = len(lo)
+
+    T, lengths, g2t = _target_layout(G, guides_per_target)
+    mu_true = np.where(rng.random(T) < frac_effect, rng.normal(0.0, 1.0, T), 0.0)
+    sd_true = np.ones(T)
+    is_negctrl = rng.random(T) < 0.05
+    mu_true[is_negctrl] = 0.0
+    pi_true = rng.beta(2.0, 5.0, G)
+    abundance = np.exp(rng.normal(0.0, 0.5, G))
+    abundance /= abundance.mean()
+    acc = np.exp(rng.normal(1.0, 0.8, G)) if with_accessibility else None
+    pi_endo = pi_true
+    if with_accessibility:
+        # endogenous editing rate ~ reporter rate scaled by accessibility
+        # (bean/model/utils.py:79-103), used only to generate data
+        pi_endo = np.clip(pi_true * np.exp(-1.9458) * acc**0.2513, 1e-3, 1 - 1e-3)
+
+    # bin probabilities of the two mixture components
+    with np.errstate(invalid="ignore"):
+        z_hi = np.where(hi >= 1.0, np.inf, ndtri(np.clip(hi, 1e-300, 1)))
+        z_lo = np.where(lo <= 0.0, -np.inf, ndtri(np.clip(lo, 1e-300, 1)))
+    p_wt = ndtr(z_hi) - ndtr(z_lo)  # (B,)
+    mu_g, sd_g = mu_true[g2t], sd_true[g2t]
+    p_ed = ndtr((z_hi[:, None] - mu_g[None, :]) / sd_g[None, :]) - ndtr(
+        (z_lo[:, None] - mu_g[None, :]) / sd_g[None, :]
+    )  # (B, G)
+    e = (1 - pi_endo)[None, :] * p_wt[:, None] + pi_endo[None, :] * p_ed  # (B, G)
+
+    depth = rng.uniform(0.7, 1.3, (R, B))  # per-sample sequencing depth factor
+    # the control sample holds all cells (p = 1): sequence it as deep as one bin
+    is_ctrl = (lo == 0.0) & (hi == 1.0)
+    depth[:, is_ctrl] *= 0.2
+    prop = e[None, :, :] * depth[:, :, None]  # (R, B, G)
+    prop_g = prop / prop.sum(1, keepdims=True)
+    n_rg = rng.poisson(depth_per_guide * abundance[None, :] * prop.sum(1) / 0.2)
+    a0_true = np.exp(-1.510 + 0.7861 * np.log(np.maximum(n_rg, 1)))
+    alpha = np.moveaxis(prop_g, 1, -1) * a0_true[:, :, None]  # (R, G, B)
+    X = np.moveaxis(_dirmult_counts(rng, n_rg, alpha), -1, 1).astype(np.float64)
+    X_bc = rng.binomial(X.astype(np.int64), 0.8).astype(np.float64)
+
+    ctrl = int(np.nonzero(is_ctrl)[0][0])
+    X_bc_ctrl = X_bc[:, ctrl : ctrl + 1, :]  # (R, 1, G)
+    edited = rng.binomial(X_bc_ctrl.astype(np.int64), pi_true[None, None, :]).astype(
+        np.float64
+    )
+    allele_counts_control = np.stack([X_bc_ctrl - edited, edited], axis=-1)
+
+    sample_mask = np.ones((R, B), dtype=np.int64)
+    repguide = np.ones((R, G), dtype=bool)
+    if mask_fraction > 0:
+        repguide &= rng.random((R, G)) >= mask_fraction
+        sample_mask[R - 1, 0] = 0
+
+    # size factors over all samples of the screen, as ScreenData.__init__ does
+    sf = _size_factor(X.reshape(R * B, G).T).reshape(R, B)
+    sf_bc = _size_factor(X_bc.reshape(R * B, G).T).reshape(R, B)
+
+    a0, popt = fitted_alpha0(X, sf, sample_mask)
+    a0_bc = pred_alpha0(X_bc, sf_bc, popt, sample_mask)
+    pi_a0, _ = fitted_pi_alpha0(allele_counts_control, sf[:, ctrl : ctrl + 1])
+
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32)
+    f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64)
+    sm = torch.as_tensor(sample_mask)
+    Xt, Xbt = f32(X), f32(X_bc)
+    repguide_t = torch.as_tensor(repguide) & ~(Xt == 0).any(dim=1)
+    data = ScreenTensors(
+        n_reps=R,
+        n_condits=B,
+        n_guides=G,
+        n_targets=T,
+        n_max_alleles=2,
+        X=Xt,
+        X_masked=Xt * sm[:, :, None],
+        X_bcmatch=Xbt,
+        X_bcmatch_masked=Xbt * sm[:, :, None],
+        X_control=Xt[:, ctrl : ctrl + 1, :].clone(),
+        X_bcmatch_control=Xbt[:, ctrl : ctrl + 1, :].clone(),
+        sample_mask=sm,
+        control_sample_mask=sm[:, ctrl : ctrl + 1].clone(),
+        repguide_mask=repguide_t,
+        size_factor=f64(sf),
+        size_factor_bcmatch=f64(sf_bc),
+        size_factor_control=f64(sf[:, ctrl : ctrl + 1]),
+        size_factor_bcmatch_control=f64(sf_bc[:, ctrl : ctrl + 1]),
+        a0=f64(a0),
+        a0_bcmatch=f64(a0_bc),
+        pi_a0=f64(pi_a0),
+        allele_counts_control=f32(allele_counts_control),
+        upper_bounds=f64(hi),
+        lower_bounds=f64(lo),
+        target_lengths=torch.as_tensor(lengths),
+        guide_accessibility=f64(acc) if acc is not None else None,
+        popt=popt,
+    )
+    data.selection, data.library_design = "sorting", "variant"
+    data.truth = {
+        "mu": mu_true,
+        "sd": sd_true,
+        "pi": pi_true,
+        "negctrl_target": is_negctrl,
+    }
+    data.negctrl_guide_idx = np.nonzero(is_negctrl[g2t])[0]
+    data.validate()
+    return data

@@ -1,0 +1,212 @@
+/*
+ * bean_hip.h - C ABI of the MI355X-native BEAN SVI step (libbean_hip.so).
+ *
+ * The reference has no FFI boundary for this path: the seam is the Python call
+ *   run_inference(model, guide, data, initial_lr, gamma, num_steps)
+ *       (bean/model/run.py:347-396)
+ * which drives pyro.infer.SVI over the model/guide pairs of
+ * bean/model/model.py and bean/model/survival_model.py.  This header is the
+ * C-ABI a maintainer would bind (ctypes) to replace the body
+ * of that loop.  Entry points and what they replace:
+ *
+ *   bean_hip_elbo_grad   one Trace_ELBO.loss_and_grads evaluation
+ *                        (svi.step minus the optimiser; run.py:377)
+ *   bean_hip_adam        pyro.optim.ClippedAdam update (run.py:371)
+ *   bean_hip_svi_run     the whole "for t in range(num_steps): svi.step(data)"
+ *                        loop (run.py:376-380) with the loss history kept on
+ *                        the device
+ *
+ * Conventions
+ *   - plain C: opaque handle, int status codes (0 = ok, < 0 = error; the message
+ *     is available from bean_hip_last_error()); nothing throws across the ABI.
+ *   - every data / parameter / optimiser-state / gradient buffer is a
+ *     caller-owned DEVICE pointer bound to a slot with bean_hip_bind(); the
+ *     library never frees or retains them beyond the handle's lifetime.  The
+ *     handle owns only scratch workspace.
+ *   - all launches go to the hipStream_t passed in (void* here so that the
+ *     header needs no HIP include); no call synchronises the host unless noted.
+ *   - one handle per (device, stream); calls on one handle are serialised by
+ *     the caller.
+ *   - random draws come from a counter-based generator keyed by
+ *     (seed, site, element, step): results do not depend on grid shape or on
+ *     how guides are sharded across GPUs.
+ *
+ * Tensor layouts (R reps, B conditions, G guides, T targets, A alleles,
+ * C control conditions) follow the reference's ScreenData contract
+ * (bean/preprocessing/data_class.py): counts are
+ * (R, B, G) float32 with G contiguous.
+ */
+#ifndef BEAN_HIP_H
+#define BEAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bean_hip_ctx bean_hip_ctx;
+
+/* model families: bean/model/run.py:399-474 (identify_model_guide) */
+enum bean_hip_family {
+    BEAN_FAMILY_NORMAL = 0,          /* NormalModel/NormalGuide            model.py:19,754  */
+    BEAN_FAMILY_CONTROL_NORMAL = 1,  /* ControlNormalModel/Guide           model.py:168,861 */
+    BEAN_FAMILY_MIXTURE_NORMAL = 2,  /* MixtureNormalModel/Guide           model.py:378,785 */
+    BEAN_FAMILY_MULTI_MIXTURE = 3    /* MultiMixtureNormalModel/Guide      model.py:550,878 */
+};
+
+enum bean_hip_selection { BEAN_SELECTION_SORTING = 0, BEAN_SELECTION_SURVIVAL = 1 };
+
+enum bean_hip_flags {
+    BEAN_FLAG_USE_BCMATCH = 1,     /* second DirMult site on X_bcmatch (model.py:536-547) */
+    BEAN_FLAG_SCALE_BY_ACC = 2,    /* scale_pi_by_accessibility (utils.py:106-178)         */
+    BEAN_FLAG_FIT_NOISE = 4,       /* guide learns noise_loc/noise_scale (utils.py:144-155) */
+    BEAN_FLAG_PRIOR_NORMAL_MU = 8, /* --prior-params: Normal instead of Laplace (model.py:408-420) */
+    BEAN_FLAG_DUMP_PI = 16         /* write the Dirichlet draws to BEAN_BUF_PI_OUT (tests)  */
+};
+
+typedef struct bean_hip_shape {
+    int32_t family;        /* enum bean_hip_family */
+    int32_t selection;     /* enum bean_hip_selection */
+    int32_t flags;         /* OR of enum bean_hip_flags */
+    int32_t n_reps;        /* R */
+    int32_t n_condits;     /* B: sort bins incl. the control pseudo-bin, or timepoints */
+    int32_t n_guides;      /* G */
+    int32_t n_targets;     /* T (variant) */
+    int32_t n_max_alleles; /* A (2 in variant mode) */
+    int32_t n_edits;       /* E (tiling) */
+    int32_t n_ctrl;        /* C: control conditions in allele_counts_control */
+    int32_t mask_thres;    /* guides with sum_b x <= mask_thres are masked (10) */
+    int32_t reserved;
+    double sd_prior_scale; /* LogNormal prior scale of sd_targets (0.01; 1.0 for ControlNormal) */
+    double initial_lr;     /* ClippedAdam lr (0.01) */
+    double lrd;            /* per-step lr decay gamma ** (1 / num_steps) */
+    double clip_norm;      /* 10 */
+} bean_hip_shape;
+
+/* Buffer slots.  dtype / shape in brackets; "opt" = only for some families. */
+enum bean_hip_buf {
+    /* ---- data (read-only) */
+    BEAN_BUF_X = 0,           /* f32 (R,B,G)   X_masked                               */
+    BEAN_BUF_X_BC,            /* f32 (R,B,G)   X_bcmatch_masked                  opt  */
+    BEAN_BUF_ALLELE_CTRL,     /* f32 (R,C,G,A) allele_counts_control             opt  */
+    BEAN_BUF_REPGUIDE,        /* u8  (R,G)     repguide_mask                          */
+    BEAN_BUF_SIZE_FACTOR,     /* f64 (R,B)                                            */
+    BEAN_BUF_SIZE_FACTOR_BC,  /* f64 (R,B)                                       opt  */
+    BEAN_BUF_SAMPLE_MASK,     /* f64 (R,B)     0/1                                    */
+    BEAN_BUF_A0,              /* f64 (G)                                              */
+    BEAN_BUF_A0_BC,           /* f64 (G)                                         opt  */
+    BEAN_BUF_PI_A0,           /* f64 (G)                                         opt  */
+    BEAN_BUF_Z_HI,            /* f64 (B)  Phi^-1(upper quantile), +inf where it is 1  */
+    BEAN_BUF_Z_LO,            /* f64 (B)  Phi^-1(lower quantile), -inf where it is 0  */
+    BEAN_BUF_TARGET_OFFSETS,  /* i32 (T+1) exclusive prefix sum of target_lengths     */
+    BEAN_BUF_GUIDE_TO_TARGET, /* i32 (G)                                              */
+    BEAN_BUF_ACCESSIBILITY,   /* f64 (G)                                         opt  */
+    BEAN_BUF_PRIOR_MU_LOC,    /* f64 (T)  --prior-params                         opt  */
+    BEAN_BUF_PRIOR_MU_SCALE,  /* f64 (T)                                         opt  */
+    BEAN_BUF_PRIOR_SD_LOC,    /* f64 (T)                                         opt  */
+    BEAN_BUF_PRIOR_SD_SCALE,  /* f64 (T)                                         opt  */
+    /* ---- parameters: unconstrained values as Pyro's param store keeps them */
+    BEAN_BUF_P_MU_LOC = 32,   /* f32 (T)                                              */
+    BEAN_BUF_P_MU_SCALE,      /* f32 (T)   log mu_scale                               */
+    BEAN_BUF_P_SD_LOC,        /* f32 (T)                                              */
+    BEAN_BUF_P_SD_SCALE,      /* f32 (T)   log sd_scale                               */
+    BEAN_BUF_P_ALPHA_PI,      /* f32 (G,A) log alpha_pi                          opt  */
+    BEAN_BUF_P_NOISE_LOC,     /* f32 (G)                                         opt  */
+    BEAN_BUF_P_NOISE_SCALE,   /* f32 (G)   log noise_scale                       opt  */
+    /* ---- gradients w.r.t. the unconstrained parameters (bean_hip_elbo_grad) */
+    BEAN_BUF_G_MU_LOC = 48,
+    BEAN_BUF_G_MU_SCALE,
+    BEAN_BUF_G_SD_LOC,
+    BEAN_BUF_G_SD_SCALE,
+    BEAN_BUF_G_ALPHA_PI,
+    BEAN_BUF_G_NOISE_LOC,
+    BEAN_BUF_G_NOISE_SCALE,
+    /* ---- ClippedAdam first / second moments, same shapes as the parameters */
+    BEAN_BUF_M_MU_LOC = 64,
+    BEAN_BUF_M_MU_SCALE,
+    BEAN_BUF_M_SD_LOC,
+    BEAN_BUF_M_SD_SCALE,
+    BEAN_BUF_M_ALPHA_PI,
+    BEAN_BUF_M_NOISE_LOC,
+    BEAN_BUF_M_NOISE_SCALE,
+    BEAN_BUF_V_MU_LOC = 80,
+    BEAN_BUF_V_MU_SCALE,
+    BEAN_BUF_V_SD_LOC,
+    BEAN_BUF_V_SD_SCALE,
+    BEAN_BUF_V_ALPHA_PI,
+    BEAN_BUF_V_NOISE_LOC,
+    BEAN_BUF_V_NOISE_SCALE,
+    /* ---- injected / exported noise (parity tests) */
+    BEAN_BUF_EPS_MU_IN = 96,  /* f64 (T)   standard-normal draws for mu_targets  opt  */
+    BEAN_BUF_EPS_SD_IN,       /* f64 (T)                                         opt  */
+    BEAN_BUF_PI_IN,           /* f64 (R,G,A) Dirichlet draws                     opt  */
+    BEAN_BUF_EPS_NOISE_IN,    /* f64 (G)                                         opt  */
+    BEAN_BUF_EPS_MU_OUT,      /* f64 (T)   draws actually used                   opt  */
+    BEAN_BUF_EPS_SD_OUT,      /* f64 (T)                                         opt  */
+    BEAN_BUF_PI_OUT,          /* f64 (R,G,A)                                     opt  */
+    BEAN_BUF_EPS_NOISE_OUT,   /* f64 (G)                                         opt  */
+    /* ---- loss */
+    BEAN_BUF_LOSS_HIST = 112, /* f64 (capacity) one entry per SVI step                */
+    BEAN_BUF_COUNT = 128
+};
+
+const char* bean_hip_version(void);
+const char* bean_hip_last_error(void);
+
+/* Create / destroy a handle for one screen shape on the current HIP device.
+ * Allocates the scratch workspace (O(G + B*T) doubles). */
+int bean_hip_create(const bean_hip_shape* shape, bean_hip_ctx** out);
+int bean_hip_destroy(bean_hip_ctx* ctx);
+
+/* Bind a caller-owned device buffer to a slot; nbytes is checked against the
+ * size the shape implies (a mismatch is an error, nothing is launched). */
+int bean_hip_bind(bean_hip_ctx* ctx, int slot, void* device_ptr, uint64_t nbytes);
+
+/* Validate that every slot the family needs is bound, and run the one-off
+ * data-only precomputation (masks, log-factorial constants of the likelihoods).
+ * Must be called after the data slots are bound and before any step. */
+int bean_hip_prepare(bean_hip_ctx* ctx, void* stream);
+
+/* One ELBO evaluation with gradients: draws the step's noise (or reads the
+ * *_IN slots when bound), writes d loss / d param to the BEAN_BUF_G_* slots and
+ * the loss to loss_hist[loss_index].  Parameters are not modified. */
+int bean_hip_elbo_grad(bean_hip_ctx* ctx, uint64_t seed, uint64_t step,
+                       uint64_t loss_index, void* stream);
+
+/* ClippedAdam update of every bound parameter from the BEAN_BUF_G_* slots;
+ * t is the 1-based update count (lr_t = initial_lr * lrd ** t). */
+int bean_hip_adam(bean_hip_ctx* ctx, uint64_t t, void* stream);
+
+/* Fused SVI loop: n_steps x {draw, ELBO, gradient, ClippedAdam}, steps
+ * first_step .. first_step + n_steps - 1, loss of step s written to
+ * loss_hist[s].  Kernels are enqueued through a captured hipGraph of
+ * graph_chunk steps when graph_chunk > 0 (eager launches when 0). */
+int bean_hip_svi_run(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step,
+                     uint64_t n_steps, int32_t graph_chunk, void* stream);
+
+/* Introspection for bench.py / DESIGN.md: algorithmic bytes one step moves
+ * (each input read once, each parameter and moment read and written once) and
+ * the name of the dominant kernel. */
+uint64_t bean_hip_step_bytes(const bean_hip_ctx* ctx);
+const char* bean_hip_dominant_kernel(const bean_hip_ctx* ctx);
+
+/* Time (ms, HIP events on `stream`) of the dominant kernel averaged over the
+ * launches issued since the previous call; enable with profile != 0 in
+ * bean_hip_set_profile before running steps (eager mode only). */
+int bean_hip_set_profile(bean_hip_ctx* ctx, int32_t enable);
+int bean_hip_get_profile(bean_hip_ctx* ctx, double* avg_ms, uint64_t* launches);
+
+/* Unit-test hooks for the device special functions (n elements, device ptrs):
+ *   op 0: out0 = lgamma(a+x)-lgamma(a), out1 = digamma(a+x)-digamma(a)
+ *   op 1: out0 = lgamma(a),             out1 = digamma(a)
+ *   op 2: out0 = dirichlet_grad(x, a, total=b)
+ *   op 3: out0 = Phi(a)
+ *   op 4: out0, out1 = Dirichlet(a, b) draw (seed = x[0] bits, element index) */
+int bean_hip_test_special(int32_t op, uint64_t n, const double* a, const double* x,
+                          const double* b, double* out0, double* out1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEAN_HIP_H */
