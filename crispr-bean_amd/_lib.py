@@ -120,6 +120,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's): import it
+    # first so that this library binds to the one HIP runtime of the process.
+    # Loaded the other way round, two runtimes coexist and device discovery
+    # fails ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
