@@ -29,7 +29,8 @@
 namespace bean {
 
 constexpr double kEps = 1e-5;         // epsilon of get_alpha (utils.py:11)
-constexpr double kPiNoiseSd = 0.655;  // utils.py:133
+// utils.py:133; the reference builds Normal(0, 0.655) from Python floats, i.e. float32 tensors
+constexpr double kPiNoiseSd = (double)0.655f;
 constexpr double kAccA = 0.2513;      // utils.py:82
 constexpr float kAccBf = -1.9458f;    // utils.py:83 (exp taken in float32 there)
 constexpr double kHalfLog2PiC = 0.91893853320467274178;
@@ -116,11 +117,18 @@ __device__ __forceinline__ AdamCoef adam_coef(const DevArgs& c, unsigned long lo
     return k;
 }
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float grad, AdamCoef k) {
+    // every rounding is pinned (no implicit contraction) so that the stand-alone
+    // k_adam and the fused update inside k_param produce identical bits
+#pragma clang fp contract(off)
     const float gc = fminf(fmaxf(grad, -k.clip), k.clip);
-    m = m * 0.9f + gc * 0.1f;
-    v = v * 0.999f + (gc * gc) * 0.001f;
+    const float m9 = m * 0.9f;
+    m = fmaf(gc, 0.1f, m9);            // exp_avg.mul_(b1).add_(grad, alpha=1-b1)
+    const float v9 = v * 0.999f;
+    const float g2 = gc * gc;
+    v = fmaf(g2, 0.001f, v9);          // exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1-b2)
     const float denom = sqrtf(v) + 1e-8f;
-    p = p - k.step_size * (m / denom);
+    const float q = m / denom;
+    p = fmaf(-k.step_size, q, p);      // p.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
 template <bool ADAM>
@@ -187,7 +195,19 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) pf[i] = c.p[i][t];
             const double l0 = c.pr_sd_loc ? c.pr_sd_loc[t] : 0.0;
-            const double s0 = c.pr_sd_scale ? c.pr_sd_scale[t] : c.sd_prior_scale;
+            // LogNormal(sd_loc, sd_scale) prior: the default scale lives in a float32
+            // tensor in the reference (model.py:405-406), so torch forms scale**2 and
+            // log(scale) in float32; user-supplied --prior-params are taken as float64
+            double var0, logs0;
+            if (c.pr_sd_scale) {
+                const double s0 = c.pr_sd_scale[t];
+                var0 = s0 * s0;
+                logs0 = log(s0);
+            } else {
+                const float s0f = (float)c.sd_prior_scale;
+                var0 = (double)(s0f * s0f);
+                logs0 = (double)logf(s0f);
+            }
             if (FINISH) {
                 const double eps1 = c.eps_mu[t], eps2 = c.eps_sd[t];
                 const double mu = c.mu_t[t], y = c.y_t[t];
@@ -203,9 +223,9 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                     logp_mu = -kLog2 - fabs(mu);
                     dlogp_mu = mu > 0.0 ? -1.0 : (mu < 0.0 ? 1.0 : 0.0);
                 }
-                const double zz = (y - l0) / s0;
-                const double logp_sd = -y - log(s0) - kHalfLog2PiC - 0.5 * zz * zz;
-                const double dlogp_dy = -1.0 - zz / s0;
+                const double dy0 = y - l0;
+                const double logp_sd = -y - logs0 - kHalfLog2PiC - dy0 * dy0 / (2.0 * var0);
+                const double dlogp_dy = -1.0 - dy0 / var0;
                 const double logq_mu = -0.5 * eps1 * eps1 - (double)pf[1] - kHalfLog2PiC;
                 const double logq_sd = -y - 0.5 * eps2 * eps2 - (double)pf[3] - kHalfLog2PiC;
                 loss_fin = -logp_mu - logp_sd + logq_mu + logq_sd;
@@ -320,12 +340,14 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                     const double lpn = c.lpn[g], eps = c.eps_noise[g];
                     const double gl = c.part[(long)kPGnoise * c.G + g];
                     const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
-                    const double zp = lpn / kPiNoiseSd;
-                    const double logp = -0.5 * zp * zp - log(kPiNoiseSd) - kHalfLog2PiC;
+                    // Normal(0, 0.655) prior held in float32 by the reference (utils.py:158-161)
+                    const float nsf = 0.655f;
+                    const double nvar = (double)(nsf * nsf);
+                    const double logp = -lpn * lpn / (2.0 * nvar) - (double)logf(nsf) - kHalfLog2PiC;
                     const double logq = -0.5 * eps * eps - log(ns) - kHalfLog2PiC;
                     loss_fin += -logp + logq;
                     if (fit_noise) {
-                        const double Gl = gl + lpn / (kPiNoiseSd * kPiNoiseSd);
+                        const double Gl = gl + lpn / nvar;
                         emit_grad<ADAM>(c, 5, g, Gl, ak);
                         emit_grad<ADAM>(c, 6, g, Gl * eps * ns - 1.0, ak);
                         if (ADAM) {

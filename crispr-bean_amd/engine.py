@@ -109,7 +109,9 @@ class HipSVI:
         shape = _lib.bean_hip_shape(
             family=_lib.FAMILY[family], selection=0, flags=flags, n_reps=R, n_condits=B, n_guides=G,
             n_targets=T, n_max_alleles=2, n_edits=0, n_ctrl=n_ctrl, mask_thres=int(mask_thres),
-            reserved=max_len, sd_prior_scale=1.0 if family == "ControlNormal" else float(sd_scale),
+            reserved=max_len,
+            # the reference holds the prior scale in a float32 tensor (model.py:406)
+            sd_prior_scale=1.0 if family == "ControlNormal" else float(np.float32(sd_scale)),
             initial_lr=self.initial_lr, lrd=self.lrd, clip_norm=10.0,
         )
         self._shape = shape

@@ -1,0 +1,177 @@
+"""``run_inference`` and model selection for the HIP engine.
+
+Mirrors the public surface of ``bean/model/run.py``: ``run_inference`` (347-396),
+``identify_model_guide`` (399-457) and ``identify_negctrl_model_guide``
+(460-474), with the same argument meaning, return structure and error behaviour.
+The per-step loop the reference runs through ``pyro.infer.SVI`` is executed by
+``libbean_hip`` (``bean_hip_svi_run``).
+"""
+from __future__ import annotations
+
+import logging
+import pickle as pkl
+import sys
+from functools import partial
+from typing import Dict
+
+import torch
+
+from ..engine import HipSVI
+from . import model as sorting_model
+from .model import ModelSpec
+
+logger = logging.getLogger(__name__)
+info, error = logger.info, logger.error
+
+SEED = 101  # pyro.set_rng_seed(101) at import of bean/model/run.py:36
+
+
+class ParamStore:
+    """Minimal stand-in for ``pyro.get_param_store()`` as the reference consumes
+    it (``bean/model/readwrite.py:66-98``, ``bean/cli/run.py:258-267``):
+    ``store[name]`` is the *constrained* tensor; ``keys()``; ``in``; ``items()``."""
+
+    def __init__(self, constrained: Dict[str, torch.Tensor]):
+        self._c = constrained
+
+    def __getitem__(self, name):
+        return self._c[name]
+
+    def __contains__(self, name):
+        return name in self._c
+
+    def keys(self):
+        return self._c.keys()
+
+    def items(self):
+        return self._c.items()
+
+    def __iter__(self):
+        return iter(self._c)
+
+    def __len__(self):
+        return len(self._c)
+
+
+def _resolve(obj) -> ModelSpec:
+    if isinstance(obj, ModelSpec):
+        return obj
+    spec = obj()
+    if not isinstance(spec, ModelSpec):
+        raise TypeError(f"{obj!r} is not a crispr-bean_amd model/guide descriptor")
+    return spec
+
+
+def build_engine(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000, **engine_kw) -> HipSVI:
+    m, g = _resolve(model), _resolve(guide)
+    if m.family != g.family and not (m.family == "MixtureNormalConstPi"):
+        raise ValueError(f"model family {m.family} does not match guide family {g.family}")
+    if m.selection != "sorting":
+        raise NotImplementedError("survival models are not implemented in the HIP engine yet")
+    return HipSVI(
+        m.family,
+        data,
+        use_bcmatch=bool(m.get("use_bcmatch", True)),
+        scale_by_accessibility=bool(m.get("scale_by_accessibility", False)),
+        fit_noise=bool(g.get("fit_noise", False)),
+        sd_scale=float(m.get("sd_scale", 0.01)),
+        prior_params=m.get("prior_params"),
+        mask_thres=int(m.get("mask_thres", 10)),
+        initial_lr=initial_lr,
+        gamma=gamma,
+        num_steps=num_steps,
+        **engine_kw,
+    )
+
+
+def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000, autoguide=False,
+                  seed: int = SEED, report_every: int = 100, verbose: bool = True):
+    """Run SVI for the given model and guide (``bean/model/run.py:347-396``).
+
+    Returns ``(param_store, {"loss": [float] * num_steps, "params": {name: cpu
+    tensor}})`` where ``param_store[name]`` and ``params[name]`` are the
+    constrained values, exactly the structure the reference returns.
+    A non-finite loss raises ``ValueError`` after dumping the parameters to
+    ``tmp_result.pkl``, as the reference does on a ``ValueError`` inside the loop.
+    """
+    data_dev = data if data.X.is_cuda else data.to("cuda")
+    eng = build_engine(model, guide, data_dev, initial_lr=initial_lr, gamma=gamma, num_steps=num_steps)
+    try:
+        done = 0
+        while done < num_steps:
+            k = min(report_every, num_steps - done)
+            eng.run(k, seed=seed)
+            if verbose:
+                torch.cuda.synchronize(eng.device)
+                print(f"loss {float(eng.loss_hist[done])} @ iter {done}")
+            done += k
+        losses = eng.losses()
+        if not all(l == l and abs(l) != float("inf") for l in losses):
+            bad = next(i for i, l in enumerate(losses) if not (l == l and abs(l) != float("inf")))
+            raise ValueError(f"non-finite loss at iteration {bad}")
+    except ValueError as exc:
+        error("Error occurred during fitting. Saving temporary output at tmp_result.pkl.")
+        with open("tmp_result.pkl", "wb") as handle:
+            pkl.dump({"param": {k: v.cpu() for k, v in eng.constrained().items()}}, handle)
+        eng.close()
+        raise ValueError(
+            f"Fitting halted for command: {' '.join(sys.argv)} with following error: \n {exc}"
+        )
+    constrained = eng.constrained()
+    store = ParamStore(constrained)
+    out = {"loss": losses, "params": {k: v.detach().cpu() for k, v in constrained.items()}}
+    eng.close()
+    return store, out
+
+
+def identify_model_guide(args):
+    """Model label and (model, guide) descriptors for the parsed ``bean run``
+    arguments (``bean/model/run.py:399-457``), including the reference's
+    always-truthy ``use_bcmatch`` tuple and ``~bool`` ``fit_noise``."""
+    if args.selection == "sorting":
+        m = sorting_model
+    else:
+        from . import survival_model as m  # noqa: WPS433
+    if args.library_design == "tiling":
+        info("Using Mixture Normal model...")
+        return (
+            f"MultiMixtureNormal{'+Acc' if args.scale_by_acc else ''}",
+            partial(m.MultiMixtureNormalModel, scale_by_accessibility=args.scale_by_acc,
+                    use_bcmatch=(not args.ignore_bcmatch,)),
+            partial(m.MultiMixtureNormalGuide, scale_by_accessibility=args.scale_by_acc,
+                    fit_noise=~args.dont_fit_noise),
+        )
+    if args.uniform_edit:
+        if args.guide_activity_col is not None:
+            raise ValueError("Can't use the guide activity column while constraining uniform edit.")
+        info("Using Normal model...")
+        return ("Normal", partial(m.NormalModel, use_bcmatch=(not args.ignore_bcmatch)), m.NormalGuide)
+    elif args.const_pi:
+        if args.guide_activity_col is not None:
+            raise ValueError("--guide-activity-col to be used as constant pi is not provided.")
+        info("Using Mixture Normal model with constant weight ...")
+        return (
+            "MixtureNormalConstPi",
+            partial(m.MixtureNormalConstPiModel, use_bcmatch=(not args.ignore_bcmatch)),
+            m.MixtureNormalGuide,
+        )
+    else:
+        info(f"Using Mixture Normal model {'with accessibility normalization' if args.scale_by_acc else ''}...")
+        return (
+            f"{'_' if args.dont_fit_noise else ''}MixtureNormal{'+Acc' if args.scale_by_acc else ''}",
+            partial(m.MixtureNormalModel, scale_by_accessibility=args.scale_by_acc,
+                    use_bcmatch=(not args.ignore_bcmatch,)),
+            partial(m.MixtureNormalGuide, scale_by_accessibility=args.scale_by_acc,
+                    fit_noise=(not args.dont_fit_noise)),
+        )
+
+
+def identify_negctrl_model_guide(args, data_has_bcmatch):
+    """``bean/model/run.py:460-474``."""
+    if args.selection == "sorting":
+        m = sorting_model
+    else:
+        from . import survival_model as m  # noqa: WPS433
+    negctrl_model = partial(m.ControlNormalModel, use_bcmatch=(not args.ignore_bcmatch and data_has_bcmatch))
+    negctrl_guide = partial(m.ControlNormalGuide, use_bcmatch=(not args.ignore_bcmatch and data_has_bcmatch))
+    return negctrl_model, negctrl_guide

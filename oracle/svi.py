@@ -51,7 +51,7 @@ def svi_step(loss_fn: Callable, data, params, optim: ClippedAdam, noise=None, **
     loss = loss_fn(data, params, noise=noise, **kw)
     loss.backward()
     optim.step()
-    return float(loss)
+    return float(loss.detach())
 
 
 def loss_and_grads(loss_fn: Callable, data, params, noise=None, **kw):
@@ -62,7 +62,7 @@ def loss_and_grads(loss_fn: Callable, data, params, noise=None, **kw):
     loss = loss_fn(data, params, noise=noise, record=rec, **kw)
     loss.backward()
     grads = {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
-    return float(loss), grads, rec
+    return float(loss.detach()), grads, rec
 
 
 def run_svi(loss_fn: Callable, data, params, num_steps=2000, initial_lr=0.01, gamma=0.1,

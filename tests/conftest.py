@@ -1,0 +1,20 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def small_screen():
+    import bean_amd  # noqa: F401
+    from bean_amd.preprocessing.synthetic import make_sorting_variant_screen
+
+    return make_sorting_variant_screen(600, 3, seed=11, mask_fraction=0.05)

@@ -1,0 +1,332 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  -m gpu.
+
+Tolerances: the kernels compute in float64 from float32-stored parameters and
+emit float32 gradients (as the reference's autograd does for float32 leaves), so
+  * against the oracle in "f64" mode (same arithmetic width): loss rel 1e-9,
+    gradients rel 5e-7 of the largest entry (float32 output rounding);
+  * against the oracle in the reference's mixed f32/f64 dtypes: loss rel 1e-6,
+    gradients rel 2e-5.
+"""
+import ast
+import os
+
+import numpy as np
+import pytest
+import scipy.special as sp
+import scipy.stats as st
+import torch
+
+import bean_amd  # noqa: F401
+from bean_amd.preprocessing.synthetic import DEFAULT_BINS, make_sorting_variant_screen
+from oracle import elbo, svi
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "elbo_cases.npz"))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from bean_amd import engine as eng
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return eng
+
+
+# ------------------------------------------------------------ special functions
+def test_lgamma_digamma_differences(engine):
+    rng = np.random.default_rng(0)
+    n = 300_000
+    a = np.exp(rng.uniform(np.log(1e-5), np.log(1e5), n))
+    x = np.floor(np.exp(rng.uniform(0, np.log(1e5), n))) * (rng.random(n) > 0.1)
+    x[:1000] = rng.integers(0, 14, 1000)           # product-form branch
+    x[1000:2000] += 0.5                            # non-integer counts take the series branch
+    d, dp = engine.test_special(0, a, x)
+    ref_d = sp.gammaln(a + x) - sp.gammaln(a)
+    ref_dp = sp.digamma(a + x) - sp.digamma(a)
+    # the scipy reference is itself a difference of rounded values: allow its
+    # cancellation error (a few ulp of the larger term) on top of 1e-12 relative
+    eps = np.finfo(float).eps
+    tol_d = 1e-12 * np.maximum(1.0, np.abs(ref_d)) + 8 * eps * (np.abs(sp.gammaln(a + x)) + np.abs(sp.gammaln(a)))
+    tol_dp = 1e-12 * np.maximum(1.0, np.abs(ref_dp)) + 8 * eps * (np.abs(sp.digamma(a + x)) + np.abs(sp.digamma(a)))
+    assert np.all(np.abs(d.cpu().numpy() - ref_d) <= tol_d)
+    assert np.all(np.abs(dp.cpu().numpy() - ref_dp) <= tol_dp)
+    # small arguments, where no cancellation hides errors, to 1e-13
+    small = (a < 50) & (x < 50)
+    assert np.max(np.abs(d.cpu().numpy() - ref_d)[small] / np.maximum(1.0, np.abs(ref_d[small]))) < 1e-13
+
+
+def test_lgamma_digamma_and_phi(engine):
+    rng = np.random.default_rng(1)
+    a = np.exp(rng.uniform(np.log(1e-5), np.log(1e6), 100_000))
+    lg, dg = engine.test_special(1, a)
+    assert np.max(np.abs(lg.cpu().numpy() - sp.gammaln(a)) / np.maximum(1.0, np.abs(sp.gammaln(a)))) < 1e-13
+    assert np.max(np.abs(dg.cpu().numpy() - sp.digamma(a)) / np.maximum(1.0, np.abs(sp.digamma(a)))) < 1e-13
+    u = rng.normal(0, 3, 100_000)
+    phi, _ = engine.test_special(3, u)
+    assert np.max(np.abs(phi.cpu().numpy() - st.norm.cdf(u))) < 1e-15
+
+
+def test_dirichlet_grad_matches_torch(engine):
+    rng = np.random.default_rng(2)
+    n = 200_000
+    al = np.exp(rng.uniform(np.log(1e-3), np.log(2e3), n))
+    be = np.exp(rng.uniform(np.log(1e-3), np.log(2e3), n))
+    x = rng.beta(al, be).clip(1e-12, 1 - 1e-12)
+    g, _ = engine.test_special(2, al, x, al + be)
+    ref = torch._dirichlet_grad(torch.tensor(x), torch.tensor(al), torch.tensor(al + be)).numpy()
+    ok = np.isfinite(ref)
+    assert ok.mean() > 0.999
+    rel = np.abs(g.cpu().numpy()[ok] - ref[ok]) / np.maximum(1e-300, np.abs(ref[ok]))
+    assert rel.max() < 1e-8, rel.max()
+
+
+@pytest.mark.parametrize("a,b", [(0.3, 0.7), (0.9, 14.0), (2.5, 2.5), (40.0, 7.0), (1e-5, 3.0)])
+def test_dirichlet_sampler_distribution(engine, a, b):
+    n = 200_000
+    seed = np.zeros(n)
+    seed[:1] = np.frombuffer(np.uint64(77 + int(a * 10)).tobytes(), dtype=np.float64)
+    p0, p1 = engine.test_special(4, np.full(n, a), seed, np.full(n, b))
+    p0, p1 = p0.cpu().numpy(), p1.cpu().numpy()
+    assert np.all((p0 > 0) & (p0 < 1) & (p1 > 0) & (p1 < 1))
+    np.testing.assert_allclose(p0 + p1, 1.0, atol=1e-15)
+    if a >= 0.01:
+        ks = st.kstest(p0, st.beta(a, b).cdf)
+        assert ks.pvalue > 1e-4, ks
+    else:
+        # concentration 1e-5 (masked alleles): almost all mass at 0
+        assert np.mean(p0 < 1e-100) > 0.99
+
+
+# ------------------------------------------------------------------ ELBO parity
+def _compare(engine, family, data, kw, seed=7, step=3, tol_loss=(1e-9, 1e-6), tol_grad=(5e-7, 2e-5),
+             perturb=0.3, eng_kw=None):
+    torch.manual_seed(seed)
+    eng = engine.HipSVI(family, data.to(DEV), dump_noise=True, num_steps=50, **(eng_kw or kw))
+    for v in eng.unconstrained.values():
+        v.add_(perturb * torch.randn_like(v))
+    loss, grads = eng.elbo_grad(step=step, seed=seed)
+    noise = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+    assert np.isfinite(loss)
+    for mode, tl, tg in (("f64", tol_loss[0], tol_grad[0]), ("ref", tol_loss[1], tol_grad[1])):
+        params = {k: v.detach().cpu().clone() for k, v in eng.unconstrained.items()}
+        d = data
+        if mode == "f64":
+            params = {k: v.double() for k, v in params.items()}
+            d = elbo.as_float64(data)
+        params = {k: v.requires_grad_(True) for k, v in params.items()}
+        ref_loss, ref_grads, _ = svi.loss_and_grads(elbo.LOSSES[family], d, params, noise=noise, **kw)
+        assert abs(loss - ref_loss) <= tl * abs(ref_loss), (mode, loss, ref_loss)
+        for k, g in grads.items():
+            ref = ref_grads[k].double().reshape(-1)
+            err = (g.cpu().double().reshape(-1) - ref).abs().max().item()
+            assert err <= tg * (ref.abs().max().item() + 1e-30), (mode, k, err, ref.abs().max().item())
+    # injecting the same draws reproduces the evaluation exactly
+    eng.set_noise(noise)
+    loss_b, grads_b = eng.elbo_grad(step=step, seed=seed)
+    assert abs(loss_b - loss) <= 1e-12 * abs(loss)
+    for k in grads:
+        assert torch.equal(grads[k], grads_b[k])
+    eng.close()
+    return loss
+
+
+@pytest.mark.parametrize("family,gen_kw,kw", [
+    ("MixtureNormal", dict(n_guides=3000, n_reps=3, mask_fraction=0.05), {}),
+    ("MixtureNormal", dict(n_guides=1500, n_reps=2, with_accessibility=True), dict(scale_by_accessibility=True)),
+    ("MixtureNormal", dict(n_guides=1500, n_reps=2, with_accessibility=True),
+     dict(scale_by_accessibility=True, fit_noise=False)),
+    ("Normal", dict(n_guides=2000, n_reps=3, mask_fraction=0.05), {}),
+    ("Normal", dict(n_guides=700, n_reps=2), dict(use_bcmatch=False)),
+])
+def test_elbo_and_gradients_match_oracle(engine, family, gen_kw, kw):
+    data = make_sorting_variant_screen(seed=31, **gen_kw)
+    _compare(engine, family, data, kw)
+
+
+def test_control_normal_matches_oracle(engine):
+    data = make_sorting_variant_screen(3000, 3, seed=32)
+    sub = data[data.negctrl_guide_idx]
+    assert sub.n_guides >= 10
+    _compare(engine, "ControlNormal", sub, {})
+
+
+@pytest.mark.parametrize("n_guides,n_reps", [(1, 1), (63, 1), (64, 2), (65, 3), (130, 9), (257, 12)])
+def test_ragged_shapes(engine, n_guides, n_reps):
+    data = make_sorting_variant_screen(n_guides, n_reps, seed=40 + n_guides, guides_per_target=3)
+    _compare(engine, "MixtureNormal", data, {})
+
+
+@pytest.mark.parametrize("n_bins", [1, 2, 3, 5, 7])
+def test_bin_counts(engine, n_bins):
+    edges = np.linspace(0, 1, n_bins + 1)
+    bins = tuple((float(edges[i]), float(edges[i + 1])) for i in range(n_bins))
+    data = make_sorting_variant_screen(300, 2, bins=bins, seed=50 + n_bins)
+    assert data.n_condits == n_bins + 1
+    _compare(engine, "MixtureNormal", data, {})
+
+
+def test_prior_params(engine):
+    data = make_sorting_variant_screen(500, 2, seed=61)
+    T = data.n_targets
+    g = torch.Generator().manual_seed(0)
+    prior = {
+        "mu_loc": torch.randn((T, 1), generator=g, dtype=torch.float64) * 0.2,
+        "mu_scale": torch.rand((T, 1), generator=g, dtype=torch.float64) + 0.5,
+        "sd_loc": torch.randn((T, 1), generator=g, dtype=torch.float64) * 0.1,
+        "sd_scale": torch.rand((T, 1), generator=g, dtype=torch.float64) * 0.05 + 0.01,
+    }
+    _compare(engine, "MixtureNormal", data, dict(prior_params=prior))
+    _compare(engine, "Normal", data, dict(prior_params={"sd_scale": prior["sd_scale"]}))
+
+
+def test_all_masked_and_low_count_guides(engine):
+    data = make_sorting_variant_screen(200, 2, seed=62, depth_per_guide=2.0)  # sums <= 10 get masked
+    assert (data.X_masked.sum(1) <= 10).any()
+    _compare(engine, "MixtureNormal", data, {})
+    data2 = make_sorting_variant_screen(100, 2, seed=63)
+    data2.repguide_mask[:] = False
+    _compare(engine, "MixtureNormal", data2, {})
+
+
+@pytest.mark.parametrize("tag,family,kw", [
+    ("mix", "MixtureNormal", {}), ("mixacc", "MixtureNormal", dict(scale_by_accessibility=True)),
+    ("normal", "Normal", {}), ("control", "ControlNormal", {}),
+])
+def test_frozen_golden_cases(engine, tag, family, kw):
+    gen_kw = ast.literal_eval(str(GOLD[f"{tag}__gen"]))
+    data = make_sorting_variant_screen(**gen_kw)
+    eng = engine.HipSVI(family, data.to(DEV), num_steps=10, **kw)
+    for k, v in eng.unconstrained.items():
+        v.copy_(torch.as_tensor(GOLD[f"{tag}__param__{k}"]).reshape(v.shape))
+    noise = {k.split("__")[-1]: torch.as_tensor(GOLD[k]) for k in GOLD.files if k.startswith(f"{tag}__noise__")}
+    eng.set_noise(noise)
+    loss, grads = eng.elbo_grad()
+    want = float(GOLD[f"{tag}__loss"])
+    assert abs(loss - want) <= 1e-6 * abs(want)
+    for k, g in grads.items():
+        ref = torch.as_tensor(GOLD[f"{tag}__grad__{k}"]).double().reshape(-1)
+        err = (g.cpu().double().reshape(-1) - ref).abs().max().item()
+        assert err <= 2e-5 * ref.abs().max().item(), (k, err)
+    eng.close()
+
+
+# ------------------------------------------------------------------ trajectories
+def test_exact_noise_trajectory_matches_oracle(engine):
+    """30 steps of {ELBO grad -> ClippedAdam} on the same draws as the oracle."""
+    data = make_sorting_variant_screen(400, 2, seed=71)
+    n = 30
+    eng = engine.HipSVI("MixtureNormal", data.to(DEV), dump_noise=True, num_steps=2000)
+    params = elbo.init_params("MixtureNormal", data)
+    optim = svi.ClippedAdam(params, lr=0.01, lrd=0.1 ** (1 / 2000))
+    for t in range(n):
+        loss, _ = eng.elbo_grad(step=t, seed=5, loss_index=t)
+        noise = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+        eng.adam(t + 1)
+        ref = svi.svi_step(elbo.mixture_normal_loss, data, params, optim, noise=noise)
+        assert abs(loss - ref) <= 2e-6 * abs(ref), (t, loss, ref)
+    torch.cuda.synchronize()
+    for k, v in eng.unconstrained.items():
+        ref = params[k].detach()
+        err = (v.cpu() - ref).abs().max().item()
+        assert err <= 1e-4 * max(1.0, ref.abs().max().item()), (k, err)
+    eng.close()
+
+
+def test_fused_loop_equals_stepwise_and_graph_equals_eager(engine):
+    data = make_sorting_variant_screen(900, 3, seed=72).to(DEV)
+    n = 40
+    a = engine.HipSVI("MixtureNormal", data, num_steps=500)
+    for t in range(n):
+        a.elbo_grad(step=t, seed=9, loss_index=t)
+        a.adam(t + 1)
+    torch.cuda.synchronize()
+    b = engine.HipSVI("MixtureNormal", data, num_steps=500)
+    b.run(n, seed=9, graph_chunk=0)
+    c = engine.HipSVI("MixtureNormal", data, num_steps=500)
+    c.run(n, seed=9, graph_chunk=8)
+    lb, lc = b.losses(), c.losses()
+    la = a.loss_hist[:n].cpu().tolist()
+    np.testing.assert_allclose(lb, la, rtol=1e-12)
+    np.testing.assert_allclose(lc, lb, rtol=1e-12)
+    for k in a.unconstrained:
+        assert torch.equal(a.unconstrained[k], b.unconstrained[k]), k   # same arithmetic, bitwise
+        assert torch.equal(b.unconstrained[k], c.unconstrained[k]), k
+    # continuing a run in two calls is the same as one call
+    d = engine.HipSVI("MixtureNormal", data, num_steps=500)
+    d.run(15, seed=9, graph_chunk=4)
+    d.run(n - 15, seed=9, graph_chunk=4)
+    for k in a.unconstrained:
+        assert torch.equal(b.unconstrained[k], d.unconstrained[k]), k
+    for e in (a, b, c, d):
+        e.close()
+
+
+def test_run_inference_interface(engine):
+    from functools import partial
+
+    from bean_amd.model import model as m
+    from bean_amd.model.run import run_inference
+
+    data = make_sorting_variant_screen(500, 2, seed=73, frac_effect=0.5)
+    store, out = run_inference(
+        partial(m.MixtureNormalModel, use_bcmatch=(True,)), partial(m.MixtureNormalGuide, fit_noise=True),
+        data, num_steps=300, verbose=False)
+    assert set(store.keys()) == {"mu_loc", "mu_scale", "sd_loc", "sd_scale", "alpha_pi"}
+    assert "mu_loc" in store.keys() and store["mu_loc"].dim() == 2
+    assert len(out["loss"]) == 300 and isinstance(out["loss"][0], float)
+    assert out["loss"][-1] < 0.8 * out["loss"][0]
+    assert (store["mu_scale"] > 0).all() and (store["alpha_pi"] > 0).all()
+    assert out["params"]["mu_loc"].device.type == "cpu"
+    mu = out["params"]["mu_loc"].numpy().ravel()
+    truth = data.truth["mu"]
+    big = np.abs(truth) > 0.8
+    assert np.mean(np.sign(mu[big]) == np.sign(truth[big])) > 0.8
+
+
+# --------------------------------------------------- full-size (metric shape) properties
+@pytest.fixture(scope="module")
+def full_screen():
+    return make_sorting_variant_screen(50_000, 5, seed=20240502)
+
+
+def test_full_size_shard_additivity(engine, full_screen):
+    """Loss and per-guide gradients of the whole 50k-guide screen equal those of
+    two target-aligned shards evaluated on the same draws (guides shard without
+    any data-path exchange)."""
+    data = full_screen
+    T, G, R = data.n_targets, data.n_guides, data.n_reps
+    whole = engine.HipSVI("MixtureNormal", data.to(DEV), dump_noise=True, num_steps=10)
+    loss, grads = whole.elbo_grad(step=0, seed=3)
+    noise = whole.drawn_noise()
+    cut_t = T // 3
+    cut_g = int(data.target_offsets[cut_t])
+    tot = 0.0
+    for (g0, g1, t0, t1) in ((0, cut_g, 0, cut_t), (cut_g, G, cut_t, T)):
+        sub = data[np.arange(g0, g1)]
+        e = engine.HipSVI("MixtureNormal", sub.to(DEV), num_steps=10)
+        e.set_noise({"eps_mu": noise["eps_mu"][t0:t1], "eps_sd": noise["eps_sd"][t0:t1],
+                     "pi": noise["pi"][:, :, g0:g1]})
+        l, g = e.elbo_grad()
+        tot += l
+        assert torch.equal(g["alpha_pi"], grads["alpha_pi"][g0:g1])
+        assert torch.equal(g["mu_loc"], grads["mu_loc"][t0:t1])
+        assert torch.equal(g["sd_scale"], grads["sd_scale"][t0:t1])
+        e.close()
+    assert abs(tot - loss) <= 1e-11 * abs(loss)
+    whole.close()
+
+
+def test_full_size_fit_is_deterministic_and_improves(engine, full_screen):
+    data = full_screen.to(DEV)
+    runs = []
+    for _ in range(2):
+        e = engine.HipSVI("MixtureNormal", data, num_steps=2000)
+        e.run(200, seed=101)
+        runs.append(({k: v.clone() for k, v in e.unconstrained.items()}, e.losses()))
+        e.close()
+    for k in runs[0][0]:
+        assert torch.equal(runs[0][0][k], runs[1][0][k]), k
+    losses = runs[0][1]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    np.testing.assert_allclose(runs[0][1], runs[1][1], rtol=1e-12)  # atomically summed, not bitwise
