@@ -15,7 +15,7 @@ from ctypes import POINTER, c_char_p, c_double, c_int32, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libbean_hip.so")
+LIB_PATH = os.environ.get("BEAN_HIP_LIB") or os.path.join(LIB_DIR, "libbean_hip.so")  # env override: kernel A/B experiments
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "bean_hip.h")
 
 HIPCC_FLAGS = [

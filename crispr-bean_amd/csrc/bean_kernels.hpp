@@ -395,32 +395,34 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
 // Dirichlet-Multinomial observation term of one (rep, guide):
 // returns -log p and accumulates d(-log p)/d e[b] into ge.
 template <int B>
-__device__ __forceinline__ double dirmult_nll(const float (&x)[B], const double* __restrict__ sf,
+__device__ __forceinline__ double dirmult_nll(const float* __restrict__ xp, long stride,
+                                              const double* __restrict__ sf,
                                               const double* __restrict__ sm, double a0,
                                               const double (&e)[B], double (&ge)[B]) {
-    double p[B], araw[B], S = 0.0, n = 0.0;
+    double araw[B], ga[B], S = 0.0, n = 0.0;
+    float x[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        p[b] = e[b] * sf[b];
-        S += p[b];
+        x[b] = xp[b * stride];
+        araw[b] = e[b] * sf[b];  // p[b] for now
+        S += araw[b];
         n += (double)x[b];
     }
-    const double inv = 1.0 / (S + kEps);
+    const double inv = frcp(S + kEps);
     double A0 = 0.0;
-    bool clamped[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        araw[b] = (p[b] + kEps / B) * inv * a0 * sm[b];
-        clamped[b] = araw[b] < kEps;
-        A0 += clamped[b] ? kEps : araw[b];
+        araw[b] = (araw[b] + kEps / B) * inv * a0 * sm[b];
+        A0 += araw[b] < kEps ? kEps : araw[b];
     }
     const DD d0 = lgamma_digamma_diff(A0, n);
-    double nll = d0.d, W = 0.0, ga[B];
+    double nll = d0.d, W = 0.0;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        const DD db = lgamma_digamma_diff(clamped[b] ? kEps : araw[b], (double)x[b]);
+        const bool clamped = araw[b] < kEps;
+        const DD db = lgamma_digamma_diff(clamped ? kEps : araw[b], (double)x[b]);
         nll -= db.d;
-        ga[b] = clamped[b] ? 0.0 : (d0.dp - db.dp);  // d nll / d alpha_b
+        ga[b] = clamped ? 0.0 : (d0.dp - db.dp);  // d nll / d alpha_b
         W += ga[b] * araw[b];
     }
     W *= inv;
@@ -431,8 +433,12 @@ __device__ __forceinline__ double dirmult_nll(const float (&x)[B], const double*
 
 // blockDim.x = 64 * nw (nw waves cover the replicates of 64 guides); dynamic
 // LDS = nw * kNumPart * 64 doubles + 16.
+#ifndef BEAN_GUIDE_WAVES_PER_EU
+#define BEAN_GUIDE_WAVES_PER_EU 2
+#endif
 template <int B, int FAM, bool ACC>
-__global__ __launch_bounds__(512) void k_guide(DevArgs c) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BEAN_GUIDE_WAVES_PER_EU)))
+void k_guide(DevArgs c) {
     extern __shared__ double lds[];
     constexpr bool MIX = FAM == kMixture;
     const int lane = threadIdx.x & 63;
@@ -450,25 +456,15 @@ __global__ __launch_bounds__(512) void k_guide(DevArgs c) {
 
     if (valid) {
         const int t = c.g2t[g];
-        double P1[B], Pmu[B], Py[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b) {
-            const long o = (long)b * T + t;
-            P1[b] = c.tabP[o];
-            Pmu[b] = c.tabPmu[o];
-            Py[b] = c.tabPy[o];
-        }
-        const double a0 = c.a0[g];
         const bool use_bc = (c.flags & kUseBc) != 0;
-        const double a0bc = use_bc ? c.a0_bc[g] : 1.0;
         double cp[2] = {1.0, 1.0}, cq[2] = {1.0, 1.0};
         bool cl[2] = {false, false};
         double kacc = 0.0, lpn = 0.0;
         if (MIX) {
             const double al0 = (double)expf(c.p[4][2 * g]), al1 = (double)expf(c.p[4][2 * g + 1]);
-            const double s = al0 + al1, pa0 = c.pi_a0[g];
-            cp[0] = al0 / s * pa0;
-            cp[1] = al1 / s * pa0;
+            const double rs = frcp(al0 + al1) * c.pi_a0[g];
+            cp[0] = al0 * rs;
+            cp[1] = al1 * rs;
             cl[0] = cp[0] < 1e-5;
             cl[1] = cp[1] < 1e-5;
             cq[0] = cl[0] ? 1e-5 : cp[0];
@@ -479,42 +475,32 @@ __global__ __launch_bounds__(512) void k_guide(DevArgs c) {
             }
         }
         for (int r = w; r < c.R; r += nw) {
-            const double* sf = c.sf + r * B;
-            const double* sfb = c.sf_bc + r * B;
-            const double* sm = c.smask + r * B;
             const bool rgm = c.rg[(long)r * G + g] != 0;
-            float x[B], xb[B];
-            float n = 0.f, nb = 0.f;
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                x[b] = c.X[((long)r * B + b) * G + g];
-                n += x[b];
-            }
-            if (use_bc) {
-#pragma unroll
-                for (int b = 0; b < B; ++b) {
-                    xb[b] = c.Xbc[((long)r * B + b) * G + g];
-                    nb += xb[b];
-                }
-            }
-            const bool obs = rgm && n > (float)c.mask_thres;
-            const bool obs_bc = use_bc && rgm && nb > (float)c.mask_thres;
-
             double pi[2] = {0.0, 1.0}, pe1 = 1.0;  // pe1: effective weight of the edited component
             double dpe1_dpi1 = 0.0;                // ACC: d pe1 / d pi1 (0 when clamped)
             double dpe1_dl = 0.0;                  // ACC: d pe1 / d logit noise
             if (MIX) {
+#ifdef BEAN_SKIP_SAMPLING
+                if (true) {
+#else
                 if (c.pi_in) {
+#endif
                     pi[0] = c.pi_in[((long)r * G + g) * 2];
                     pi[1] = c.pi_in[((long)r * G + g) * 2 + 1];
                 } else {
                     Rng rng(c.seed, kSitePi, (unsigned long long)r * G + g, ctr.step * 256ull);
-                    double g0 = sample_gamma(cq[0], rng), g1 = sample_gamma(cq[1], rng);
-                    g0 = fmax(g0, kDblMin);
-                    g1 = fmax(g1, kDblMin);
-                    const double s = g0 + g1;
-                    pi[0] = fmin(fmax(g0 / s, kDblMin), kOneMinus);
-                    pi[1] = fmin(fmax(g1 / s, kDblMin), kOneMinus);
+                    // rolled loop (one copy of the sampler in the code); selects instead of
+                    // runtime-indexed arrays, which would live in scratch
+                    double gm0 = 0.0, gm1 = 0.0;
+#pragma unroll 1
+                    for (int a = 0; a < 2; ++a) {
+                        const double gv = fmax(sample_gamma(a ? cq[1] : cq[0], rng), kDblMin);
+                        gm0 = a ? gm0 : gv;
+                        gm1 = a ? gv : gm1;
+                    }
+                    const double rs = frcp(gm0 + gm1);
+                    pi[0] = fmin(fmax(gm0 * rs, kDblMin), kOneMinus);
+                    pi[1] = fmin(fmax(gm1 * rs, kDblMin), kOneMinus);
                 }
                 if (c.flags & kDumpPi) {
                     c.pi_out[((long)r * G + g) * 2] = pi[0];
@@ -526,65 +512,79 @@ __global__ __launch_bounds__(512) void k_guide(DevArgs c) {
                     const double s1 = pi[1] * kacc;
                     const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
                     const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
-                    const double l = log(p1c / (1.0 - p1c)) + lpn;
+                    const double l = flog(p1c * frcp(1.0 - p1c)) + lpn;
                     const double el = exp(l);
-                    const double pn = el / (1.0 + el);
+                    const double pn = el * frcp(1.0 + el);
                     const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
                     pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
                     dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
-                    dpe1_dpi1 = in1 ? dpe1_dl / (p1c * (1.0 - p1c)) * kacc : 0.0;
+                    dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
                 }
             }
             double e[B], ge[B];
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                e[b] = MIX ? (1.0 - pe1) * c.P0[b] + pe1 * P1[b] : P1[b];
+                const double p1 = c.tabP[(long)b * T + t];
+                e[b] = MIX ? (ACC ? (1.0 - pe1) * c.P0[b] + pe1 * p1 : pi[0] * c.P0[b] + pi[1] * p1) : p1;
                 ge[b] = 0.0;
             }
             double nll = 0.0;
-            if (obs) nll += dirmult_nll<B>(x, sf, sm, a0, e, ge);
-            if (obs_bc) nll += dirmult_nll<B>(xb, sfb, sm, a0bc, e, ge);
+            const double* sm = c.smask + r * B;
+#pragma unroll 1
+            for (int lik = 0; lik < 2; ++lik) {
+                if (lik == 1 && !use_bc) break;
+                const float* xp = (lik ? c.Xbc : c.X) + (long)r * B * G + g;
+                float n = 0.f;
+#pragma unroll
+                for (int b = 0; b < B; ++b) n += xp[(long)b * G];
+#ifdef BEAN_SKIP_DIRMULT
+                if (n < 0.f)
+#else
+                if (rgm && n > (float)c.mask_thres)
+#endif
+                    nll += dirmult_nll<B>(xp, (long)G, (lik ? c.sf_bc : c.sf) + r * B, sm,
+                                          lik ? c.a0_bc[g] : c.a0[g], e, ge);
+            }
             // likelihood gradient w.r.t. the table entries of this guide's target
-            double dmu = 0.0, dy = 0.0, gpe1 = 0.0;
+            double dmu = 0.0, dy = 0.0, g0 = 0.0, g1 = 0.0;
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                dmu += ge[b] * Pmu[b];
-                dy += ge[b] * Py[b];
-                gpe1 += ge[b] * (P1[b] - c.P0[b]);
+                const long o = (long)b * T + t;
+                dmu += ge[b] * c.tabPmu[o];
+                dy += ge[b] * c.tabPy[o];
+                if (MIX) {
+                    g0 += ge[b] * c.P0[b];
+                    g1 += ge[b] * c.tabP[o];
+                }
             }
             acc[kPGmu] += pe1 * dmu;
             acc[kPGy] += pe1 * dy;
             if (MIX) {
                 // d loss / d pi through the likelihood
-                double gpi[2] = {0.0, 0.0};
+                double gpi[2] = {g0, g1};
                 if (ACC) {
-                    gpi[1] = gpe1 * dpe1_dpi1;
-                    acc[kPGnoise] += gpe1 * dpe1_dl;
-                } else {
-                    // e = pi0 P0 + pi1 P1 with both components free
-                    double g0 = 0.0, g1 = 0.0;
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        g0 += ge[b] * c.P0[b];
-                        g1 += ge[b] * P1[b];
-                    }
-                    gpi[0] = g0;
-                    gpi[1] = g1;
+                    gpi[0] = 0.0;
+                    gpi[1] = (g1 - g0) * dpe1_dpi1;
+                    acc[kPGnoise] += (g1 - g0) * dpe1_dl;
                 }
-                const double lpi[2] = {log(pi[0]), log(pi[1])};
+                const double lpi[2] = {flog(pi[0]), flog(pi[1])};
+                const double rpi[2] = {frcp(pi[0]), frcp(pi[1])};
                 if (rgm) {
-                    // Multinomial(probs = pi) on control allele counts (model.py:470-474)
+                    // Multinomial(probs = pi) on control allele counts (model.py:470-474):
+                    // torch renormalises the probabilities and clamps them to [eps, 1 - eps]
                     const double s = pi[0] + pi[1];
+                    const double ls = s == 1.0 ? 0.0 : flog(s);
+                    const double rs = s == 1.0 ? 1.0 : frcp(s);
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        const double pr = pi[a] / s;
+                        const double pr = pi[a] * rs;
                         const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
-                        const double lg = log(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                        const double lg = inside ? lpi[a] - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
                         double cnt = 0.0;
                         for (int cc = 0; cc < c.C; ++cc)
                             cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * 2 + a];
                         nll -= cnt * lg;
-                        if (inside) gpi[a] -= cnt / pi[a];
+                        if (inside) gpi[a] -= cnt * rpi[a];
                     }
                     acc[kPNrg] += 1.0;
                 }
@@ -592,16 +592,28 @@ __global__ __launch_bounds__(512) void k_guide(DevArgs c) {
                 for (int a = 0; a < 2; ++a) {
                     if (rgm) {
                         acc[kPLp + a] += lpi[a];
-                        gpi[a] -= (cp[a] - 1.0) / pi[a];
+                        gpi[a] -= (cp[a] - 1.0) * rpi[a];
                     }
                     acc[kPLq + a] += lpi[a];
-                    gpi[a] += (cq[a] - 1.0) / pi[a];
+                    gpi[a] += (cq[a] - 1.0) * rpi[a];
                 }
                 const double proj = pi[0] * gpi[0] + pi[1] * gpi[1];
                 const double total = cq[0] + cq[1];
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    if (!cl[a]) acc[kPPath + a] += dirichlet_grad_one(pi[a], cq[a], total) * (gpi[a] - proj);
+                double path0 = 0.0, path1 = 0.0;
+#pragma unroll 1
+                for (int a = 0; a < 2; ++a) {
+                    const bool skip = a ? cl[1] : cl[0];
+                    if (skip) continue;
+#ifdef BEAN_SKIP_DIRGRAD
+                    continue;
+#endif
+                    const double v = dirichlet_grad_one(a ? pi[1] : pi[0], a ? cq[1] : cq[0], total) *
+                                     ((a ? gpi[1] : gpi[0]) - proj);
+                    path0 = a ? path0 : v;
+                    path1 = a ? v : path1;
+                }
+                acc[kPPath] += path0;
+                acc[kPPath + 1] += path1;
             }
             loss += nll;
         }

@@ -7,12 +7,56 @@
 #include <hip/hip_runtime.h>
 #include <rocrand/rocrand_kernel.h>
 
+#ifndef BEAN_NOINLINE
+#define BEAN_NOINLINE __noinline__
+#endif
+
 namespace bean {
 
 struct DD {
     double d;   // lgamma(a + x) - lgamma(a)
     double dp;  // digamma(a + x) - digamma(a)
 };
+
+// ---------------------------------------------------------------------------
+// Lean float64 primitives.  The ocml log/division are correctly rounded but cost
+// ~100 / ~12 instructions (double-double arithmetic); the ELBO needs ~1e-15
+// relative accuracy, which these reach in ~28 / 5 instructions.  Arguments are
+// positive finite normal numbers everywhere they are used.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: ~2^-26 relative
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// natural log of a positive normal double: x = m 2^e, m in [sqrt(1/2), sqrt(2)),
+// log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, series to s^19.
+__device__ __forceinline__ double flog(double x) {
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f * frcp(2.0 + f);
+    const double z = s * s;
+    double p = 2.0 / 19.0;
+    p = fma(p, z, 2.0 / 17.0);
+    p = fma(p, z, 2.0 / 15.0);
+    p = fma(p, z, 2.0 / 13.0);
+    p = fma(p, z, 2.0 / 11.0);
+    p = fma(p, z, 2.0 / 9.0);
+    p = fma(p, z, 2.0 / 7.0);
+    p = fma(p, z, 2.0 / 5.0);
+    p = fma(p, z, 2.0 / 3.0);
+    const double ed = (double)e;
+    // e*ln2 split so that the leading product is exact for |e| < 2^11
+    const double hi = ed * 6.93147180369123816490e-01;
+    const double lo2 = fma(ed, 1.90821492927058770002e-10, s * z * p);
+    return hi + (2.0 * s + lo2);
+}
 
 // Stirling tails, valid to ~1e-14 absolute for z >= 10 (r = 1/z, w = r*r).
 __device__ __forceinline__ double stirling_lgamma_tail(double r, double w) {
@@ -50,12 +94,12 @@ __device__ __forceinline__ void shift_up(double& z, double& P, double& Q) {
 __device__ __forceinline__ void lgamma_digamma(double z, double& lg, double& dg) {
     double P, Q;
     shift_up(z, P, Q);
-    const double l = log(z), r = 1.0 / z, w = r * r;
+    const double l = flog(z), r = frcp(z), w = r * r;
     lg = (z - 0.5) * l - z + kHalfLog2Pi + stirling_lgamma_tail(r, w);
     dg = l - 0.5 * r - stirling_digamma_tail(w);
     if (P != 1.0) {
-        lg -= log(P);
-        dg -= Q / P;
+        lg -= flog(P);
+        dg -= Q * frcp(P);
     }
 }
 
@@ -69,7 +113,7 @@ __device__ __forceinline__ double digamma(double z) {
 // x >= 0.  Counts are integer-valued, so small x uses the exact product form
 // prod_{i<x}(a + i); everything else is a difference of Stirling series, with
 // both arguments first raised to >= kShift.
-__device__ __forceinline__ DD lgamma_digamma_diff(double a, double x) {
+__device__ BEAN_NOINLINE DD lgamma_digamma_diff(double a, double x) {
     DD out;
     if (x == 0.0) {
         out.d = 0.0;
@@ -84,27 +128,27 @@ __device__ __forceinline__ DD lgamma_digamma_diff(double a, double x) {
             P *= t;
             t += 1.0;
         }
-        out.d = log(P);
-        out.dp = Q / P;
+        out.d = flog(P);
+        out.dp = Q * frcp(P);
         return out;
     }
     double z1 = a, z2 = a + x, P1, Q1, P2, Q2;
     shift_up(z1, P1, Q1);
     shift_up(z2, P2, Q2);
-    const double l1 = log(z1), l2 = log(z2);
-    const double r1 = 1.0 / z1, r2 = 1.0 / z2;
+    const double l1 = flog(z1), l2 = flog(z2);
+    const double r1 = frcp(z1), r2 = frcp(z2);
     const double w1 = r1 * r1, w2 = r2 * r2;
     double d = (z2 - 0.5) * l2 - (z1 - 0.5) * l1 - (z2 - z1) +
                (stirling_lgamma_tail(r2, w2) - stirling_lgamma_tail(r1, w1));
     double dp = (l2 - l1) - 0.5 * (r2 - r1) -
                 (stirling_digamma_tail(w2) - stirling_digamma_tail(w1));
     if (P1 != 1.0) {
-        d += log(P1);
-        dp += Q1 / P1;
+        d += flog(P1);
+        dp += Q1 * frcp(P1);
     }
     if (P2 != 1.0) {
-        d -= log(P2);
-        dp -= Q2 / P2;
+        d -= flog(P2);
+        dp -= Q2 * frcp(P2);
     }
     out.d = d;
     out.dp = dp;
@@ -129,38 +173,45 @@ __device__ __forceinline__ double norm_pdf(double u) {
 // reference's alpha_pi gradient requires the same approximation, so the region
 // boundaries and fitted coefficients below are torch's.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
+
+// x^y for x > 0 through exp(y log x) (used only on rarely taken paths)
+__device__ __forceinline__ double fpow(double x, double y) { return exp(y * flog(x)); }
+
 __device__ inline double beta_grad_alpha_small(double x, double alpha, double beta) {
-    const double factor = digamma(alpha) - digamma(alpha + beta) - log(x);
+    const double factor = digamma(alpha) - digamma(alpha + beta) - flog(x);
+    const double ra = frcp(alpha);
     double numer = 1.0;
-    double series = numer / alpha * (factor + 1.0 / alpha);
+    double series = numer * ra * (factor + ra);
     for (int i = 1; i <= 10; ++i) {
         const double ci = (double)i;
-        numer *= (ci - beta) * x / ci;
-        const double denom = alpha + ci;
-        series += numer / denom * (factor + 1.0 / denom);
+        numer *= (ci - beta) * x * frcp(ci);
+        const double rd = frcp(alpha + ci);
+        series += numer * rd * (factor + rd);
     }
-    const double result = x * pow(1.0 - x, -beta) * series;
+    const double result = x * fpow(1.0 - x, -beta) * series;
     return isnan(result) ? 0.0 : result;
 }
 
 __device__ inline double beta_grad_beta_small(double x, double alpha, double beta) {
     const double factor = digamma(alpha + beta) - digamma(beta);
-    double numer = 1.0, betas = 1.0, dbetas = 0.0, series = factor / alpha;
+    double numer = 1.0, betas = 1.0, dbetas = 0.0, series = factor * frcp(alpha);
     for (int i = 1; i <= 8; ++i) {
         const double ci = (double)i;
-        numer *= -x / ci;
+        numer *= -x * frcp(ci);
         dbetas = dbetas * (beta - ci) + betas;
         betas = betas * (beta - ci);
-        series += numer / (alpha + ci) * (dbetas + factor * betas);
+        series += numer * frcp(alpha + ci) * (dbetas + factor * betas);
     }
-    const double result = -pow(1.0 - x, 1.0 - beta) * series;
+    const double result = -fpow(1.0 - x, 1.0 - beta) * series;
     return isnan(result) ? 0.0 : result;
 }
 
 __device__ inline double beta_grad_alpha_mid(double x, double alpha, double beta) {
     const double total = alpha + beta;
-    const double mean = alpha / total;
-    const double sd = sqrt(alpha * beta / (total + 1.0)) / total;
+    const double rtot = frcp(total);
+    const double mean = alpha * rtot;
+    const double sd = fsqrt(alpha * beta * frcp(total + 1.0)) * rtot;
     if (mean - 0.1 * sd <= x && x <= mean + 0.1 * sd) {
         const double b2 = beta * beta;
         const double poly =
@@ -169,25 +220,27 @@ __device__ inline double beta_grad_alpha_mid(double x, double alpha, double beta
                      alpha * (3.0 * (59.0 + 180.0 * beta - 90.0 * x) * b2 +
                               alpha * ((453.0 + 1620.0 * beta * (1.0 - x) - 455.0 * x) * beta +
                                        alpha * (8.0 * (1.0 - x) * (135.0 * beta - 11.0)))));
-        const double pre_num = (1.0 + 12.0 * alpha) * (1.0 + 12.0 * beta) / (total * total);
+        const double pre_num = (1.0 + 12.0 * alpha) * (1.0 + 12.0 * beta) * rtot * rtot;
         const double pre_den =
             12960.0 * alpha * alpha * alpha * beta * beta * (1.0 + 12.0 * total);
-        return pre_num / (1.0 - x) * poly / pre_den;
+        return pre_num * poly * frcp((1.0 - x) * pre_den);
     }
-    const double prefactor = -x / sqrt(2.0 * alpha * beta / total);
-    const double stirling = (1.0 + 1.0 / (12.0 * alpha) + 1.0 / (288.0 * alpha * alpha)) *
-                            (1.0 + 1.0 / (12.0 * beta) + 1.0 / (288.0 * beta * beta)) /
-                            (1.0 + 1.0 / (12.0 * total) + 1.0 / (288.0 * total * total));
+    const double ra = frcp(alpha), rb = frcp(beta);
+    const double prefactor = -x * frcp(fsqrt(2.0 * alpha * beta * rtot));
+    const double stirling = (1.0 + ra * (1.0 / 12.0) + ra * ra * (1.0 / 288.0)) *
+                            (1.0 + rb * (1.0 / 12.0) + rb * rb * (1.0 / 288.0)) *
+                            frcp(1.0 + rtot * (1.0 / 12.0) + rtot * rtot * (1.0 / 288.0));
     const double term1_num =
         2.0 * (alpha * alpha) * (x - 1.0) + alpha * beta * (x - 1.0) - x * (beta * beta);
     const double axbx = alpha * (x - 1.0) + beta * x;
-    const double term1_den = sqrt(2.0 * alpha / beta) * pow(total, 1.5) * axbx * axbx;
-    const double term1 = term1_num / term1_den;
-    const double term2 = 0.5 * log(alpha / (total * x));
-    const double term3 = sqrt(8.0 * alpha * beta / total) / (beta * x + alpha * (x - 1.0));
-    const double term4_base =
-        beta * log(beta / (total * (1.0 - x))) + alpha * log(alpha / (total * x));
-    const double term4 = pow(term4_base, -1.5);
+    const double term1_den = fsqrt(2.0 * alpha * rb) * (total * fsqrt(total)) * axbx * axbx;
+    const double term1 = term1_num * frcp(term1_den);
+    const double la = flog(alpha * frcp(total * x));
+    const double lb = flog(beta * frcp(total * (1.0 - x)));
+    const double term2 = 0.5 * la;
+    const double term3 = fsqrt(8.0 * alpha * beta * rtot) * frcp(axbx);
+    const double term4_base = beta * lb + alpha * la;
+    const double term4 = frcp(term4_base * fsqrt(term4_base));
     const double term1234 = term1 + term2 * (term3 + (x < mean ? term4 : -term4));
     return stirling * prefactor * term1234;
 }
@@ -214,7 +267,7 @@ __device__ __constant__ const double kDirGradC[2][3][3][4] = {
       {-0.0003477407336, 6.959756487e-05, 1.097287507e-05, -1.650964693e-06}}},
 };
 
-__device__ inline double dirichlet_grad_one(double x, double alpha, double total) {
+__device__ BEAN_NOINLINE double dirichlet_grad_one(double x, double alpha, double total) {
     const double beta = total - alpha;
     const double boundary = total * x * (1.0 - x);
     if (x <= 0.5 && boundary < 2.5) return beta_grad_alpha_small(x, alpha, beta);
@@ -222,9 +275,9 @@ __device__ inline double dirichlet_grad_one(double x, double alpha, double total
     if (alpha > 6.0 && beta > 6.0) return beta_grad_alpha_mid(x, alpha, beta);
     // rational correction to an analytic approximation (kDirGradC below)
     const auto& c = kDirGradC;
-    const double u = log(x);
-    const double a = log(alpha) - u;
-    const double b = log(total) - a;
+    const double u = flog(x);
+    const double a = flog(alpha) - u;
+    const double b = flog(total) - a;
     const double pow_u[3] = {1.0, u, u * u};
     const double pow_a[3] = {1.0, a, a * a};
     double p = 0.0, q = 0.0;
@@ -237,8 +290,8 @@ __device__ inline double dirichlet_grad_one(double x, double alpha, double total
             q += ua * (c[1][i][j][0] + b * (c[1][i][j][1] + b * (c[1][i][j][2] + b * c[1][i][j][3])));
         }
     }
-    const double approx = x * (digamma(total) - digamma(alpha)) / beta;
-    return p / q * approx;
+    const double approx = x * (digamma(total) - digamma(alpha)) * frcp(beta);
+    return p * approx * frcp(q);
 }
 
 // ---------------------------------------------------------------------------
@@ -263,26 +316,38 @@ struct Rng {
             has_spare = false;
             return spare;
         }
-        const double2 n = rocrand_normal_double2(&st);
-        spare = n.y;
+        // Box-Muller on two 53-bit uniforms built from one Philox counter (4 words)
+        const uint4 v = rocrand4(&st);
+        const double u1 = to_unit(v.x, v.y), u2 = to_unit(v.z, v.w);
+        const double rad = sqrt(-2.0 * flog(u1));
+        double sn, cs;
+        sincospi(2.0 * u2, &sn, &cs);
+        spare = rad * sn;
         has_spare = true;
-        return n.x;
+        return rad * cs;
     }
-    // uniform on (0, 1]
-    __device__ __forceinline__ double uniform() { return rocrand_uniform_double(&st); }
+    // (0, 1] from 53 random bits
+    static __device__ __forceinline__ double to_unit(unsigned int a, unsigned int b) {
+        const unsigned long long bits = (((unsigned long long)a << 32) | b) >> 11;
+        return ((double)bits + 1.0) * 1.1102230246251565e-16;  // 2^-53
+    }
+    __device__ __forceinline__ double uniform() {
+        const unsigned int a = rocrand(&st), b = rocrand(&st);
+        return to_unit(a, b);
+    }
 };
 
 // Gamma(alpha, 1) by Marsaglia & Tsang (2000) with the alpha < 1 boost
 // (the method torch's sample_gamma uses for Dirichlet draws).
-__device__ inline double sample_gamma(double alpha, Rng& rng) {
+__device__ BEAN_NOINLINE double sample_gamma(double alpha, Rng& rng) {
     double scale = 1.0;
     if (alpha < 1.0) {
         if (alpha == 0.0) return 0.0;
-        scale = pow(rng.uniform(), 1.0 / alpha);
+        scale = exp(flog(rng.uniform()) * frcp(alpha));
         alpha += 1.0;
     }
     const double d = alpha - 1.0 / 3.0;
-    const double c = 1.0 / sqrt(9.0 * d);
+    const double c = frcp(sqrt(9.0 * d));
     for (int it = 0; it < 64; ++it) {  // acceptance >= 95 % per round; bounded for safety
         double x, y;
         do {
@@ -293,7 +358,7 @@ __device__ inline double sample_gamma(double alpha, Rng& rng) {
         const double u = rng.uniform();
         const double xx = x * x;
         if (u < 1.0 - 0.0331 * xx * xx) return scale * d * v;
-        if (log(u) < 0.5 * xx + d * (1.0 - v + log(v))) return scale * d * v;
+        if (flog(u) < 0.5 * xx + d * (1.0 - v + flog(v))) return scale * d * v;
     }
     return scale * d;  // unreachable in practice (p < 1e-80)
 }

@@ -78,7 +78,10 @@ def test_dirichlet_grad_matches_torch(engine):
     ok = np.isfinite(ref)
     assert ok.mean() > 0.999
     rel = np.abs(g.cpu().numpy()[ok] - ref[ok]) / np.maximum(1e-300, np.abs(ref[ok]))
-    assert rel.max() < 1e-8, rel.max()
+    # the saddle-point branch cancels near x ~ mean: torch's own value carries the same
+    # rounding sensitivity, so bound the tail loosely and the bulk tightly
+    assert rel.max() < 1e-6, rel.max()
+    assert np.quantile(rel, 0.999) < 1e-10
 
 
 @pytest.mark.parametrize("a,b", [(0.3, 0.7), (0.9, 14.0), (2.5, 2.5), (40.0, 7.0), (1e-5, 3.0)])
