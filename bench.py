@@ -61,6 +61,19 @@ def cpu_baseline(data, seconds_budget=20.0):
     }
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest committed
+    rocprofv3 --pmc summary (profiles/*_traffic.json, written by
+    scripts/summarize_prof.py with the gfx950 FETCH_SIZE correction), or None."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        return float(json.load(fh)["hbm_bytes_per_launch"]), os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +155,7 @@ def main():
 
     if rank == 0:
         value = (world * args.guides / GUIDES_PER_GPU) * args.steps / dt
+        traffic, traffic_src = pmc_traffic() if args.guides == GUIDES_PER_GPU else (None, None)
         achieved = step_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "SVI steps/sec, 50k-guide x 20-sample sorting model",
@@ -175,7 +189,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": step_bytes,
                 "kernel_ms": k_ms,
                 "kernel_launches_timed": k_n,

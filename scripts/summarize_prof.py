@@ -1,22 +1,54 @@
-"""Condense rocprofv3 CSV output (scripts/profile.sh) into a small text summary."""
+"""Condense rocprofv3 CSV output (scripts/profile.sh) into profiles/<tag>_*.
+
+    python scripts/summarize_prof.py gpurun_out/prof_<tag> <tag>
+
+Writes profiles/<tag>_kernel_stats.csv (the --stats table restricted to this
+library's kernels), profiles/<tag>_counters.txt (mean per dispatch of every PMC
+counter collected, per kernel) and profiles/<tag>_traffic.json (HBM bytes per
+launch of the dominant kernel: FETCH_SIZE is doubled as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950, both counters are
+in KiB).
+"""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
-root = sys.argv[1]
-out = []
+root, tag = sys.argv[1], sys.argv[2]
+os.makedirs("profiles", exist_ok=True)
 for f in glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recursive=True):
-    out.append(f"== kernel stats ({os.path.relpath(f, root)})")
-    out.append(open(f).read().strip())
+    rows = list(csv.reader(open(f)))
+    keep = [rows[0]] + [r for r in rows[1:] if "bean::" in r[0]]
+    with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as out:
+        csv.writer(out).writerows(keep)
+lines, traffic = [], {}
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         agg = defaultdict(lambda: defaultdict(list))
+        meta = {}
         for row in csv.DictReader(open(f)):
-            agg[row["Kernel_Name"].split("(")[0][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        out.append(f"== counters, mean per dispatch ({sub})")
+            if "bean::" not in row["Kernel_Name"]:
+                continue
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            meta[k] = (row["VGPR_Count"], row["Accum_VGPR_Count"], row["SGPR_Count"], row["Scratch_Size"],
+                       row["LDS_Block_Size"], row["Workgroup_Size"], row["Grid_Size"])
+        lines.append(f"== {sub}: mean per dispatch")
         for k, cs in sorted(agg.items()):
+            lines.append(f"{k}  [vgpr {meta[k][0]} agpr {meta[k][1]} sgpr {meta[k][2]} scratch {meta[k][3]} "
+                         f"lds {meta[k][4]} wg {meta[k][5]} grid {meta[k][6]}]")
             for c, v in sorted(cs.items()):
-                out.append(f"{k:60s} {c:24s} n={len(v):5d} mean={sum(v)/len(v):.6g}")
-print("\n".join(out))
+                lines.append(f"    {c:24s} n={len(v):5d} mean={sum(v) / len(v):.6g}")
+                if "k_guide" in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
+                    traffic[c] = sum(v) / len(v)
+open(f"profiles/{tag}_counters.txt", "w").write("\n".join(lines) + "\n")
+if traffic:
+    fetch = traffic.get("FETCH_SIZE", 0.0) * 1024 * 2  # KiB; gfx950 reports half of a coalesced stream
+    write = traffic.get("WRITE_SIZE", 0.0) * 1024
+    json.dump({"kernel": "k_guide", "fetch_bytes_corrected": fetch, "write_bytes": write,
+               "hbm_bytes_per_launch": fetch + write,
+               "note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as read; separate --pmc passes"},
+              open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+print("\n".join(lines))
