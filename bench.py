@@ -110,6 +110,7 @@ def main():
     eng = engine.HipSVI(
         "MixtureNormal", data, num_steps=max(total, 1), loss_capacity=total + 64,
         scale_by_accessibility=args.scale_by_acc, device=dev,
+        guide_offset=rank * args.guides, target_offset=rank * data.n_targets, n_guides_total=world * args.guides,
     )
 
     def run_steps(n):

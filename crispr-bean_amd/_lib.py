@@ -41,6 +41,10 @@ class bean_hip_shape(ctypes.Structure):
         ("n_edits", c_int32),
         ("n_ctrl", c_int32),
         ("mask_thres", c_int32),
+        ("max_target_len", c_int32),
+        ("guide_offset", c_int32),
+        ("target_offset", c_int32),
+        ("n_guides_total", c_int32),
         ("reserved", c_int32),
         ("sd_prior_scale", c_double),
         ("initial_lr", c_double),

@@ -155,6 +155,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (s->family == BEAN_FAMILY_CONTROL_NORMAL && s->n_targets != 1)
         return fail("bean_hip_create: ControlNormal requires n_targets == 1");
     if (!(s->lrd > 0.0) || !(s->initial_lr > 0.0)) return fail("bean_hip_create: lr and lrd must be > 0");
+    if (s->guide_offset < 0 || s->target_offset < 0 ||
+        (s->n_guides_total > 0 && s->guide_offset + s->n_guides > s->n_guides_total))
+        return fail("bean_hip_create: shard offsets outside the whole screen");
 
     bean_hip_ctx* c = new bean_hip_ctx();
     memset(&c->d, 0, sizeof(DevArgs));
@@ -171,9 +174,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.R = s->n_reps; d.B = s->n_condits; d.G = s->n_guides; d.T = s->n_targets;
     d.A = s->n_max_alleles; d.C = s->n_ctrl;
     d.family = s->family; d.flags = s->flags; d.mask_thres = s->mask_thres;
-    // reserved carries the longest target (guides per target); few very long
-    // targets are reduced by one block each
-    d.wide_targets = (s->n_targets < 64 || s->reserved > 256) ? 1 : 0;
+    d.wide_targets = (s->n_targets < 64 || s->max_target_len > 256) ? 1 : 0;
+    d.g_off = s->guide_offset; d.t_off = s->target_offset;
+    d.G_tot = s->n_guides_total > 0 ? s->n_guides_total : s->n_guides;
     d.sd_prior_scale = s->sd_prior_scale; d.lr0 = s->initial_lr; d.log_lrd = log(s->lrd);
     d.clip = s->clip_norm;
 

@@ -53,6 +53,7 @@ enum Part { kPGmu = 0, kPGy = 1, kPGnoise = 2, kPNrg = 3, kPPath = 4, kPLp = 6, 
 struct DevArgs {
     int R, B, G, T, A, C;
     int family, flags, mask_thres, wide_targets;
+    int g_off, t_off, G_tot;  // shard position (RNG streams use global indices)
     double sd_prior_scale, lr0, log_lrd, clip;
     unsigned long long seed;
     // data
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                     eps2 = c.eps_sd_in[t];
                 } else {
                     rocrand_state_philox4x32_10 st;
-                    rocrand_init(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)t,
+                    rocrand_init(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + t),
                                  s_prep * 4ull, &st);
                     const float2 n = rocrand_normal2(&st);
                     eps1 = (double)n.x;
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                     eps = c.eps_noise_in[g];
                 } else {
                     rocrand_state_philox4x32_10 st;
-                    rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)g,
+                    rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)(c.g_off + g),
                                  s_prep * 4ull, &st);
                     eps = (double)rocrand_normal(&st);
                 }
@@ -488,7 +489,7 @@ void k_guide(DevArgs c) {
                     pi[0] = c.pi_in[((long)r * G + g) * 2];
                     pi[1] = c.pi_in[((long)r * G + g) * 2 + 1];
                 } else {
-                    Rng rng(c.seed, kSitePi, (unsigned long long)r * G + g, ctr.step * 256ull);
+                    Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
                     // rolled loop (one copy of the sampler in the code); selects instead of
                     // runtime-indexed arrays, which would live in scratch
                     double gm0 = 0.0, gm1 = 0.0;

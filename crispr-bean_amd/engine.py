@@ -55,6 +55,9 @@ class HipSVI:
         mask_thres: int = 10,
         dump_noise: bool = False,
         device=None,
+        guide_offset: int = 0,
+        target_offset: int = 0,
+        n_guides_total: int = 0,
     ):
         if family not in _lib.FAMILY:
             raise ValueError(f"unknown model family {family!r}")
@@ -109,7 +112,8 @@ class HipSVI:
         shape = _lib.bean_hip_shape(
             family=_lib.FAMILY[family], selection=0, flags=flags, n_reps=R, n_condits=B, n_guides=G,
             n_targets=T, n_max_alleles=2, n_edits=0, n_ctrl=n_ctrl, mask_thres=int(mask_thres),
-            reserved=max_len,
+            max_target_len=max_len, guide_offset=int(guide_offset), target_offset=int(target_offset),
+            n_guides_total=int(n_guides_total), reserved=0,
             # the reference holds the prior scale in a float32 tensor (model.py:406)
             sd_prior_scale=1.0 if family == "ControlNormal" else float(np.float32(sd_scale)),
             initial_lr=self.initial_lr, lrd=self.lrd, clip_norm=10.0,

@@ -93,34 +93,71 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
     constrained values, exactly the structure the reference returns.
     A non-finite loss raises ``ValueError`` after dumping the parameters to
     ``tmp_result.pkl``, as the reference does on a ``ValueError`` inside the loop.
+
+    When ``torch.distributed`` is initialised with more than one rank the guides
+    are sharded on target boundaries (``parallel.run_sharded``): every rank fits
+    its shard on its own GPU and all ranks return the whole-screen result.
     """
-    data_dev = data if data.X.is_cuda else data.to("cuda")
-    eng = build_engine(model, guide, data_dev, initial_lr=initial_lr, gamma=gamma, num_steps=num_steps)
+    import torch.distributed as dist
+
+    from .. import parallel
+
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    device = torch.device("cuda", torch.cuda.current_device())
+    spec = _resolve(model)
+    # ControlNormal has screen-wide scalar parameters and only sees the (small)
+    # negative-control subset: every rank fits it redundantly instead of sharding
+    sharded = world > 1 and spec.family != "ControlNormal"
+    engines = []
+
+    def factory(shard_data, shard, n_total):
+        eng = build_engine(
+            model, guide, shard_data.to(device), initial_lr=initial_lr, gamma=gamma, num_steps=num_steps,
+            device=device, guide_offset=shard[0], target_offset=shard[2], n_guides_total=n_total,
+        )
+        engines.append(eng)
+        return eng
+
+    def report(step, loss):
+        if verbose:
+            print(f"loss {loss} @ iter {step}")
+
     try:
-        done = 0
-        while done < num_steps:
-            k = min(report_every, num_steps - done)
-            eng.run(k, seed=seed)
-            if verbose:
-                torch.cuda.synchronize(eng.device)
-                print(f"loss {float(eng.loss_hist[done])} @ iter {done}")
-            done += k
-        losses = eng.losses()
+        if sharded:
+            constrained, losses = parallel.run_sharded(
+                factory, data, num_steps, seed=seed, report_every=report_every, on_report=report)
+        else:
+            g = parallel._Group.__new__(parallel._Group)  # single-process group: no collectives
+            g.on, g.group = False, None
+            whole = (0, data.n_guides, 0, getattr(data, "n_targets", 0))
+            eng = factory(data, whole, data.n_guides)
+            done = 0
+            while done < num_steps:
+                k = min(report_every, num_steps - done)
+                eng.run(k, seed=seed)
+                if verbose:
+                    torch.cuda.synchronize(eng.device)
+                    report(done, float(eng.loss_hist[done]))
+                done += k
+            losses = eng.losses()
+            constrained = eng.constrained()
         if not all(l == l and abs(l) != float("inf") for l in losses):
             bad = next(i for i, l in enumerate(losses) if not (l == l and abs(l) != float("inf")))
             raise ValueError(f"non-finite loss at iteration {bad}")
     except ValueError as exc:
         error("Error occurred during fitting. Saving temporary output at tmp_result.pkl.")
         with open("tmp_result.pkl", "wb") as handle:
-            pkl.dump({"param": {k: v.cpu() for k, v in eng.constrained().items()}}, handle)
-        eng.close()
+            dump = {k: v.cpu() for k, v in engines[-1].constrained().items()} if engines else {}
+            pkl.dump({"param": dump}, handle)
+        for e in engines:
+            e.close()
         raise ValueError(
             f"Fitting halted for command: {' '.join(sys.argv)} with following error: \n {exc}"
         )
-    constrained = eng.constrained()
+    for e in engines:
+        e.close()
     store = ParamStore(constrained)
     out = {"loss": losses, "params": {k: v.detach().cpu() for k, v in constrained.items()}}
-    eng.close()
     return store, out
 
 

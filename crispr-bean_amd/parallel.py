@@ -1,0 +1,153 @@
+"""Guide-sharded multi-GPU SVI: one process per GPU (``torch.distributed``).
+
+The reference has no distributed code.  The scaling axis of its hot path is the
+guide dimension, and guides are stored target-sorted
+(``bean/preprocessing/data_class.py:511-532``), so the screen is cut on *target
+boundaries*: in the variant families every parameter is per-target or per-guide
+(``bean/model/model.py:800-830``), hence parameters, gradients and ClippedAdam
+state are shard-local and no gradient crosses GPUs.  What is exchanged:
+
+* every ``report_every`` steps (100, the reference's loss-print cadence,
+  ``bean/model/run.py:378``): one all-reduce (RCCL over xGMI with the ``nccl``
+  backend) of that window of the per-step loss vector;
+* once at the end: an all-gather of the fitted parameters so every rank
+  returns the whole-screen parameter store.
+
+Random streams are keyed by global guide/target indices
+(``bean_hip_shape.guide_offset`` ...), so an N-GPU fit reproduces the 1-GPU fit
+bit for bit.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+Shard = Tuple[int, int, int, int]  # (guide_start, guide_end, target_start, target_end)
+
+
+def plan_shards(target_lengths: Sequence[int], world_size: int) -> List[Shard]:
+    """Cut the target-sorted guide axis into ``world_size`` contiguous,
+    target-aligned shards of near-equal guide count.  Shards may be empty when
+    there are fewer targets than ranks."""
+    tl = np.asarray(target_lengths, dtype=np.int64)
+    T, G = tl.size, int(tl.sum())
+    ends = np.cumsum(tl)  # guide index after each target
+    shards: List[Shard] = []
+    t0 = g0 = 0
+    for k in range(world_size):
+        left = world_size - 1 - k  # ranks after this one
+        if k == world_size - 1 or t0 >= T:
+            t1 = T
+        else:
+            want = (k + 1) * G / world_size
+            # target boundary closest to the ideal cut ...
+            j = int(np.searchsorted(ends, want, side="left"))
+            if j + 1 < T and j >= t0 and abs(ends[j] - want) > abs(want - (ends[j - 1] if j > 0 else 0)):
+                j -= 1
+            t1 = j + 1
+            # ... keeping at least one target here and one for every later rank
+            t1 = max(t1, t0 + 1)
+            t1 = min(t1, max(T - left, t0 + 1), T)
+        g1 = int(ends[t1 - 1]) if t1 > 0 else 0
+        shards.append((g0, g1, t0, t1))
+        t0, g0 = t1, g1
+    assert shards[-1][1] == G and shards[-1][3] == T
+    return shards
+
+
+def shard_screen(data, shard: Shard):
+    """Per-rank view of the screen.  Per-sample tensors (size factors, masks,
+    bin edges) are global and shared; per-guide tensors are sliced."""
+    g0, g1, _, _ = shard
+    return data[np.arange(g0, g1)]
+
+
+class _Group:
+    """torch.distributed helpers that also work single-process."""
+
+    def __init__(self, group=None):
+        self.on = dist.is_available() and dist.is_initialized()
+        self.group = group
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if self.on else 1
+
+    @property
+    def rank(self):
+        return dist.get_rank(self.group) if self.on else 0
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        if self.on and self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather_rows(self, t: torch.Tensor, sizes: Sequence[int]) -> torch.Tensor:
+        """Concatenate per-rank tensors with different leading sizes."""
+        if not self.on or self.world == 1:
+            return t
+        m = max(max(sizes), 1)
+        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        out = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(out, pad, group=self.group)
+        return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
+
+
+PER_TARGET = ("mu_loc", "mu_scale", "sd_loc", "sd_scale")
+PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale")
+
+
+def run_sharded(
+    engine_factory: Callable,
+    data,
+    num_steps: int,
+    *,
+    seed: int = 101,
+    report_every: int = 100,
+    group=None,
+    on_report: Optional[Callable[[int, float], None]] = None,
+):
+    """Fit the whole screen with one engine per rank.
+
+    ``engine_factory(shard_data, shard, n_guides_total)`` must return an object
+    with ``run(k, seed=)``, ``loss_hist`` (tensor of per-step losses),
+    ``steps_done``, ``constrained()`` and ``close()`` - ``HipSVI`` on a GPU, or a
+    CPU stand-in in the gloo tests.  Returns ``(constrained_params, losses)`` for
+    the WHOLE screen on every rank.
+    """
+    grp = _Group(group)
+    shards = plan_shards(data.target_lengths.cpu().numpy(), grp.world)
+    mine = shards[grp.rank]
+    if mine[1] - mine[0] == 0:
+        raise ValueError(
+            f"rank {grp.rank} received no guides: {data.n_targets} targets cannot feed {grp.world} ranks"
+        )
+    eng = engine_factory(shard_screen(data, mine), mine, data.n_guides)
+    done = 0
+    while done < num_steps:
+        k = min(report_every, num_steps - done)
+        eng.run(k, seed=seed)
+        window = eng.loss_hist[done : done + k]
+        stream = getattr(eng, "stream", None)
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                grp.all_reduce_sum(window)
+        else:
+            grp.all_reduce_sum(window)
+        if on_report is not None:
+            on_report(done, float(window[0]))
+        done += k
+    losses = eng.loss_hist[:num_steps].detach().cpu().tolist()
+    local = eng.constrained()
+    g_sizes = [s[1] - s[0] for s in shards]
+    t_sizes = [s[3] - s[2] for s in shards]
+    whole: Dict[str, torch.Tensor] = {}
+    for name, t in local.items():
+        sizes = g_sizes if name in PER_GUIDE else t_sizes
+        whole[name] = grp.all_gather_rows(t.contiguous(), sizes)
+    eng.close()
+    return whole, losses

@@ -77,6 +77,13 @@ typedef struct bean_hip_shape {
     int32_t n_edits;       /* E (tiling) */
     int32_t n_ctrl;        /* C: control conditions in allele_counts_control */
     int32_t mask_thres;    /* guides with sum_b x <= mask_thres are masked (10) */
+    int32_t max_target_len;/* longest target (guides); very long targets get one block each */
+    /* position of this shard inside the whole screen: the random streams are
+     * keyed by GLOBAL guide / target indices, so a guide-sharded multi-GPU fit
+     * reproduces the single-GPU fit bit for bit */
+    int32_t guide_offset;  /* index of this shard's first guide in the whole screen */
+    int32_t target_offset; /* index of this shard's first target */
+    int32_t n_guides_total;/* guides in the whole screen (0 = n_guides) */
     int32_t reserved;
     double sd_prior_scale; /* LogNormal prior scale of sd_targets (0.01; 1.0 for ControlNormal) */
     double initial_lr;     /* ClippedAdam lr (0.01) */

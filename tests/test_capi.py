@@ -64,7 +64,8 @@ def test_slot_numbers_match_header():
 
 def _shape(**kw):
     base = dict(family=2, selection=0, flags=1, n_reps=2, n_condits=5, n_guides=10, n_targets=2,
-                n_max_alleles=2, n_edits=0, n_ctrl=1, mask_thres=10, reserved=5, sd_prior_scale=0.01,
+                n_max_alleles=2, n_edits=0, n_ctrl=1, mask_thres=10, max_target_len=5, guide_offset=0,
+                target_offset=0, n_guides_total=0, reserved=0, sd_prior_scale=0.01,
                 initial_lr=0.01, lrd=0.999, clip_norm=10.0)
     base.update(kw)
     return _lib.bean_hip_shape(**base)
@@ -78,6 +79,7 @@ def _shape(**kw):
     (dict(n_max_alleles=3), "n_max_alleles"),
     (dict(family=1, n_targets=2), "ControlNormal"),
     (dict(lrd=0.0), "lrd"),
+    (dict(guide_offset=5, n_guides_total=12), "shard offsets"),
 ])
 def test_create_rejects_bad_shapes_without_a_device(lib, kw, msg):
     h = ctypes.c_void_p()

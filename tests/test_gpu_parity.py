@@ -81,7 +81,7 @@ def test_dirichlet_grad_matches_torch(engine):
     # the saddle-point branch cancels near x ~ mean: torch's own value carries the same
     # rounding sensitivity, so bound the tail loosely and the bulk tightly
     assert rel.max() < 1e-6, rel.max()
-    assert np.quantile(rel, 0.999) < 1e-10
+    assert np.quantile(rel, 0.9) < 1e-12 and np.quantile(rel, 0.999) < 1e-8
 
 
 @pytest.mark.parametrize("a,b", [(0.3, 0.7), (0.9, 14.0), (2.5, 2.5), (40.0, 7.0), (1e-5, 3.0)])
@@ -333,3 +333,31 @@ def test_full_size_fit_is_deterministic_and_improves(engine, full_screen):
     losses = runs[0][1]
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
     np.testing.assert_allclose(runs[0][1], runs[1][1], rtol=1e-12)  # atomically summed, not bitwise
+
+
+def test_sharded_engines_reproduce_the_whole_screen_fit(engine):
+    """Two target-aligned shards fitted separately with their global offsets
+    reproduce the single-engine fit bit for bit (what makes the N-GPU run
+    independent of N)."""
+    from bean_amd import parallel
+
+    data = make_sorting_variant_screen(1000, 3, seed=81, with_accessibility=True)
+    kw = dict(scale_by_accessibility=True, num_steps=300)
+    whole = engine.HipSVI("MixtureNormal", data.to(DEV), **kw)
+    whole.run(60, seed=5)
+    ref = whole.constrained()
+    ref_losses = np.array(whole.losses())
+    shards = parallel.plan_shards(data.target_lengths.numpy(), 3)
+    parts, losses = [], np.zeros(60)
+    for sh in shards:
+        e = engine.HipSVI("MixtureNormal", parallel.shard_screen(data, sh).to(DEV), guide_offset=sh[0],
+                          target_offset=sh[2], n_guides_total=data.n_guides, **kw)
+        e.run(60, seed=5)
+        parts.append(e.constrained())
+        losses += np.array(e.losses())
+        e.close()
+    for k in ref:
+        got = torch.cat([p[k] for p in parts], dim=0)
+        assert torch.equal(got, ref[k]), k
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-12)
+    whole.close()
