@@ -45,7 +45,7 @@ class bean_hip_shape(ctypes.Structure):
         ("guide_offset", c_int32),
         ("target_offset", c_int32),
         ("n_guides_total", c_int32),
-        ("reserved", c_int32),
+        ("n_a2e_nnz", c_int32),
         ("sd_prior_scale", c_double),
         ("initial_lr", c_double),
         ("lrd", c_double),
@@ -61,6 +61,7 @@ BUF = {
     "SAMPLE_MASK": 6, "A0": 7, "A0_BC": 8, "PI_A0": 9, "Z_HI": 10, "Z_LO": 11,
     "TARGET_OFFSETS": 12, "GUIDE_TO_TARGET": 13, "ACCESSIBILITY": 14,
     "PRIOR_MU_LOC": 15, "PRIOR_MU_SCALE": 16, "PRIOR_SD_LOC": 17, "PRIOR_SD_SCALE": 18,
+    "A2E_PTR": 19, "A2E_IDX": 20, "E2A_PTR": 21, "E2A_IDX": 22, "ALLELE_MASK": 23,
     "P": 32, "G": 48, "M": 64, "V": 80,
     "EPS_MU_IN": 96, "EPS_SD_IN": 97, "PI_IN": 98, "EPS_NOISE_IN": 99,
     "EPS_MU_OUT": 100, "EPS_SD_OUT": 101, "PI_OUT": 102, "EPS_NOISE_OUT": 103,

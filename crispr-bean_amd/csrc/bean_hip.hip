@@ -44,7 +44,11 @@ struct bean_hip_ctx {
 extern "C" const char* bean_hip_version(void) { return "bean_hip 0.1.0 (gfx950)"; }
 extern "C" const char* bean_hip_last_error(void) { return g_err.c_str(); }
 
-static bool is_mixture(const bean_hip_shape& s) { return s.family == BEAN_FAMILY_MIXTURE_NORMAL; }
+static bool is_tiling(const bean_hip_shape& s) { return s.family == BEAN_FAMILY_MULTI_MIXTURE; }
+// families with a Dirichlet pi site (reporter models)
+static bool is_mixture(const bean_hip_shape& s) {
+    return s.family == BEAN_FAMILY_MIXTURE_NORMAL || s.family == BEAN_FAMILY_MULTI_MIXTURE;
+}
 
 // Bytes the shape implies for a slot (0 = slot not used by this shape).
 static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
@@ -74,8 +78,12 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_A0_BC: return (s.flags & BEAN_FLAG_USE_BCMATCH) ? 8 * G : 0;
         case BEAN_BUF_PI_A0: return is_mixture(s) ? 8 * G : 0;
         case BEAN_BUF_Z_HI: case BEAN_BUF_Z_LO: return 8 * B;
-        case BEAN_BUF_TARGET_OFFSETS: return 4 * (T + 1);
-        case BEAN_BUF_GUIDE_TO_TARGET: return 4 * G;
+        case BEAN_BUF_TARGET_OFFSETS: return is_tiling(s) ? 0 : 4 * (T + 1);
+        case BEAN_BUF_GUIDE_TO_TARGET: return is_tiling(s) ? 0 : 4 * G;
+        case BEAN_BUF_A2E_PTR: return is_tiling(s) ? 4 * (G * (A - 1) + 1) : 0;
+        case BEAN_BUF_A2E_IDX: case BEAN_BUF_E2A_IDX: return is_tiling(s) ? 4 * (uint64_t)s.n_a2e_nnz : 0;
+        case BEAN_BUF_E2A_PTR: return is_tiling(s) ? 4 * ((uint64_t)s.n_edits + 1) : 0;
+        case BEAN_BUF_ALLELE_MASK: return is_tiling(s) ? G * A : 0;
         case BEAN_BUF_ACCESSIBILITY: return (s.flags & BEAN_FLAG_SCALE_BY_ACC) ? 8 * G : 0;
         case BEAN_BUF_PRIOR_MU_LOC: case BEAN_BUF_PRIOR_MU_SCALE:
         case BEAN_BUF_PRIOR_SD_LOC: case BEAN_BUF_PRIOR_SD_SCALE: return 8 * T;
@@ -105,6 +113,11 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.z_hi = (const double*)P(BEAN_BUF_Z_HI);
     d.z_lo = (const double*)P(BEAN_BUF_Z_LO);
     d.acc = (const double*)P(BEAN_BUF_ACCESSIBILITY);
+    d.a2e_ptr = (const int*)P(BEAN_BUF_A2E_PTR);
+    d.a2e_idx = (const int*)P(BEAN_BUF_A2E_IDX);
+    d.e2a_ptr = (const int*)P(BEAN_BUF_E2A_PTR);
+    d.e2a_idx = (const int*)P(BEAN_BUF_E2A_IDX);
+    d.amask = (const uint8_t*)P(BEAN_BUF_ALLELE_MASK);
     d.toff = (const int*)P(BEAN_BUF_TARGET_OFFSETS);
     d.g2t = (const int*)P(BEAN_BUF_GUIDE_TO_TARGET);
     d.pr_mu_loc = (const double*)P(BEAN_BUF_PRIOR_MU_LOC);
@@ -142,15 +155,21 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (!s || !out) return fail("bean_hip_create: null argument");
     if (s->selection != BEAN_SELECTION_SORTING)
         return fail("bean_hip_create: only sorting screens are implemented in this build");
-    if (s->family != BEAN_FAMILY_NORMAL && s->family != BEAN_FAMILY_CONTROL_NORMAL &&
-        s->family != BEAN_FAMILY_MIXTURE_NORMAL)
-        return fail("bean_hip_create: family not implemented in this build");
+    if (s->family < BEAN_FAMILY_NORMAL || s->family > BEAN_FAMILY_MULTI_MIXTURE)
+        return fail("bean_hip_create: unknown family");
     if (s->n_reps < 1 || s->n_guides < 1 || s->n_targets < 1)
         return fail("bean_hip_create: R, G, T must be >= 1");
     if (s->n_condits < 1 || s->n_condits > 8)
         return fail("bean_hip_create: n_condits must be in [1, 8]");
-    if (is_mixture(*s) && s->n_max_alleles != 2)
+    if (s->family == BEAN_FAMILY_MIXTURE_NORMAL && s->n_max_alleles != 2)
         return fail("bean_hip_create: MixtureNormal requires n_max_alleles == 2");
+    if (is_tiling(*s)) {
+        if (s->n_max_alleles < 2 || s->n_max_alleles > kAMax)
+            return fail("bean_hip_create: MultiMixtureNormal requires n_max_alleles in [2, 8]");
+        if (s->n_edits < 1 || s->n_targets != s->n_edits)
+            return fail("bean_hip_create: MultiMixtureNormal requires n_targets == n_edits >= 1");
+        if (s->n_a2e_nnz < 0) return fail("bean_hip_create: n_a2e_nnz must be >= 0");
+    }
     if (is_mixture(*s) && s->n_ctrl < 1) return fail("bean_hip_create: MixtureNormal requires n_ctrl >= 1");
     if (s->family == BEAN_FAMILY_CONTROL_NORMAL && s->n_targets != 1)
         return fail("bean_hip_create: ControlNormal requires n_targets == 1");
@@ -172,16 +191,19 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->loss_capacity = 0;
     DevArgs& d = c->d;
     d.R = s->n_reps; d.B = s->n_condits; d.G = s->n_guides; d.T = s->n_targets;
-    d.A = s->n_max_alleles; d.C = s->n_ctrl;
+    d.A = s->n_max_alleles; d.C = s->n_ctrl; d.E = s->n_edits;
     d.family = s->family; d.flags = s->flags; d.mask_thres = s->mask_thres;
-    d.wide_targets = (s->n_targets < 64 || s->max_target_len > 256) ? 1 : 0;
+    d.wide_targets = (!is_tiling(*s) && (s->n_targets < 64 || s->max_target_len > 256)) ? 1 : 0;
     d.g_off = s->guide_offset; d.t_off = s->target_offset;
     d.G_tot = s->n_guides_total > 0 ? s->n_guides_total : s->n_guides;
     d.sd_prior_scale = s->sd_prior_scale; d.lr0 = s->initial_lr; d.log_lrd = log(s->lrd);
     d.clip = s->clip_norm;
 
     const uint64_t B = d.B, T = d.T, G = d.G;
-    const uint64_t n_dbl = 3 * B * T + B + 4 * T + (uint64_t)kNumPart * G + 2 * G + 1 + 8;
+    const uint64_t A1 = is_tiling(*s) ? (uint64_t)(d.A - 1) : 0;
+    const uint64_t n_tab = is_tiling(*s) ? A1 * G : T;  // table columns: allele slots or targets
+    const uint64_t n_part = is_tiling(*s) ? (uint64_t)kTNumPart : (uint64_t)kNumPart;
+    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 1 + 8;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
     if (e != hipSuccess) {
@@ -195,15 +217,17 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         return fail(std::string("hipMemset workspace: ") + hipGetErrorString(e));
     }
     double* w = (double*)c->workspace;
-    d.tabP = w; w += B * T;
-    d.tabPmu = w; w += B * T;
-    d.tabPy = w; w += B * T;
+    d.tabP = w; w += B * n_tab;
+    d.tabPmu = w; w += B * n_tab;
+    d.tabPy = w; w += B * n_tab;
     d.P0 = w; w += B;
     d.mu_t = w; w += T;
     d.y_t = w; w += T;
     d.eps_mu = w; w += T;
     d.eps_sd = w; w += T;
-    d.part = w; w += (uint64_t)kNumPart * G;
+    d.part = w; w += n_part * G;
+    d.mu_a = w; w += A1 * G;
+    d.sig_a = w; w += A1 * G;
     d.lpn = w; w += G;
     d.eps_noise = w; w += G;
     d.loss_const = w; w += 1;
@@ -254,8 +278,13 @@ static int check_bound(bean_hip_ctx* c, bool need_grads, bool need_moments) {
     const bean_hip_shape& s = c->shape;
 #define REQ(slot) if (require(c, slot, #slot)) return -1
     REQ(BEAN_BUF_X); REQ(BEAN_BUF_REPGUIDE); REQ(BEAN_BUF_SIZE_FACTOR); REQ(BEAN_BUF_SAMPLE_MASK);
-    REQ(BEAN_BUF_A0); REQ(BEAN_BUF_Z_HI); REQ(BEAN_BUF_Z_LO); REQ(BEAN_BUF_TARGET_OFFSETS);
-    REQ(BEAN_BUF_GUIDE_TO_TARGET); REQ(BEAN_BUF_LOSS_HIST);
+    REQ(BEAN_BUF_A0); REQ(BEAN_BUF_Z_HI); REQ(BEAN_BUF_Z_LO); REQ(BEAN_BUF_LOSS_HIST);
+    if (is_tiling(s)) {
+        REQ(BEAN_BUF_A2E_PTR); REQ(BEAN_BUF_E2A_PTR); REQ(BEAN_BUF_ALLELE_MASK);
+        if (s.n_a2e_nnz > 0) { REQ(BEAN_BUF_A2E_IDX); REQ(BEAN_BUF_E2A_IDX); }
+    } else {
+        REQ(BEAN_BUF_TARGET_OFFSETS); REQ(BEAN_BUF_GUIDE_TO_TARGET);
+    }
     if (s.flags & BEAN_FLAG_USE_BCMATCH) { REQ(BEAN_BUF_X_BC); REQ(BEAN_BUF_SIZE_FACTOR_BC); REQ(BEAN_BUF_A0_BC); }
     if (is_mixture(s)) { REQ(BEAN_BUF_ALLELE_CTRL); REQ(BEAN_BUF_PI_A0); }
     if (s.flags & BEAN_FLAG_SCALE_BY_ACC) REQ(BEAN_BUF_ACCESSIBILITY);
@@ -285,7 +314,7 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
 static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_blocks) {
     const DevArgs& d = c->d;
     n_target_blocks = d.wide_targets ? d.T : (d.T + 255) / 256;
-    n_blocks = n_target_blocks + (d.family == kMixture ? (d.G + 255) / 256 : 0);
+    n_blocks = n_target_blocks + ((d.family == kMixture || d.family == kMultiMixture) ? (d.G + 255) / 256 : 0);
 }
 
 template <bool FINISH, bool ADAM, bool PREP>
@@ -298,7 +327,13 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream) {
 template <int B>
 static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 block, size_t lds) {
     const DevArgs& d = c->d;
-    if (d.family == kMixture) {
+    if (d.family == kMultiMixture) {
+        const size_t tl = ((size_t)kTNumPart * 64 + 16) * sizeof(double);
+        if (d.flags & kAcc)
+            hipLaunchKernelGGL((k_guide_tiling<B, true>), grid, block, tl, stream, d);
+        else
+            hipLaunchKernelGGL((k_guide_tiling<B, false>), grid, block, tl, stream, d);
+    } else if (d.family == kMixture) {
         if (d.flags & kAcc)
             hipLaunchKernelGGL((k_guide<B, kMixture, true>), grid, block, lds, stream, d);
         else
@@ -313,6 +348,10 @@ static int waves_per_block(const bean_hip_ctx* c) { return c->d.R < 8 ? c->d.R :
 static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     const int nw = waves_per_block(c);
+    if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
+        const long n = (long)(d.A - 1) * d.G;
+        hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
+    }
     const dim3 grid((d.G + 63) / 64), block(64 * nw);
     const size_t lds = ((size_t)nw * kNumPart * 64 + 16) * sizeof(double);
     const bool prof = c->profile && c->ev.size() < 8192;
@@ -434,12 +473,15 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
     // counts (f32) once per likelihood, repguide mask, per-guide a0 / a0_bc / g2t
     uint64_t bytes = G * (4 * R * B * (bc ? 2 : 1) + R + 8 * (bc ? 2 : 1) + 4);
     if (is_mixture(s)) bytes += G * (4 * R * s.n_ctrl * A + 8 /*pi_a0*/ + 3 * 4 * A * 2 /*alpha_pi, m, v r+w*/);
+    if (is_tiling(s)) bytes += G * A /*allele_mask*/ + 4 * (G * (A - 1) + 1) + 2 * 4 * (uint64_t)s.n_a2e_nnz + 4 * (T + 1);
     if (s.flags & BEAN_FLAG_SCALE_BY_ACC) bytes += G * (8 + ((s.flags & BEAN_FLAG_FIT_NOISE) ? 2 * 3 * 4 * 2 : 0));
     bytes += T * (4 * 3 * 4 * 2);  // four per-target params with moments, read + written
     return bytes;
 }
 
-extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx*) { return "k_guide"; }
+extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
+    return (c && c->d.family == kMultiMixture) ? "k_guide_tiling" : "k_guide";
+}
 
 extern "C" int bean_hip_set_profile(bean_hip_ctx* c, int32_t enable) {
     if (!c) return fail("bean_hip_set_profile: null handle");

@@ -81,7 +81,18 @@ struct DevArgs {
     double *lpn, *eps_noise;           // (G)
     double* loss_const;                // (1)
     StepCtr *ctrA, *ctrB;
+    // tiling (MultiMixtureNormal): CSR allele slot -> edits and its transpose
+    int E;
+    const int *a2e_ptr, *a2e_idx;  // (G*(A-1)+1), (nnz): slot = g*(A-1) + (a-1)
+    const int *e2a_ptr, *e2a_idx;  // (E+1), (nnz): slots containing each edit
+    const uint8_t* amask;          // (G, A)
+    double *mu_a, *sig_a;          // (A-1, G) allele mean / scale of the current draw
 };
+
+// rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
+constexpr int kAMax = 8;
+enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2 * kAMax,
+             kTGsig = 2 + 2 * kAMax + (kAMax - 1), kTNumPart = 2 + 2 * kAMax + 2 * (kAMax - 1) };
 
 // ---------------------------------------------------------------- reductions
 __device__ __forceinline__ double wave_sum(double v) {
@@ -146,6 +157,117 @@ __device__ __forceinline__ void emit_grad(const DevArgs& c, int which, long idx,
     }
 }
 
+// --------------------------------------------------- tiling: per-guide finish
+// Guide part of k_param for MultiMixtureNormal: Dirichlet normalisers of the
+// A-component pi site, chain to alpha_pi through the two concentration maps the
+// reference uses (guide: alpha/sum * pi_a0, model.py:938; model:
+// (alpha + eps/A)/(sum + eps) * pi_a0 floored at eps, model.py:646-651).
+template <bool FINISH, bool ADAM, bool PREP>
+__device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_target_blocks,
+                                                   unsigned long long s_prep, AdamCoef ak,
+                                                   double& loss_fin) {
+    const int g = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
+    const bool acc_on = (c.flags & kAcc) != 0;
+    const bool fit_noise = acc_on && (c.flags & kFitNoise);
+    if (g >= c.G) return;
+    const int A = c.A;
+    float nl = 0.f, ns_u = 0.f;
+    if (fit_noise) {
+        nl = c.p[5][g];
+        ns_u = c.p[6][g];
+    }
+    if (FINISH) {
+        double alpha[kAMax], S = 0.0;
+        bool am[kAMax];
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {
+            am[a] = a < A && c.amask[(long)g * A + a] != 0;
+            alpha[a] = a < A ? (am[a] ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
+            S += alpha[a];
+        }
+        const double pa0 = c.pi_a0[g];
+        const double rS = frcp(S), rSe = frcp(S + kEps);
+        const double nrg = c.part[(long)kTNrg * c.G + g];
+        double sq = 0.0, sp = 0.0;
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a)
+            if (a < A) {
+                sq += alpha[a] * rS * pa0;
+                const double v = (alpha[a] + kEps / A) * rSe * pa0;
+                sp += v < kEps ? kEps : v;
+            }
+        double lgS_q, dgS_q, lgS_p, dgS_p;
+        lgamma_digamma(sq, lgS_q, dgS_q);
+        lgamma_digamma(sp, lgS_p, dgS_p);
+        double lp = nrg * lgS_p, lq = nrg * lgS_q;
+        double gq[kAMax], gp[kAMax], dq = 0.0, dp = 0.0;
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {
+            gq[a] = 0.0;
+            gp[a] = 0.0;
+            if (a < A) {
+                const double cq = alpha[a] * rS * pa0;
+                const double cpr = (alpha[a] + kEps / A) * rSe * pa0;
+                const bool cpc = cpr < kEps;
+                const double cp = cpc ? kEps : cpr;
+                double lg, dg;
+                lgamma_digamma(cq, lg, dg);
+                const double L = c.part[(long)(kTL + a) * c.G + g];
+                lq += -nrg * lg + (cq - 1.0) * L;
+                gq[a] = L + nrg * (dgS_q - dg) + c.part[(long)(kTPath + a) * c.G + g];
+                lgamma_digamma(cp, lg, dg);
+                lp += -nrg * lg + (cp - 1.0) * L;
+                gp[a] = cpc ? 0.0 : -(L + nrg * (dgS_p - dg));
+                dq += gq[a] * alpha[a];
+                dp += gp[a] * (alpha[a] + kEps / A);
+            }
+        }
+        loss_fin = -lp + lq;
+        dq *= rS * rS;
+        dp *= rSe * rSe;
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a)
+            if (a < A) {
+                const double ga = pa0 * (gq[a] * rS - dq + gp[a] * rSe - dp);
+                emit_grad<ADAM>(c, 4, (long)g * A + a, am[a] ? ga * alpha[a] : 0.0, ak);
+            }
+        if (acc_on) {
+            const double lpn = c.lpn[g], eps = c.eps_noise[g];
+            const double gl = c.part[(long)kTGnoise * c.G + g];
+            const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
+            const float nsf = 0.655f;
+            const double nvar = (double)(nsf * nsf);
+            const double logp = -lpn * lpn / (2.0 * nvar) - (double)logf(nsf) - kHalfLog2PiC;
+            const double logq = -0.5 * eps * eps - log(ns) - kHalfLog2PiC;
+            loss_fin += -logp + logq;
+            if (fit_noise) {
+                const double Gl = gl + lpn / nvar;
+                emit_grad<ADAM>(c, 5, g, Gl, ak);
+                emit_grad<ADAM>(c, 6, g, Gl * eps * ns - 1.0, ak);
+                if (ADAM) {
+                    nl = c.p[5][g];
+                    ns_u = c.p[6][g];
+                }
+            }
+        }
+    }
+    if (PREP && acc_on) {
+        double eps;
+        if (c.eps_noise_in) {
+            eps = c.eps_noise_in[g];
+        } else {
+            rocrand_state_philox4x32_10 st;
+            rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)(c.g_off + g),
+                         s_prep * 4ull, &st);
+            eps = (double)rocrand_normal(&st);
+        }
+        const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
+        c.eps_noise[g] = eps;
+        c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
+        if (c.eps_noise_out) c.eps_noise_out[g] = eps;
+    }
+}
+
 // -------------------------------------------------------------------- k_param
 // grid = n_target_blocks + n_guide_blocks, 256 threads.
 template <bool FINISH, bool ADAM, bool PREP>
@@ -184,10 +306,24 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
             t = blockIdx.x * blockDim.x + threadIdx.x;
             active = t < c.T;
             if (FINISH && active) {
-                const int g0 = c.toff[t], g1 = c.toff[t + 1];
-                for (int g = g0; g < g1; ++g) {
-                    gmu += c.part[(long)kPGmu * c.G + g];
-                    gy += c.part[(long)kPGy * c.G + g];
+                if (c.family == kMultiMixture) {
+                    // edit <- alleles containing it (transposed CSR): the backward of
+                    // allele_to_edit @ mu_edits and ||allele_to_edit * sd_edits|| (model.py:618-622)
+                    const int A1 = c.A - 1;
+                    const double sd = exp(c.y_t[t]);
+                    for (int k = c.e2a_ptr[t]; k < c.e2a_ptr[t + 1]; ++k) {
+                        const int slot = c.e2a_idx[k];
+                        const long o = (long)(slot % A1) * c.G + slot / A1;
+                        gmu += c.part[(long)kTGmu * c.G + o];
+                        // d sigma_a / d y_e = sd_e^2 / sigma_a
+                        gy += c.part[(long)kTGsig * c.G + o] * sd * sd / c.sig_a[o];
+                    }
+                } else {
+                    const int g0 = c.toff[t], g1 = c.toff[t + 1];
+                    for (int g = g0; g < g1; ++g) {
+                        gmu += c.part[(long)kPGmu * c.G + g];
+                        gy += c.part[(long)kPGy * c.G + g];
+                    }
                 }
             }
         }
@@ -263,6 +399,7 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                     c.eps_mu_out[t] = eps1;
                     c.eps_sd_out[t] = eps2;
                 }
+                if (c.family != kMultiMixture) {  // tiling tabulates per allele in k_allele
                 // NormalModel uses sqrt(sd) as the scale (model.py:92-98)
                 const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
                 const double dsig_dy = c.family == kNormal ? 0.5 * sigma : sigma;
@@ -287,8 +424,11 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                     c.tabPmu[o] = -(fh - fl) * inv;
                     c.tabPy[o] = -(ufh - ufl) * inv * dsig_dy;
                 }
+                }
             }
         }
+    } else if (c.family == kMultiMixture) {
+        param_guide_tiling<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
     } else if (mixture) {
         // ------------------------------------------------- guide part
         const int g = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
@@ -648,6 +788,317 @@ void k_guide(DevArgs c) {
     }
 }
 
+// ------------------------------------------------------------------- k_allele
+// Tiling: per allele slot (g, a >= 1): mu_a = sum of its edits' mu, sigma_a =
+// l2 norm of their sd (model.py:618-622) as a CSR gather, then the bin
+// probabilities and their derivatives.  Tables are laid out (B, A-1, G).
+__global__ __launch_bounds__(256) void k_allele(DevArgs c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int A1 = c.A - 1;
+    if (idx >= (long)A1 * c.G) return;
+    const int a1 = (int)(idx / c.G), g = (int)(idx % c.G);
+    const long slot = (long)g * A1 + a1;
+    const bool valid = c.amask[(long)g * c.A + a1 + 1] != 0;
+    double mu = 0.0, var = 0.0;
+    for (int k = c.a2e_ptr[slot]; k < c.a2e_ptr[slot + 1]; ++k) {
+        const int e = c.a2e_idx[k];
+        mu += c.mu_t[e];
+        const double sd = exp(c.y_t[e]);
+        var += sd * sd;
+    }
+    const double sigma = sqrt(var);
+    c.mu_a[idx] = mu;
+    c.sig_a[idx] = sigma;
+    const bool live = valid && var > 0.0;  // masked alleles: probability 0, no gradient (utils.py:56-59,73-74)
+    const double inv = live ? 1.0 / sigma : 0.0;
+    for (int b = 0; b < c.B; ++b) {
+        double P = 0.0, dmu = 0.0, dsig = 0.0;
+        if (live) {
+            const double zh = c.z_hi[b], zl = c.z_lo[b];
+            double ch = 1.0, cl = 0.0, fh = 0.0, fl = 0.0, ufh = 0.0, ufl = 0.0;
+            if (!isinf(zh)) {
+                const double u = (zh - mu) * inv;
+                ch = norm_cdf(u);
+                fh = norm_pdf(u);
+                ufh = u * fh;
+            }
+            if (!isinf(zl)) {
+                const double u = (zl - mu) * inv;
+                cl = norm_cdf(u);
+                fl = norm_pdf(u);
+                ufl = u * fl;
+            }
+            P = ch - cl;
+            dmu = -(fh - fl) * inv;
+            dsig = -(ufh - ufl) * inv;
+        }
+        const long o = ((long)b * A1 + a1) * c.G + g;
+        c.tabP[o] = P;
+        c.tabPmu[o] = dmu;
+        c.tabPy[o] = dsig;  // d/d sigma_a here (chain to y_e in k_param)
+    }
+}
+
+// ------------------------------------------------------------- k_guide_tiling
+// MultiMixtureNormal per (rep, guide): A-component Dirichlet draw, mixture over
+// the guide's alleles, both DirMult terms, Multinomial on control allele counts,
+// implicit gradient.  Static loops over kAMax components, predicated by a < A.
+// dynamic LDS = kTNumPart * 64 doubles + 16.
+template <int B, bool ACC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BEAN_GUIDE_WAVES_PER_EU)))
+void k_guide_tiling(DevArgs c) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int g = blockIdx.x * 64 + lane;
+    const bool valid = g < c.G;
+    const StepCtr ctr = *c.ctrB;
+    const int G = c.G, A = c.A, A1 = c.A - 1;
+
+    double path[kAMax], L[kAMax], gmu_s[kAMax - 1], gsig_s[kAMax - 1];
+#pragma unroll
+    for (int a = 0; a < kAMax; ++a) {
+        path[a] = 0.0;
+        L[a] = 0.0;
+        if (a < kAMax - 1) {
+            gmu_s[a] = 0.0;
+            gsig_s[a] = 0.0;
+        }
+    }
+    double gnoise = 0.0, nrg = 0.0, loss = 0.0;
+
+    if (valid) {
+        const bool use_bc = (c.flags & kUseBc) != 0;
+        double cq[kAMax], total = 0.0;
+        {
+            double alpha[kAMax], S = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a) {
+                const bool am = a < A && c.amask[(long)g * A + a] != 0;
+                alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
+                S += alpha[a];
+            }
+            const double rs = frcp(S) * c.pi_a0[g];
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a) {
+                cq[a] = alpha[a] * rs;
+                total += cq[a];
+            }
+        }
+        double kacc = 0.0, lpn = 0.0;
+        if (ACC) {
+            kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+            lpn = c.lpn[g];
+        }
+        for (int r = w; r < c.R; r += nw) {
+            const bool rgm = c.rg[(long)r * G + g] != 0;
+            // both pi sites, the Multinomial and the count likelihoods are masked by
+            // repguide_mask in tiling (model.py:659,682,731; guide 941): nothing to do
+            if (!rgm) {
+                if (c.flags & kDumpPi)  // exported draws must stay a valid simplex point
+                    for (int a = 0; a < A; ++a) c.pi_out[((long)r * G + g) * A + a] = 1.0 / A;
+                continue;
+            }
+            double pi[kAMax], pe[kAMax], dpe_dpi[kAMax], dpe_dl[kAMax];
+            if (c.pi_in) {
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a) pi[a] = a < A ? c.pi_in[((long)r * G + g) * A + a] : 0.0;
+            } else {
+                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+                double sum = 0.0;
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a) {
+                    pi[a] = 0.0;
+                    if (a < A) {
+                        pi[a] = fmax(sample_gamma(cq[a], rng), kDblMin);
+                        sum += pi[a];
+                    }
+                }
+                const double rs = frcp(sum);
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a)
+                    if (a < A) pi[a] = fmin(fmax(pi[a] * rs, kDblMin), kOneMinus);
+            }
+            if (c.flags & kDumpPi) {
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a)
+                    if (a < A) c.pi_out[((long)r * G + g) * A + a] = pi[a];
+            }
+            double pe0 = pi[0];
+#pragma unroll
+            for (int a = 1; a < kAMax; ++a) {
+                pe[a] = pi[a];
+                dpe_dpi[a] = 1.0;
+                dpe_dl[a] = 0.0;
+            }
+            if (ACC) {
+                double sum = 0.0;
+#pragma unroll
+                for (int a = 1; a < kAMax; ++a) {
+                    if (a < A) {
+                        const double s1 = pi[a] * kacc;
+                        const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+                        const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+                        const double l = flog(p1c * frcp(1.0 - p1c)) + lpn;
+                        const double el = exp(l);
+                        const double pn = el * frcp(1.0 + el);
+                        const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+                        pe[a] = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+                        dpe_dl[a] = in2 ? pn * (1.0 - pn) : 0.0;
+                        dpe_dpi[a] = in1 ? dpe_dl[a] * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+                        sum += pe[a];
+                    }
+                }
+                pe0 = 1.0 - sum;
+            }
+            double e[B], ge[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                double v = pe0 * c.P0[b];
+#pragma unroll
+                for (int a = 1; a < kAMax; ++a)
+                    if (a < A) v += pe[a] * c.tabP[((long)b * A1 + (a - 1)) * G + g];
+                e[b] = v;
+                ge[b] = 0.0;
+            }
+            double nll = 0.0;
+            const double* sm = c.smask + r * B;
+#pragma unroll 1
+            for (int lik = 0; lik < 2; ++lik) {
+                if (lik == 1 && !use_bc) break;
+                const float* xp = (lik ? c.Xbc : c.X) + (long)r * B * G + g;
+                float n = 0.f;
+#pragma unroll
+                for (int b = 0; b < B; ++b) n += xp[(long)b * G];
+                if (n > (float)c.mask_thres)
+                    nll += dirmult_nll<B>(xp, (long)G, (lik ? c.sf_bc : c.sf) + r * B, sm,
+                                          lik ? c.a0_bc[g] : c.a0[g], e, ge);
+            }
+            // back through the mixture
+            double s0 = 0.0, gpi[kAMax];
+#pragma unroll
+            for (int b = 0; b < B; ++b) s0 += ge[b] * c.P0[b];
+            gpi[0] = ACC ? 0.0 : s0;
+#pragma unroll
+            for (int a = 1; a < kAMax; ++a) {
+                gpi[a] = 0.0;
+                if (a < A) {
+                    double sa = 0.0, dm = 0.0, ds = 0.0;
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const long o = ((long)b * A1 + (a - 1)) * G + g;
+                        sa += ge[b] * c.tabP[o];
+                        dm += ge[b] * c.tabPmu[o];
+                        ds += ge[b] * c.tabPy[o];
+                    }
+                    gmu_s[a - 1] += pe[a] * dm;
+                    gsig_s[a - 1] += pe[a] * ds;
+                    if (ACC) {
+                        gpi[a] = (sa - s0) * dpe_dpi[a];
+                        gnoise += (sa - s0) * dpe_dl[a];
+                    } else {
+                        gpi[a] = sa;
+                    }
+                }
+            }
+            // Multinomial on control allele counts + Dirichlet log-prob pieces
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a)
+                if (a < A) s += pi[a];
+            const double ls = s == 1.0 ? 0.0 : flog(s);
+            const double rsum = s == 1.0 ? 1.0 : frcp(s);
+            double proj = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a) {
+                if (a < A) {
+                    const double lpi = flog(pi[a]), rpi = frcp(pi[a]);
+                    const double pr = pi[a] * rsum;
+                    const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+                    const double lg = inside ? lpi - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                    double cnt = 0.0;
+                    for (int cc = 0; cc < c.C; ++cc)
+                        cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                    nll -= cnt * lg;
+                    if (inside) gpi[a] -= cnt * rpi;
+                    L[a] += lpi;
+                    gpi[a] += (cq[a] - 1.0) * rpi;  // + d log q / d pi
+                }
+            }
+            nrg += 1.0;
+            loss += nll;
+            // - d log p / d pi needs the model's floored concentration c_p: recompute from alpha
+            {
+                double alpha[kAMax], S = 0.0;
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a) {
+                    const bool am = a < A && c.amask[(long)g * A + a] != 0;
+                    alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
+                    S += alpha[a];
+                }
+                const double rSe = frcp(S + kEps) * c.pi_a0[g];
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a)
+                    if (a < A) {
+                        const double v = (alpha[a] + kEps / A) * rSe;
+                        const double cp = v < kEps ? kEps : v;
+                        gpi[a] -= (cp - 1.0) * frcp(pi[a]);
+                    }
+            }
+            proj = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a)
+                if (a < A) proj += pi[a] * gpi[a];
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a)
+                if (a < A) path[a] += dirichlet_grad_one(pi[a], cq[a], total) * (gpi[a] - proj);
+        }
+    }
+
+    // ---- reduce over the block's waves in a fixed order (one LDS image)
+    double* red = lds;  // [kTNumPart][64]
+    for (int ww = 0; ww < nw; ++ww) {
+        if (w == ww) {
+            auto put = [&](int q, double v) {
+                if (ww == 0) red[q * 64 + lane] = v;
+                else red[q * 64 + lane] += v;
+            };
+            put(kTGnoise, gnoise);
+            put(kTNrg, nrg);
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a) {
+                put(kTPath + a, path[a]);
+                put(kTL + a, L[a]);
+                if (a < kAMax - 1) {
+                    put(kTGmu + a, gmu_s[a]);
+                    put(kTGsig + a, gsig_s[a]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        // rows are spread over the waves; per-allele rows use the (A-1, G) slot layout
+        for (int q = w; q < kTNumPart; q += nw) {
+            const double v = red[q * 64 + lane];
+            if (q >= kTGmu && q < kTGmu + (kAMax - 1)) {
+                if (q - kTGmu < A1) c.part[(long)kTGmu * G + (long)(q - kTGmu) * G + g] = v;
+            } else if (q >= kTGsig) {
+                if (q - kTGsig < A1) c.part[(long)kTGsig * G + (long)(q - kTGsig) * G + g] = v;
+            } else {
+                c.part[(long)q * G + g] = v;
+            }
+        }
+    }
+    double* scratch = lds + kTNumPart * 64;
+    const double tot = block_sum(loss, scratch);
+    if (threadIdx.x == 0) {
+        atomicAdd(&c.loss_hist[ctr.slot], tot);
+        if (blockIdx.x == 0) *c.ctrA = ctr;
+    }
+}
+
 // ------------------------------------------------------------------ one-offs
 // Data-only constants: P0[b] and the log-factorial terms of the three observed
 // sites (they are part of the reported loss and carry no gradient).
@@ -672,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
         }
         if (rgm && n > (double)c.mask_thres) v -= lgamma(1.0 + n) - lf;
         if ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) v -= lgamma(1.0 + nb) - lfb;
-        if (c.family == kMixture && rgm) {
+        if ((c.family == kMixture || c.family == kMultiMixture) && rgm) {
             for (int cc = 0; cc < c.C; ++cc) {
                 double tot = 0.0, l = 0.0;
                 for (int a = 0; a < c.A; ++a) {

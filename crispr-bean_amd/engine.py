@@ -63,8 +63,6 @@ class HipSVI:
             raise ValueError(f"unknown model family {family!r}")
         if getattr(data, "selection", "sorting") != "sorting":
             raise NotImplementedError("survival screens are not implemented in the HIP engine yet")
-        if family == "MultiMixtureNormal":
-            raise NotImplementedError("tiling (MultiMixtureNormal) is not implemented in the HIP engine yet")
         if not torch.cuda.is_available():
             raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
         self.lib = _lib.load()
@@ -74,17 +72,36 @@ class HipSVI:
         data.validate()
         dev = self.device
         R, B, G = data.n_reps, data.n_condits, data.n_guides
-        mixture = family == "MixtureNormal"
+        tiling = family == "MultiMixtureNormal"
+        mixture = family in ("MixtureNormal", "MultiMixtureNormal")  # families with a Dirichlet pi site
         acc = bool(scale_by_accessibility) and mixture
         self.scale_by_accessibility = acc
-        self.fit_noise = bool(fit_noise) and acc
+        # tiling: fit_noise=~args.dont_fit_noise is always truthy (bean/model/run.py:416)
+        self.fit_noise = (bool(fit_noise) or tiling) and acc
         has_bc = getattr(data, "X_bcmatch_masked", None) is not None
         self.use_bcmatch = bool(use_bcmatch) and has_bc
         if mixture and not has_bc:
             raise ValueError("MixtureNormal needs barcode-matched counts (X_bcmatch)")
-        T = 1 if family == "ControlNormal" else data.n_targets
+        T = 1 if family == "ControlNormal" else (data.n_edits if tiling else data.n_targets)
         self.T = T
-        if family == "ControlNormal":
+        A = int(data.n_max_alleles) if tiling else 2
+        self.A = A
+        nnz = 0
+        if tiling:
+            toff = g2t = None
+            max_len = 0
+            a2e_ptr = data.a2e_ptr.cpu().to(torch.int32)
+            a2e_idx = data.a2e_idx.cpu().to(torch.int32)
+            nnz = int(a2e_idx.numel())
+            # transpose: edit -> allele slots containing it (stable, so sums keep a fixed order)
+            rows = torch.repeat_interleave(
+                torch.arange(a2e_ptr.numel() - 1, dtype=torch.int64), (a2e_ptr[1:] - a2e_ptr[:-1]).to(torch.int64))
+            order = torch.argsort(a2e_idx.to(torch.int64), stable=True)
+            e2a_idx = rows[order].to(torch.int32)
+            counts = torch.bincount(a2e_idx.to(torch.int64), minlength=T)
+            e2a_ptr = torch.zeros(T + 1, dtype=torch.int32)
+            e2a_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        elif family == "ControlNormal":
             toff = torch.tensor([0, G], dtype=torch.int32)
             g2t = torch.zeros(G, dtype=torch.int32)
             max_len = G
@@ -111,9 +128,9 @@ class HipSVI:
         n_ctrl = int(data.allele_counts_control.shape[1]) if mixture else 0
         shape = _lib.bean_hip_shape(
             family=_lib.FAMILY[family], selection=0, flags=flags, n_reps=R, n_condits=B, n_guides=G,
-            n_targets=T, n_max_alleles=2, n_edits=0, n_ctrl=n_ctrl, mask_thres=int(mask_thres),
+            n_targets=T, n_max_alleles=A, n_edits=T if tiling else 0, n_ctrl=n_ctrl, mask_thres=int(mask_thres),
             max_target_len=max_len, guide_offset=int(guide_offset), target_offset=int(target_offset),
-            n_guides_total=int(n_guides_total), reserved=0,
+            n_guides_total=int(n_guides_total), n_a2e_nnz=nnz,
             # the reference holds the prior scale in a float32 tensor (model.py:406)
             sd_prior_scale=1.0 if family == "ControlNormal" else float(np.float32(sd_scale)),
             initial_lr=self.initial_lr, lrd=self.lrd, clip_norm=10.0,
@@ -136,8 +153,16 @@ class HipSVI:
         self._bind("A0", f64(data.a0))
         self._bind("Z_HI", f64(z_hi))
         self._bind("Z_LO", f64(z_lo))
-        self._bind("TARGET_OFFSETS", toff.to(dev).contiguous())
-        self._bind("GUIDE_TO_TARGET", g2t.to(dev).contiguous())
+        if tiling:
+            self._bind("A2E_PTR", a2e_ptr.to(dev).contiguous())
+            self._bind("E2A_PTR", e2a_ptr.to(dev).contiguous())
+            if nnz:
+                self._bind("A2E_IDX", a2e_idx.to(dev).contiguous())
+                self._bind("E2A_IDX", e2a_idx.to(dev).contiguous())
+            self._bind("ALLELE_MASK", data.allele_mask.to(dev, torch.uint8).contiguous())
+        else:
+            self._bind("TARGET_OFFSETS", toff.to(dev).contiguous())
+            self._bind("GUIDE_TO_TARGET", g2t.to(dev).contiguous())
         if self.use_bcmatch:
             self._bind("X_BC", f32(data.X_bcmatch_masked))
             self._bind("SIZE_FACTOR_BC", f64(data.size_factor_bcmatch))
@@ -159,13 +184,15 @@ class HipSVI:
                     self._bind(slot, f64(v))
 
         # ---- parameters (unconstrained), as pyro.param initialises them
-        pshape = () if family == "ControlNormal" else (T, 1)
+        pshape = () if family == "ControlNormal" else ((T,) if tiling else (T, 1))
         init = {
             "mu_loc": torch.zeros(pshape), "mu_scale": torch.zeros(pshape),
             "sd_loc": torch.zeros(pshape), "sd_scale": torch.zeros(pshape),
         }
         if mixture:
-            init["alpha_pi"] = torch.zeros((G, 2))
+            init["alpha_pi"] = torch.zeros((G, A))
+            if tiling:  # alpha_pi0[~allele_mask] = epsilon (model.py:643)
+                init["alpha_pi"][~data.allele_mask.cpu()] = float(np.log(1e-5))
         if self.fit_noise:
             init["noise_loc"] = torch.zeros(G)
             init["noise_scale"] = torch.full((G,), float(np.log(PI_NOISE_SD)))
@@ -195,7 +222,7 @@ class HipSVI:
             self._bind("EPS_MU_OUT", self._noise_out["eps_mu"])
             self._bind("EPS_SD_OUT", self._noise_out["eps_sd"])
             if mixture:
-                self._noise_out["pi"] = torch.zeros((R, G, 2), dtype=torch.float64, device=dev)
+                self._noise_out["pi"] = torch.zeros((R, G, A), dtype=torch.float64, device=dev)
                 self._bind("PI_OUT", self._noise_out["pi"])
             if acc:
                 self._noise_out["eps_noise"] = torch.zeros(G, dtype=torch.float64, device=dev)
@@ -264,7 +291,7 @@ class HipSVI:
                 continue
             t = torch.as_tensor(t).to(dev, torch.float64)
             if key == "pi":
-                t = t.reshape(self.data.n_reps, self.data.n_guides, 2)
+                t = t.reshape(self.data.n_reps, self.data.n_guides, self.A)
             else:
                 t = t.reshape(-1)
             self._bind(slot, t.contiguous())
@@ -285,7 +312,9 @@ class HipSVI:
         out = {k: v.clone() for k, v in self._noise_out.items()}
         if "pi" in out:
             out["pi"] = out["pi"].unsqueeze(1)  # (R, 1, G, A) as the reference shapes it
-        if self.family != "ControlNormal":
+        if self.family == "MultiMixtureNormal":
+            pass  # per-edit draws are 1-D, as the reference shapes them
+        elif self.family != "ControlNormal":
             for k in ("eps_mu", "eps_sd"):
                 if k in out:
                     out[k] = out[k].reshape(self.T, 1)

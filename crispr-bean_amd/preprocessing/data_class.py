@@ -192,6 +192,12 @@ class ScreenTensors:
         assert tuple(self.repguide_mask.shape) == (R, G)
         assert tuple(self.size_factor.shape) == (R, B)
         assert tuple(self.a0.shape) == (G,)
+        if getattr(self, "a2e_ptr", None) is not None:
+            A1 = self.n_max_alleles - 1
+            assert self.a2e_ptr.numel() == G * A1 + 1
+            assert int(self.a2e_ptr[-1]) == self.a2e_idx.numel()
+            assert self.a2e_idx.numel() == 0 or int(self.a2e_idx.max()) < self.n_edits
+            assert tuple(self.allele_mask.shape) == (G, self.n_max_alleles)
         if getattr(self, "target_lengths", None) is not None:
             assert int(self.target_lengths.sum()) == G, "target_lengths must sum to G"
             assert self.target_lengths.numel() == self.n_targets

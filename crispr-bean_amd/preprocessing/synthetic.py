@@ -186,3 +186,123 @@ def make_sorting_variant_screen(
     data.negctrl_guide_idx = np.nonzero(is_negctrl[g2t])[0]
     data.validate()
     return data
+
+
+def make_sorting_tiling_screen(
+    n_guides: int = 50_000,
+    n_reps: int = 5,
+    n_max_alleles: int = 8,
+    bins=DEFAULT_BINS,
+    depth_per_guide: float = 500.0,
+    seed: int = BASE_SEED + 3,
+    with_accessibility: bool = False,
+    edits_per_guide: float = 0.6,
+    mask_fraction: float = 0.0,
+) -> ScreenTensors:
+    """Tiling sorting screen (BASELINE config 3): every guide produces up to
+    ``n_max_alleles - 1`` edited alleles, each a set of 1-3 edits drawn from a
+    window of 10 positions around the guide, so edits are shared by neighbouring
+    guides.  ``allele_to_edit`` is returned in CSR form (rows = ``G * (A - 1)``
+    allele slots; the reference builds the dense 0/1 tensor,
+    ``data_class.py:656-699``)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    R, G, A = n_reps, n_guides, n_max_alleles
+    A1 = A - 1
+    lo = np.array([b[0] for b in bins] + [0.0])
+    hi = np.array([b[1] for b in bins] + [1.0])
+    order = np.lexsort((lo, hi))
+    lo, hi = lo[order], hi[order]
+    B = len(lo)
+    E = max(int(G * edits_per_guide) + 10, 12)
+    mu_e = np.where(rng.random(E) < 0.1, rng.normal(0.0, 1.0, E), 0.0)
+    sd_e = np.ones(E)
+    n_al = np.minimum(1 + rng.poisson(3.0, G), A1)
+    base = np.minimum((np.arange(G) * (E - 10) / max(G, 1)).astype(np.int64), E - 10)
+    ptr = np.zeros(G * A1 + 1, dtype=np.int64)
+    idx = []
+    allele_mask = np.zeros((G, A), dtype=bool)
+    allele_mask[:, 0] = True
+    mu_a = np.zeros((G, A))
+    sd_a = np.ones((G, A))
+    for g in range(G):
+        seen = set()
+        k = 0
+        for _ in range(int(n_al[g])):
+            ne = int(rng.integers(1, 4))
+            es = tuple(sorted(base[g] + rng.choice(10, size=ne, replace=False)))
+            if es in seen:
+                continue
+            seen.add(es)
+            slot = g * A1 + k
+            idx.extend(es)
+            ptr[slot + 1] = len(es)
+            allele_mask[g, k + 1] = True
+            mu_a[g, k + 1] = mu_e[list(es)].sum()
+            sd_a[g, k + 1] = np.sqrt((sd_e[list(es)] ** 2).sum())
+            k += 1
+    ptr = np.cumsum(ptr)
+    idx = np.asarray(idx, dtype=np.int64)
+    # allele frequencies: wild type heavy
+    conc = np.where(allele_mask, 1.0, 0.0)
+    conc[:, 0] = 5.0
+    gam = rng.standard_gamma(np.where(conc > 0, conc, 1.0)) * (conc > 0)
+    pi_true = gam / gam.sum(1, keepdims=True)
+    abundance = np.exp(rng.normal(0.0, 0.5, G))
+    abundance /= abundance.mean()
+    acc = np.exp(rng.normal(1.0, 0.8, G)) if with_accessibility else None
+
+    with np.errstate(invalid="ignore"):
+        z_hi = np.where(hi >= 1.0, np.inf, ndtri(np.clip(hi, 1e-300, 1)))
+        z_lo = np.where(lo <= 0.0, -np.inf, ndtri(np.clip(lo, 1e-300, 1)))
+    p_bin = ndtr((z_hi[:, None, None] - mu_a[None]) / sd_a[None]) - ndtr(
+        (z_lo[:, None, None] - mu_a[None]) / sd_a[None]
+    )  # (B, G, A)
+    e = (pi_true[None] * p_bin).sum(-1)  # (B, G)
+    depth = rng.uniform(0.7, 1.3, (R, B))
+    is_ctrl = (lo == 0.0) & (hi == 1.0)
+    depth[:, is_ctrl] *= 0.2
+    prop = e[None] * depth[:, :, None]
+    prop_g = prop / prop.sum(1, keepdims=True)
+    n_rg = rng.poisson(depth_per_guide * abundance[None, :] * prop.sum(1) / 0.2)
+    a0_true = np.exp(-1.510 + 0.7861 * np.log(np.maximum(n_rg, 1)))
+    alpha = np.moveaxis(prop_g, 1, -1) * a0_true[:, :, None]
+    X = np.moveaxis(_dirmult_counts(rng, n_rg, alpha), -1, 1).astype(np.float64)
+    X_bc = rng.binomial(X.astype(np.int64), 0.8).astype(np.float64)
+    ctrl = int(np.nonzero(is_ctrl)[0][0])
+    X_bc_ctrl = X_bc[:, ctrl, :].astype(np.int64)  # (R, G)
+    ac = rng.multinomial(X_bc_ctrl.reshape(-1), np.tile(pi_true, (R, 1))).reshape(R, 1, G, A).astype(np.float64)
+
+    sample_mask = np.ones((R, B), dtype=np.int64)
+    repguide = np.ones((R, G), dtype=bool)
+    if mask_fraction > 0:
+        repguide &= rng.random((R, G)) >= mask_fraction
+        sample_mask[R - 1, 0] = 0
+    sf = _size_factor(X.reshape(R * B, G).T).reshape(R, B)
+    sf_bc = _size_factor(X_bc.reshape(R * B, G).T).reshape(R, B)
+    a0, popt = fitted_alpha0(X, sf, sample_mask)
+    a0_bc = pred_alpha0(X_bc, sf_bc, popt, sample_mask)
+    pi_a0, _ = fitted_pi_alpha0(ac, sf[:, ctrl : ctrl + 1])
+
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32)
+    f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64)
+    sm = torch.as_tensor(sample_mask)
+    Xt, Xbt = f32(X), f32(X_bc)
+    data = ScreenTensors(
+        n_reps=R, n_condits=B, n_guides=G, n_targets=E, n_edits=E, n_max_alleles=A,
+        X=Xt, X_masked=Xt * sm[:, :, None], X_bcmatch=Xbt, X_bcmatch_masked=Xbt * sm[:, :, None],
+        X_control=Xt[:, ctrl : ctrl + 1, :].clone(), X_bcmatch_control=Xbt[:, ctrl : ctrl + 1, :].clone(),
+        sample_mask=sm, control_sample_mask=sm[:, ctrl : ctrl + 1].clone(),
+        repguide_mask=torch.as_tensor(repguide) & ~(Xt == 0).any(dim=1),
+        size_factor=f64(sf), size_factor_bcmatch=f64(sf_bc), size_factor_control=f64(sf[:, ctrl : ctrl + 1]),
+        size_factor_bcmatch_control=f64(sf_bc[:, ctrl : ctrl + 1]),
+        a0=f64(a0), a0_bcmatch=f64(a0_bc), pi_a0=f64(pi_a0), allele_counts_control=f32(ac),
+        upper_bounds=f64(hi), lower_bounds=f64(lo), target_lengths=None,
+        guide_accessibility=f64(acc) if acc is not None else None,
+        allele_mask=torch.as_tensor(allele_mask),
+        a2e_ptr=torch.as_tensor(ptr.astype(np.int32)), a2e_idx=torch.as_tensor(idx.astype(np.int32)),
+        popt=popt,
+    )
+    data.selection, data.library_design = "sorting", "tiling"
+    data.truth = {"mu_edits": mu_e, "pi": pi_true}
+    data.validate()
+    return data

@@ -72,7 +72,7 @@ typedef struct bean_hip_shape {
     int32_t n_reps;        /* R */
     int32_t n_condits;     /* B: sort bins incl. the control pseudo-bin, or timepoints */
     int32_t n_guides;      /* G */
-    int32_t n_targets;     /* T (variant) */
+    int32_t n_targets;     /* T (variant); = n_edits for tiling: the per-target parameters are per edit */
     int32_t n_max_alleles; /* A (2 in variant mode) */
     int32_t n_edits;       /* E (tiling) */
     int32_t n_ctrl;        /* C: control conditions in allele_counts_control */
@@ -84,7 +84,7 @@ typedef struct bean_hip_shape {
     int32_t guide_offset;  /* index of this shard's first guide in the whole screen */
     int32_t target_offset; /* index of this shard's first target */
     int32_t n_guides_total;/* guides in the whole screen (0 = n_guides) */
-    int32_t reserved;
+    int32_t n_a2e_nnz;     /* tiling: total number of (allele, edit) pairs */
     double sd_prior_scale; /* LogNormal prior scale of sd_targets (0.01; 1.0 for ControlNormal) */
     double initial_lr;     /* ClippedAdam lr (0.01) */
     double lrd;            /* per-step lr decay gamma ** (1 / num_steps) */
@@ -113,6 +113,12 @@ enum bean_hip_buf {
     BEAN_BUF_PRIOR_MU_SCALE,  /* f64 (T)                                         opt  */
     BEAN_BUF_PRIOR_SD_LOC,    /* f64 (T)                                         opt  */
     BEAN_BUF_PRIOR_SD_SCALE,  /* f64 (T)                                         opt  */
+    /* tiling: allele slot s = g*(A-1) + (a-1) -> its edits (CSR), and the transpose */
+    BEAN_BUF_A2E_PTR,         /* i32 (G*(A-1)+1)                                 opt  */
+    BEAN_BUF_A2E_IDX,         /* i32 (nnz)  edit ids                             opt  */
+    BEAN_BUF_E2A_PTR,         /* i32 (E+1)                                       opt  */
+    BEAN_BUF_E2A_IDX,         /* i32 (nnz)  allele slots containing the edit     opt  */
+    BEAN_BUF_ALLELE_MASK,     /* u8  (G,A)  allele_mask                          opt  */
     /* ---- parameters: unconstrained values as Pyro's param store keeps them */
     BEAN_BUF_P_MU_LOC = 32,   /* f32 (T)                                              */
     BEAN_BUF_P_MU_SCALE,      /* f32 (T)   log mu_scale                               */

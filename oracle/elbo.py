@@ -346,7 +346,7 @@ def multi_mixture_normal_loss(data, params, noise=None, use_bcmatch=True, sd_sca
     (``model.py:550-751,878-962``): per-edit latents, allele = sum of edits."""
     P = constrained(params)
     R, B, G, A, E = data.n_reps, data.n_condits, data.n_guides, data.n_max_alleles, data.n_edits
-    a2e = data.allele_to_edit_dense()
+    a2e = data.allele_to_edit_dense().to(P["mu_loc"].dtype)  # f32 in the reference
     mu_e = normal_rsample(P["mu_loc"], P["mu_scale"], _noise(noise, "eps_mu"))
     sd_e = normal_rsample(P["sd_loc"], P["sd_scale"], _noise(noise, "eps_sd")).exp()
     guide_lp = {

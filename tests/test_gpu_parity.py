@@ -361,3 +361,97 @@ def test_sharded_engines_reproduce_the_whole_screen_fit(engine):
         assert torch.equal(got, ref[k]), k
     np.testing.assert_allclose(losses, ref_losses, rtol=1e-12)
     whole.close()
+
+
+# ------------------------------------------------------------------- tiling
+from bean_amd.preprocessing.synthetic import make_sorting_tiling_screen  # noqa: E402
+
+
+def _compare_tiling(engine, data, kw, seed=7, step=2):
+    torch.manual_seed(seed)
+    eng = engine.HipSVI("MultiMixtureNormal", data.to(DEV), dump_noise=True, num_steps=50, **kw)
+    for k, v in eng.unconstrained.items():
+        noise = 0.3 * torch.randn_like(v)
+        if k == "alpha_pi":  # masked alleles keep their fixed log(eps) storage
+            noise = noise * data.allele_mask.to(DEV)
+        v.add_(noise)
+    loss, grads = eng.elbo_grad(step=step, seed=seed)
+    draws = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+    for mode, tl, tg in (("f64", 1e-9, 5e-7), ("ref", 1e-6, 2e-5)):
+        params = {k: v.detach().cpu().clone() for k, v in eng.unconstrained.items()}
+        d = data
+        if mode == "f64":
+            params = {k: v.double() for k, v in params.items()}
+            d = elbo.as_float64(data)
+        params = {k: v.requires_grad_(True) for k, v in params.items()}
+        ref_loss, ref_grads, _ = svi.loss_and_grads(elbo.multi_mixture_normal_loss, d, params, noise=draws, **kw)
+        assert abs(loss - ref_loss) <= tl * abs(ref_loss), (mode, loss, ref_loss)
+        for k, g in grads.items():
+            ref = ref_grads[k].double().reshape(-1)
+            err = (g.cpu().double().reshape(-1) - ref).abs().max().item()
+            assert err <= tg * (ref.abs().max().item() + 1e-30), (mode, k, err)
+    # gradient of masked alleles' alpha is exactly zero (in-place write at model.py:645)
+    assert torch.all(grads["alpha_pi"][~data.allele_mask.to(DEV)] == 0)
+    eng.set_noise(draws)
+    loss_b, grads_b = eng.elbo_grad(step=step, seed=seed)
+    assert abs(loss_b - loss) <= 1e-12 * abs(loss)
+    for k in grads:
+        assert torch.equal(grads[k], grads_b[k])
+    eng.close()
+
+
+@pytest.mark.parametrize("gen_kw,kw", [
+    (dict(n_guides=500, n_reps=3, mask_fraction=0.05), {}),
+    (dict(n_guides=300, n_reps=2, with_accessibility=True, n_max_alleles=5), dict(scale_by_accessibility=True)),
+    (dict(n_guides=130, n_reps=9, n_max_alleles=3), {}),
+    (dict(n_guides=65, n_reps=1, n_max_alleles=2), {}),
+    (dict(n_guides=200, n_reps=2, n_max_alleles=8, bins=((0.0, 0.3), (0.3, 1.0))), {}),
+])
+def test_tiling_elbo_and_gradients_match_oracle(engine, gen_kw, kw):
+    data = make_sorting_tiling_screen(seed=4, **gen_kw)
+    _compare_tiling(engine, data, kw)
+
+
+def test_tiling_trajectory_and_fused_loop(engine):
+    data = make_sorting_tiling_screen(250, 2, seed=6, n_max_alleles=6)
+    n = 20
+    eng = engine.HipSVI("MultiMixtureNormal", data.to(DEV), dump_noise=True, num_steps=2000)
+    params = elbo.init_params("MultiMixtureNormal", data)
+    optim = svi.ClippedAdam(params, lr=0.01, lrd=0.1 ** (1 / 2000))
+    for t in range(n):
+        loss, _ = eng.elbo_grad(step=t, seed=5, loss_index=t)
+        draws = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+        eng.adam(t + 1)
+        ref = svi.svi_step(elbo.multi_mixture_normal_loss, data, params, optim, noise=draws)
+        assert abs(loss - ref) <= 2e-6 * abs(ref), (t, loss, ref)
+    torch.cuda.synchronize()
+    for k, v in eng.unconstrained.items():
+        ref = params[k].detach()
+        err = (v.cpu() - ref).abs().max().item()
+        assert err <= 1e-4 * max(1.0, ref.abs().max().item()), (k, err)
+    fused = engine.HipSVI("MultiMixtureNormal", data.to(DEV), num_steps=2000)
+    fused.run(n, seed=5, graph_chunk=6)
+    for k in eng.unconstrained:
+        assert torch.equal(eng.unconstrained[k], fused.unconstrained[k]), k
+    np.testing.assert_allclose(fused.losses(), eng.loss_hist[:n].cpu().tolist(), rtol=1e-12)
+    eng.close()
+    fused.close()
+
+
+def test_tiling_run_inference_recovers_edit_effects(engine):
+    from types import SimpleNamespace
+
+    from bean_amd.model.run import identify_model_guide, run_inference
+
+    args = SimpleNamespace(selection="sorting", library_design="tiling", scale_by_acc=False,
+                           ignore_bcmatch=False, dont_fit_noise=False, uniform_edit=False, const_pi=False,
+                           guide_activity_col=None)
+    label, model, guide = identify_model_guide(args)
+    assert label == "MultiMixtureNormal"
+    data = make_sorting_tiling_screen(2000, 3, seed=8)
+    store, out = run_inference(model, guide, data, num_steps=400, verbose=False)
+    assert store["mu_loc"].shape == (data.n_edits,) and store["alpha_pi"].shape == (2000, 8)
+    assert out["loss"][-1] < 0.8 * out["loss"][0]
+    mu, truth = out["params"]["mu_loc"].numpy(), data.truth["mu_edits"]
+    big = np.abs(truth) > 1.0
+    assert big.sum() > 10 and np.mean(np.sign(mu[big]) == np.sign(truth[big])) > 0.8
