@@ -44,6 +44,7 @@ struct bean_hip_ctx {
 extern "C" const char* bean_hip_version(void) { return "bean_hip 0.1.0 (gfx950)"; }
 extern "C" const char* bean_hip_last_error(void) { return g_err.c_str(); }
 
+static bool is_survival(const bean_hip_shape& s) { return s.selection == BEAN_SELECTION_SURVIVAL; }
 static bool is_tiling(const bean_hip_shape& s) { return s.family == BEAN_FAMILY_MULTI_MIXTURE; }
 // families with a Dirichlet pi site (reporter models)
 static bool is_mixture(const bean_hip_shape& s) {
@@ -56,16 +57,18 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
     const uint64_t A = s.n_max_alleles, C = s.n_ctrl;
     auto param_elems = [&](int i) -> uint64_t {
         switch (i) {
-            case 0: case 1: case 2: case 3: return T;
+            case 0: case 1: return T;
+            case 2: case 3: return is_survival(s) ? 0 : T;  // survival models have no sd latent
+            case 7: return (is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) ? G : 0;
             case 4: return is_mixture(s) ? G * A : 0;
             case 5: case 6: return (is_mixture(s) && (s.flags & BEAN_FLAG_SCALE_BY_ACC) && (s.flags & BEAN_FLAG_FIT_NOISE)) ? G : 0;
         }
         return 0;
     };
-    if (slot >= BEAN_BUF_P_MU_LOC && slot < BEAN_BUF_P_MU_LOC + 7) return 4 * param_elems(slot - BEAN_BUF_P_MU_LOC);
-    if (slot >= BEAN_BUF_G_MU_LOC && slot < BEAN_BUF_G_MU_LOC + 7) return 4 * param_elems(slot - BEAN_BUF_G_MU_LOC);
-    if (slot >= BEAN_BUF_M_MU_LOC && slot < BEAN_BUF_M_MU_LOC + 7) return 4 * param_elems(slot - BEAN_BUF_M_MU_LOC);
-    if (slot >= BEAN_BUF_V_MU_LOC && slot < BEAN_BUF_V_MU_LOC + 7) return 4 * param_elems(slot - BEAN_BUF_V_MU_LOC);
+    if (slot >= BEAN_BUF_P_MU_LOC && slot < BEAN_BUF_P_MU_LOC + 8) return 4 * param_elems(slot - BEAN_BUF_P_MU_LOC);
+    if (slot >= BEAN_BUF_G_MU_LOC && slot < BEAN_BUF_G_MU_LOC + 8) return 4 * param_elems(slot - BEAN_BUF_G_MU_LOC);
+    if (slot >= BEAN_BUF_M_MU_LOC && slot < BEAN_BUF_M_MU_LOC + 8) return 4 * param_elems(slot - BEAN_BUF_M_MU_LOC);
+    if (slot >= BEAN_BUF_V_MU_LOC && slot < BEAN_BUF_V_MU_LOC + 8) return 4 * param_elems(slot - BEAN_BUF_V_MU_LOC);
     switch (slot) {
         case BEAN_BUF_X: return 4 * R * B * G;
         case BEAN_BUF_X_BC: return (s.flags & BEAN_FLAG_USE_BCMATCH) ? 4 * R * B * G : 0;
@@ -77,7 +80,12 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_A0: return 8 * G;
         case BEAN_BUF_A0_BC: return (s.flags & BEAN_FLAG_USE_BCMATCH) ? 8 * G : 0;
         case BEAN_BUF_PI_A0: return is_mixture(s) ? 8 * G : 0;
-        case BEAN_BUF_Z_HI: case BEAN_BUF_Z_LO: return 8 * B;
+        case BEAN_BUF_Z_HI: case BEAN_BUF_Z_LO: return is_survival(s) ? 0 : 8 * B;
+        case BEAN_BUF_TIMEPOINTS: return is_survival(s) ? 8 * B : 0;
+        case BEAN_BUF_CONTROL_TIME: return (is_survival(s) && is_mixture(s)) ? 8 * C : 0;
+        case BEAN_BUF_LOG_OBS0: case BEAN_BUF_X0_IN: case BEAN_BUF_X0_OUT:
+            return (is_survival(s) && is_mixture(s)) ? 8 * R * G : 0;
+        case BEAN_BUF_EPS_U_IN: case BEAN_BUF_EPS_U_OUT: return (is_survival(s) && is_mixture(s)) ? 8 * G : 0;
         case BEAN_BUF_TARGET_OFFSETS: return is_tiling(s) ? 0 : 4 * (T + 1);
         case BEAN_BUF_GUIDE_TO_TARGET: return is_tiling(s) ? 0 : 4 * G;
         case BEAN_BUF_A2E_PTR: return is_tiling(s) ? 4 * (G * (A - 1) + 1) : 0;
@@ -87,8 +95,8 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_ACCESSIBILITY: return (s.flags & BEAN_FLAG_SCALE_BY_ACC) ? 8 * G : 0;
         case BEAN_BUF_PRIOR_MU_LOC: case BEAN_BUF_PRIOR_MU_SCALE:
         case BEAN_BUF_PRIOR_SD_LOC: case BEAN_BUF_PRIOR_SD_SCALE: return 8 * T;
-        case BEAN_BUF_EPS_MU_IN: case BEAN_BUF_EPS_SD_IN:
-        case BEAN_BUF_EPS_MU_OUT: case BEAN_BUF_EPS_SD_OUT: return 8 * T;
+        case BEAN_BUF_EPS_MU_IN: case BEAN_BUF_EPS_MU_OUT: return 8 * T;
+        case BEAN_BUF_EPS_SD_IN: case BEAN_BUF_EPS_SD_OUT: return is_survival(s) ? 0 : 8 * T;
         case BEAN_BUF_PI_IN: case BEAN_BUF_PI_OUT: return is_mixture(s) ? 8 * R * G * A : 0;
         case BEAN_BUF_EPS_NOISE_IN: case BEAN_BUF_EPS_NOISE_OUT:
             return (s.flags & BEAN_FLAG_SCALE_BY_ACC) ? 8 * G : 0;
@@ -124,7 +132,7 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.pr_mu_scale = (const double*)P(BEAN_BUF_PRIOR_MU_SCALE);
     d.pr_sd_loc = (const double*)P(BEAN_BUF_PRIOR_SD_LOC);
     d.pr_sd_scale = (const double*)P(BEAN_BUF_PRIOR_SD_SCALE);
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < 8; ++i) {
         d.p[i] = (float*)P(BEAN_BUF_P_MU_LOC + i);
         d.g[i] = (float*)P(BEAN_BUF_G_MU_LOC + i);
         d.m[i] = (float*)P(BEAN_BUF_M_MU_LOC + i);
@@ -139,6 +147,13 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.pi_out = (double*)P(BEAN_BUF_PI_OUT);
     d.eps_noise_out = (double*)P(BEAN_BUF_EPS_NOISE_OUT);
     d.loss_hist = (double*)P(BEAN_BUF_LOSS_HIST);
+    d.time = (const double*)P(BEAN_BUF_TIMEPOINTS);
+    d.ctrl_time = (const double*)P(BEAN_BUF_CONTROL_TIME);
+    d.log_obs0 = (const double*)P(BEAN_BUF_LOG_OBS0);
+    d.x0_in = (const double*)P(BEAN_BUF_X0_IN);
+    d.eps_u_in = (const double*)P(BEAN_BUF_EPS_U_IN);
+    d.x0_out = (double*)P(BEAN_BUF_X0_OUT);
+    d.eps_u_out = (double*)P(BEAN_BUF_EPS_U_OUT);
     d.flags = c->shape.flags & ~kDumpPi;
     if (d.pi_out && (c->shape.flags & BEAN_FLAG_DUMP_PI)) d.flags |= kDumpPi;
 }
@@ -153,8 +168,11 @@ static void drop_graph(bean_hip_ctx* c) {
 
 extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (!s || !out) return fail("bean_hip_create: null argument");
-    if (s->selection != BEAN_SELECTION_SORTING)
-        return fail("bean_hip_create: only sorting screens are implemented in this build");
+    if (s->selection != BEAN_SELECTION_SORTING && s->selection != BEAN_SELECTION_SURVIVAL)
+        return fail("bean_hip_create: unknown selection");
+    if (is_survival(*s) && s->family != BEAN_FAMILY_CONTROL_NORMAL && s->family != BEAN_FAMILY_MIXTURE_NORMAL)
+        return fail("bean_hip_create: survival screens support ControlNormal and MixtureNormal in this build");
+    if (is_survival(*s) && !(s->negctrl_scale > 0.0)) return fail("bean_hip_create: negctrl_scale must be > 0");
     if (s->family < BEAN_FAMILY_NORMAL || s->family > BEAN_FAMILY_MULTI_MIXTURE)
         return fail("bean_hip_create: unknown family");
     if (s->n_reps < 1 || s->n_guides < 1 || s->n_targets < 1)
@@ -198,12 +216,19 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.G_tot = s->n_guides_total > 0 ? s->n_guides_total : s->n_guides;
     d.sd_prior_scale = s->sd_prior_scale; d.lr0 = s->initial_lr; d.log_lrd = log(s->lrd);
     d.clip = s->clip_norm;
+    d.survival = is_survival(*s) ? 1 : 0;
+    d.neg_loc = s->negctrl_loc; d.neg_scale = s->negctrl_scale;
 
     const uint64_t B = d.B, T = d.T, G = d.G;
     const uint64_t A1 = is_tiling(*s) ? (uint64_t)(d.A - 1) : 0;
     const uint64_t n_tab = is_tiling(*s) ? A1 * G : T;  // table columns: allele slots or targets
     const uint64_t n_part = is_tiling(*s) ? (uint64_t)kTNumPart : (uint64_t)kNumPart;
-    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 1 + 8;
+    const bool surv_mix = is_survival(*s) && is_mixture(*s);
+    const uint64_t Rr = d.R;
+    const uint64_t n_gblk = (G + 255) / 256;
+    d.n_gamma_blocks = (int)n_gblk;
+    const uint64_t n_surv = surv_mix ? 2 * G + Rr * G + n_gblk * (Rr + 1) + (Rr + 1) : 0;
+    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 1 + 8 + n_surv;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
     if (e != hipSuccess) {
@@ -231,6 +256,13 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.lpn = w; w += G;
     d.eps_noise = w; w += G;
     d.loss_const = w; w += 1;
+    if (surv_mix) {
+        d.u_g = w; w += G;
+        d.eps_u = w; w += G;
+        d.gam = w; w += Rr * G;
+        d.gpart = w; w += n_gblk * (Rr + 1);
+        d.gsum = w; w += Rr + 1;
+    }
     d.ctrA = (StepCtr*)w; w += 2;
     d.ctrB = (StepCtr*)w; w += 2;
     *out = c;
@@ -278,7 +310,13 @@ static int check_bound(bean_hip_ctx* c, bool need_grads, bool need_moments) {
     const bean_hip_shape& s = c->shape;
 #define REQ(slot) if (require(c, slot, #slot)) return -1
     REQ(BEAN_BUF_X); REQ(BEAN_BUF_REPGUIDE); REQ(BEAN_BUF_SIZE_FACTOR); REQ(BEAN_BUF_SAMPLE_MASK);
-    REQ(BEAN_BUF_A0); REQ(BEAN_BUF_Z_HI); REQ(BEAN_BUF_Z_LO); REQ(BEAN_BUF_LOSS_HIST);
+    REQ(BEAN_BUF_A0); REQ(BEAN_BUF_LOSS_HIST);
+    if (is_survival(s)) {
+        REQ(BEAN_BUF_TIMEPOINTS);
+        if (is_mixture(s)) { REQ(BEAN_BUF_CONTROL_TIME); REQ(BEAN_BUF_LOG_OBS0); }
+    } else {
+        REQ(BEAN_BUF_Z_HI); REQ(BEAN_BUF_Z_LO);
+    }
     if (is_tiling(s)) {
         REQ(BEAN_BUF_A2E_PTR); REQ(BEAN_BUF_E2A_PTR); REQ(BEAN_BUF_ALLELE_MASK);
         if (s.n_a2e_nnz > 0) { REQ(BEAN_BUF_A2E_IDX); REQ(BEAN_BUF_E2A_IDX); }
@@ -288,7 +326,7 @@ static int check_bound(bean_hip_ctx* c, bool need_grads, bool need_moments) {
     if (s.flags & BEAN_FLAG_USE_BCMATCH) { REQ(BEAN_BUF_X_BC); REQ(BEAN_BUF_SIZE_FACTOR_BC); REQ(BEAN_BUF_A0_BC); }
     if (is_mixture(s)) { REQ(BEAN_BUF_ALLELE_CTRL); REQ(BEAN_BUF_PI_A0); }
     if (s.flags & BEAN_FLAG_SCALE_BY_ACC) REQ(BEAN_BUF_ACCESSIBILITY);
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < 8; ++i) {
         if (expected_bytes(s, BEAN_BUF_P_MU_LOC + i) == 0) continue;
         REQ(BEAN_BUF_P_MU_LOC + i);
         if (need_grads) REQ(BEAN_BUF_G_MU_LOC + i);
@@ -327,7 +365,16 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream) {
 template <int B>
 static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 block, size_t lds) {
     const DevArgs& d = c->d;
-    if (d.family == kMultiMixture) {
+    if (d.survival) {
+        if (d.family == kMixture) {
+            if (d.flags & kAcc)
+                hipLaunchKernelGGL((k_guide_survival<B, kMixture, true>), grid, block, lds, stream, d);
+            else
+                hipLaunchKernelGGL((k_guide_survival<B, kMixture, false>), grid, block, lds, stream, d);
+        } else {
+            hipLaunchKernelGGL((k_guide_survival<B, kNormal, false>), grid, block, lds, stream, d);
+        }
+    } else if (d.family == kMultiMixture) {
         const size_t tl = ((size_t)kTNumPart * 64 + 16) * sizeof(double);
         if (d.flags & kAcc)
             hipLaunchKernelGGL((k_guide_tiling<B, true>), grid, block, tl, stream, d);
@@ -348,6 +395,8 @@ static int waves_per_block(const bean_hip_ctx* c) { return c->d.R < 8 ? c->d.R :
 static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     const int nw = waves_per_block(c);
+    if (d.survival && d.family == kMixture)  // normalisers of the Dirichlet(q0) draw
+        hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, stream, d);
     if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
         const long n = (long)(d.A - 1) * d.G;
         hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
@@ -401,7 +450,7 @@ extern "C" int bean_hip_adam(bean_hip_ctx* c, uint64_t t, void* stream_) {
     if (check_bound(c, true, true)) return -1;
     if (t < 1) return fail("bean_hip_adam: t is 1-based");
     hipStream_t stream = (hipStream_t)stream_;
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < 8; ++i) {
         const uint64_t bytes = expected_bytes(c->shape, BEAN_BUF_P_MU_LOC + i);
         if (!bytes) continue;
         const long n = (long)(bytes / 4);
@@ -475,11 +524,13 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
     if (is_mixture(s)) bytes += G * (4 * R * s.n_ctrl * A + 8 /*pi_a0*/ + 3 * 4 * A * 2 /*alpha_pi, m, v r+w*/);
     if (is_tiling(s)) bytes += G * A /*allele_mask*/ + 4 * (G * (A - 1) + 1) + 2 * 4 * (uint64_t)s.n_a2e_nnz + 4 * (T + 1);
     if (s.flags & BEAN_FLAG_SCALE_BY_ACC) bytes += G * (8 + ((s.flags & BEAN_FLAG_FIT_NOISE) ? 2 * 3 * 4 * 2 : 0));
-    bytes += T * (4 * 3 * 4 * 2);  // four per-target params with moments, read + written
+    bytes += T * ((is_survival(s) ? 2 : 4) * 3 * 4 * 2);  // per-target params with moments, read + written
+    if (is_survival(s) && is_mixture(s)) bytes += G * (3 * 4 * 2 /*q0*/ + 8 * R /*log_obs0*/);
     return bytes;
 }
 
 extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
+    if (c && c->d.survival) return "k_guide_survival";
     return (c && c->d.family == kMultiMixture) ? "k_guide_tiling" : "k_guide";
 }
 

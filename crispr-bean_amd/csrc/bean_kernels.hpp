@@ -48,7 +48,8 @@ struct StepCtr {
 };
 
 // partial-sum rows written by k_guide, (kNumPart, G) doubles
-enum Part { kPGmu = 0, kPGy = 1, kPGnoise = 2, kPNrg = 3, kPPath = 4, kPLp = 6, kPLq = 8, kNumPart = 10 };
+// (survival reuses row kPGy for the q0 gradient: it has no sd latent)
+enum Part { kPGmu = 0, kPGy = 1, kPQ0 = 1, kPGnoise = 2, kPNrg = 3, kPPath = 4, kPLp = 6, kPLq = 8, kNumPart = 10 };
 
 struct DevArgs {
     int R, B, G, T, A, C;
@@ -64,11 +65,11 @@ struct DevArgs {
     const double *sf, *sf_bc, *smask, *a0, *a0_bc, *pi_a0, *z_hi, *z_lo, *acc;
     const int *toff, *g2t;
     const double *pr_mu_loc, *pr_mu_scale, *pr_sd_loc, *pr_sd_scale;
-    // parameters / grads / moments: mu_loc, mu_scale, sd_loc, sd_scale, alpha_pi, noise_loc, noise_scale
-    float* p[7];
-    float* g[7];
-    float* m[7];
-    float* v[7];
+    // parameters / grads / moments: mu_loc, mu_scale, sd_loc, sd_scale, alpha_pi, noise_loc, noise_scale, q0
+    float* p[8];
+    float* g[8];
+    float* m[8];
+    float* v[8];
     // noise
     const double *eps_mu_in, *eps_sd_in, *pi_in, *eps_noise_in;
     double *eps_mu_out, *eps_sd_out, *pi_out, *eps_noise_out;
@@ -87,6 +88,18 @@ struct DevArgs {
     const int *e2a_ptr, *e2a_idx;  // (E+1), (nnz): slots containing each edit
     const uint8_t* amask;          // (G, A)
     double *mu_a, *sig_a;          // (A-1, G) allele mean / scale of the current draw
+    // survival (exp(mu t) growth instead of Normal-CDF bins)
+    int survival;
+    const double *time, *ctrl_time;  // (B), (C)
+    double neg_loc, neg_scale;       // prior of the per-guide baseline mu_negctrl
+    const double *x0_in, *eps_u_in;
+    const double* log_obs0;          // (R, G) log of the normalised t0 counts (data only)
+    double *x0_out, *eps_u_out;
+    double *u_g, *eps_u;             // (G) baseline draw of the current step
+    double *gam;                     // (R, G) gamma draws of the Dirichlet(q0) site
+    double *gpart;                   // (n_gamma_blocks, R + 1) block sums: gammas per rep, q0
+    double *gsum;                    // (R + 1) totals: sum_g gamma[r, g], sum_g q0
+    int n_gamma_blocks;
 };
 
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
@@ -327,7 +340,48 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                 }
             }
         }
-        if (active) {
+        if (active && c.survival) {
+            // survival families: mu only (no sd latent), growth tables are computed in k_guide_survival
+            float pl = c.p[0][t], psu = c.p[1][t];
+            if (FINISH) {
+                const double eps1 = c.eps_mu[t], mu = c.mu_t[t];
+                const double s_mu = exp((double)psu);
+                double logp_mu, dlogp_mu;
+                if (c.flags & kPriorNormalMu) {
+                    const double ploc = c.pr_mu_loc ? c.pr_mu_loc[t] : 0.0;
+                    const double ps = c.pr_mu_scale ? c.pr_mu_scale[t] : 1.0;
+                    const double zz = (mu - ploc) / ps;
+                    logp_mu = -0.5 * zz * zz - log(ps) - kHalfLog2PiC;
+                    dlogp_mu = -zz / ps;
+                } else {
+                    logp_mu = -kLog2 - fabs(mu);
+                    dlogp_mu = mu > 0.0 ? -1.0 : (mu < 0.0 ? 1.0 : 0.0);
+                }
+                const double logq_mu = -0.5 * eps1 * eps1 - (double)psu - kHalfLog2PiC;
+                loss_fin = -logp_mu + logq_mu;
+                const double Gmu = gmu - dlogp_mu;
+                emit_grad<ADAM>(c, 0, t, Gmu, ak);
+                emit_grad<ADAM>(c, 1, t, Gmu * eps1 * s_mu - 1.0, ak);
+                if (ADAM) {
+                    pl = c.p[0][t];
+                    psu = c.p[1][t];
+                }
+            }
+            if (PREP) {
+                double eps1;
+                if (c.eps_mu_in) {
+                    eps1 = c.eps_mu_in[t];
+                } else {
+                    rocrand_state_philox4x32_10 st;
+                    rocrand_init(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + t),
+                                 s_prep * 4ull, &st);
+                    eps1 = (double)rocrand_normal2(&st).x;
+                }
+                c.eps_mu[t] = eps1;
+                c.mu_t[t] = (double)pl + eps1 * exp((double)psu);
+                if (c.eps_mu_out) c.eps_mu_out[t] = eps1;
+            }
+        } else if (active) {
             float pf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pf[i] = c.p[i][t];
@@ -513,6 +567,59 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                 c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
                 if (c.eps_noise_out) c.eps_noise_out[g] = eps;
             }
+        }
+    }
+    if (c.survival && mixture && (int)blockIdx.x >= n_target_blocks) {
+        // survival MixtureNormal: the Dirichlet(q0) site over ALL guides and the per-guide
+        // baseline growth draw (survival_model.py:259-274,306-311,660-669)
+        const int gb = (int)blockIdx.x - n_target_blocks;
+        const int g = gb * blockDim.x + threadIdx.x;
+        const bool in = g < c.G;
+        float q0u = in ? c.p[7][g] : 0.f;
+        if (FINISH && in) {
+            const double q0 = (double)expf(q0u);
+            emit_grad<ADAM>(c, 7, g, c.part[(long)kPQ0 * c.G + g] * q0, ak);
+            if (ADAM) q0u = c.p[7][g];
+            // - log p(mu_negctrl): Normal(m0, s0) built from Python floats => float32 tensors
+            const float s0f = (float)c.neg_scale;
+            const double du = c.u_g[g] - (double)(float)c.neg_loc;
+            loss_fin += du * du / (2.0 * (double)(s0f * s0f)) + (double)logf(s0f) + kHalfLog2PiC;
+        }
+        if (PREP) {
+            double q0 = 0.0;
+            if (in) {
+                q0 = (double)expf(q0u);
+                double eps;
+                if (c.eps_u_in) {
+                    eps = c.eps_u_in[g];
+                } else {
+                    rocrand_state_philox4x32_10 st;
+                    rocrand_init(c.seed, ((unsigned long long)kSiteAux << 48) + (unsigned long long)(c.g_off + g),
+                                 s_prep * 4ull, &st);
+                    eps = (double)rocrand_normal(&st);
+                }
+                c.eps_u[g] = eps;
+                c.u_g[g] = (double)(float)c.neg_loc + eps * (double)(float)c.neg_scale;
+                if (c.eps_u_out) c.eps_u_out[g] = eps;
+            }
+            for (int r = 0; r < c.R; ++r) {
+                double gm = 0.0;
+                if (in) {
+                    if (c.x0_in) {
+                        gm = c.x0_in[(long)r * c.G + g];  // injected draw: already normalised
+                    } else {
+                        Rng rng(c.seed, kSiteQ0, (unsigned long long)r * c.G_tot + (c.g_off + g), s_prep * 256ull);
+                        // torch draws this site in float32 (q0 is a float32 parameter): the gamma
+                        // underflows to 0 and is floored at FLT_MIN (ATen _s_dirichlet_cpu)
+                        gm = (double)fmaxf((float)sample_gamma(q0, rng), 1.17549435e-38f);
+                    }
+                    c.gam[(long)r * c.G + g] = gm;
+                }
+                const double tot = block_sum(gm, scratch);
+                if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + r] = tot;
+            }
+            const double tq = block_sum(q0, scratch);
+            if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + c.R] = tq;
         }
     }
     if (FINISH) {
@@ -761,6 +868,236 @@ void k_guide(DevArgs c) {
     }
 
     // ---- reduce over the block's waves (replicates) and write per-guide rows
+    double* red = lds;  // [nw][kNumPart][64]
+    if (nw > 1) {
+#pragma unroll
+        for (int q = 0; q < kNumPart; ++q) red[((long)w * kNumPart + q) * 64 + lane] = acc[q];
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int q = 0; q < kNumPart; ++q) {
+                double s = acc[q];
+                for (int ww = 1; ww < nw; ++ww) s += red[((long)ww * kNumPart + q) * 64 + lane];
+                acc[q] = s;
+            }
+        }
+    }
+    if (w == 0 && valid) {
+#pragma unroll
+        for (int q = 0; q < kNumPart; ++q)
+            if (MIX || q < 2) c.part[(long)q * G + g] = acc[q];
+    }
+    double* scratch = lds + (long)nw * kNumPart * 64;
+    const double tot = block_sum(loss, scratch);
+    if (threadIdx.x == 0) {
+        atomicAdd(&c.loss_hist[ctr.slot], tot);
+        if (blockIdx.x == 0) *c.ctrA = ctr;
+    }
+}
+
+// ------------------------------------------------------------ survival kernels
+// Totals of the per-block sums written by k_param's survival guide part:
+// gsum[r] = sum_g gamma[r, g] (normaliser of the Dirichlet(q0) draw), gsum[R] = sum_g q0.
+__global__ __launch_bounds__(256) void k_sum_parts(DevArgs c) {
+    __shared__ double scratch[16];
+    for (int j = 0; j <= c.R; ++j) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < c.n_gamma_blocks; b += blockDim.x) v += c.gpart[(long)b * (c.R + 1) + j];
+        const double tot = block_sum(v, scratch);
+        if (threadIdx.x == 0) c.gsum[j] = tot;
+    }
+}
+
+// Survival analogue of k_guide (survival_model.py:133-424): component "bin
+// probabilities" are exp(mu_a * t_b) with mu = [u_g, u_g + mu_t]; the control
+// Multinomial sees the alleles after selection up to the control timepoint; the
+// Dirichlet(q0) site over all guides is handled per (rep, guide) as well.
+template <int B, int FAM, bool ACC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BEAN_GUIDE_WAVES_PER_EU)))
+void k_guide_survival(DevArgs c) {
+    extern __shared__ double lds[];
+    constexpr bool MIX = FAM == kMixture;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int g = blockIdx.x * 64 + lane;
+    const bool valid = g < c.G;
+    const StepCtr ctr = *c.ctrB;
+    const int G = c.G;
+
+    double acc[kNumPart];
+#pragma unroll
+    for (int q = 0; q < kNumPart; ++q) acc[q] = 0.0;
+    double loss = 0.0;
+
+    if (valid) {
+        const bool use_bc = (c.flags & kUseBc) != 0;
+        const double mu_t = c.mu_t[c.g2t[g]];
+        const double u = MIX ? c.u_g[g] : 0.0;
+        const double mu1 = u + mu_t;
+        double cp[2] = {1.0, 1.0}, cq[2] = {1.0, 1.0};
+        bool cl[2] = {false, false};
+        double kacc = 0.0, lpn = 0.0, q0 = 0.0;
+        if (MIX) {
+            const double al0 = (double)expf(c.p[4][2 * g]), al1 = (double)expf(c.p[4][2 * g + 1]);
+            const double rs = frcp(al0 + al1) * c.pi_a0[g];
+            cp[0] = al0 * rs;
+            cp[1] = al1 * rs;
+            cl[0] = cp[0] < 1e-5;
+            cl[1] = cp[1] < 1e-5;
+            cq[0] = cl[0] ? 1e-5 : cp[0];
+            cq[1] = cl[1] ? 1e-5 : cp[1];
+            q0 = (double)expf(c.p[7][g]);
+            if (ACC) {
+                kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                lpn = c.lpn[g];
+            }
+        }
+        for (int r = w; r < c.R; r += nw) {
+            const bool rgm = c.rg[(long)r * G + g] != 0;
+            double pi[2] = {0.0, 1.0}, pe1 = 1.0, dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
+            if (MIX) {
+                if (c.pi_in) {
+                    pi[0] = c.pi_in[((long)r * G + g) * 2];
+                    pi[1] = c.pi_in[((long)r * G + g) * 2 + 1];
+                } else {
+                    Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+                    double gm0 = 0.0, gm1 = 0.0;
+#pragma unroll 1
+                    for (int a = 0; a < 2; ++a) {
+                        const double gv = fmax(sample_gamma(a ? cq[1] : cq[0], rng), kDblMin);
+                        gm0 = a ? gm0 : gv;
+                        gm1 = a ? gv : gm1;
+                    }
+                    const double rs = frcp(gm0 + gm1);
+                    pi[0] = fmin(fmax(gm0 * rs, kDblMin), kOneMinus);
+                    pi[1] = fmin(fmax(gm1 * rs, kDblMin), kOneMinus);
+                }
+                if (c.flags & kDumpPi) {
+                    c.pi_out[((long)r * G + g) * 2] = pi[0];
+                    c.pi_out[((long)r * G + g) * 2 + 1] = pi[1];
+                }
+                pe1 = pi[1];
+                if (ACC) {
+                    const double s1 = pi[1] * kacc;
+                    const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+                    const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+                    const double l = flog(p1c * frcp(1.0 - p1c)) + lpn;
+                    const double el = exp(l);
+                    const double pn = el * frcp(1.0 + el);
+                    const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+                    pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+                    dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
+                    dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+                }
+            }
+            double e[B], ge[B], P0[B], P1[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const double tb = c.time[b];
+                P1[b] = exp(mu1 * tb);
+                P0[b] = MIX ? exp(u * tb) : 0.0;
+                e[b] = MIX ? (ACC ? (1.0 - pe1) * P0[b] + pe1 * P1[b] : pi[0] * P0[b] + pi[1] * P1[b]) : P1[b];
+                ge[b] = 0.0;
+            }
+            double nll = 0.0;
+            const double* sm = c.smask + r * B;
+#pragma unroll 1
+            for (int lik = 0; lik < 2; ++lik) {
+                if (lik == 1 && !use_bc) break;
+                const float* xp = (lik ? c.Xbc : c.X) + (long)r * B * G + g;
+                float n = 0.f;
+#pragma unroll
+                for (int b = 0; b < B; ++b) n += xp[(long)b * G];
+                if (rgm && n > (float)c.mask_thres)
+                    nll += dirmult_nll<B>(xp, (long)G, (lik ? c.sf_bc : c.sf) + r * B, sm,
+                                          lik ? c.a0_bc[g] : c.a0[g], e, ge);
+            }
+            double dmu = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                dmu += ge[b] * c.time[b] * P1[b];
+                g0 += ge[b] * P0[b];
+                g1 += ge[b] * P1[b];
+            }
+            double gmu = pe1 * dmu;
+            if (MIX) {
+                double gpi[2] = {g0, g1};
+                if (ACC) {
+                    gpi[0] = 0.0;
+                    gpi[1] = (g1 - g0) * dpe1_dpi1;
+                    acc[kPGnoise] += (g1 - g0) * dpe1_dl;
+                }
+                const double lpi[2] = {flog(pi[0]), flog(pi[1])};
+                const double rpi[2] = {frcp(pi[0]), frcp(pi[1])};
+                if (rgm) {
+                    // control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)) (survival_model.py:326-346)
+                    for (int cc = 0; cc < c.C; ++cc) {
+                        const double tc = c.ctrl_time[cc];
+                        const double gr[2] = {exp(u * tc), exp(mu1 * tc)};
+                        const double wv[2] = {pi[0] * gr[0], pi[1] * gr[1]};
+                        const double rW = frcp(wv[0] + wv[1]);
+                        double n_in = 0.0, cnt[2];
+                        bool inside[2];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            const double pr = wv[a] * rW;
+                            inside[a] = pr > kProbEps && pr < 1.0 - kProbEps;
+                            cnt[a] = (double)c.allele[(((long)r * c.C + cc) * G + g) * 2 + a];
+                            nll -= cnt[a] * flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                            if (inside[a]) n_in += cnt[a];
+                        }
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+                            gpi[a] += ((inside[a] ? -cnt[a] * frcp(wv[a]) : 0.0) + n_in * rW) * gr[a];
+                        gmu += ((inside[1] ? -cnt[1] : 0.0) + n_in * wv[1] * rW) * tc;
+                    }
+                    acc[kPNrg] += 1.0;
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    if (rgm) {
+                        acc[kPLp + a] += lpi[a];
+                        gpi[a] -= (cp[a] - 1.0) * rpi[a];
+                    }
+                    acc[kPLq + a] += lpi[a];
+                    gpi[a] += (cq[a] - 1.0) * rpi[a];
+                }
+                const double proj = pi[0] * gpi[0] + pi[1] * gpi[1];
+                const double total = cq[0] + cq[1];
+                double path0 = 0.0, path1 = 0.0;
+#pragma unroll 1
+                for (int a = 0; a < 2; ++a) {
+                    const bool skip = a ? cl[1] : cl[0];
+                    if (skip) continue;
+                    const double v = dirichlet_grad_one(a ? pi[1] : pi[0], a ? cq[1] : cq[0], total) *
+                                     ((a ? gpi[1] : gpi[0]) - proj);
+                    path0 = a ? path0 : v;
+                    path1 = a ? v : path1;
+                }
+                acc[kPPath] += path0;
+                acc[kPPath + 1] += path1;
+                // ---- Dirichlet(q0) site: +log q(x) of the guide's draw, -log p(obs) of the model
+                {
+                    const double gm = c.gam[(long)r * G + g];
+                    // float32 semantics of torch's draw: normalise, clamp to [FLT_MIN, 1 - 2^-24]
+                    const double x = c.x0_in ? gm
+                                             : (double)fminf(fmaxf((float)(gm * frcp(c.gsum[r])), 1.17549435e-38f),
+                                                             0.99999994f);
+                    if (c.x0_out) c.x0_out[(long)r * G + g] = x;
+                    const double lx = flog(x), lobs = c.log_obs0[(long)r * G + g];
+                    const double tot0 = c.gsum[c.R];
+                    nll += (q0 - 1.0) * (lx - lobs);
+                    const double gout = (q0 - 1.0) * frcp(x);
+                    const double S = tot0 - (double)c.G_tot;  // sum_g x_g * gout_g
+                    acc[kPQ0] += lx - lobs + dirichlet_grad_one(x, q0, tot0) * (gout - S);
+                }
+            }
+            acc[kPGmu] += gmu;
+            loss += nll;
+        }
+    }
+
     double* red = lds;  // [nw][kNumPart][64]
     if (nw > 1) {
 #pragma unroll
@@ -1137,7 +1474,7 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
     }
     const double tot = block_sum(v, scratch);
     if (threadIdx.x == 0) atomicAdd(c.loss_const, tot);
-    if (blockIdx.x == 0 && (int)threadIdx.x < c.B) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < c.B && !c.survival) {
         const double zh = c.z_hi[threadIdx.x], zl = c.z_lo[threadIdx.x];
         const double ch = isinf(zh) ? 1.0 : norm_cdf(zh);
         const double cl = isinf(zl) ? 0.0 : norm_cdf(zl);

@@ -299,7 +299,7 @@ __device__ BEAN_NOINLINE double dirichlet_grad_one(double x, double alpha, doubl
 // (seed, site, element) through the subsequence and by the SVI step through the
 // offset, so draws do not depend on grid shape or on the number of GPUs.
 // ---------------------------------------------------------------------------
-enum RngSite : unsigned long long { kSiteTarget = 1, kSitePi = 2, kSiteNoise = 3, kSiteAux = 4 };
+enum RngSite : unsigned long long { kSiteTarget = 1, kSitePi = 2, kSiteNoise = 3, kSiteAux = 4, kSiteQ0 = 5 };
 
 struct Rng {
     rocrand_state_philox4x32_10 st;

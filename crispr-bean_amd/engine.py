@@ -20,7 +20,7 @@ import torch
 from . import _lib
 
 PI_NOISE_SD = 0.655  # bean/model/utils.py:133
-POSITIVE = ("mu_scale", "sd_scale", "alpha_pi", "noise_scale")
+POSITIVE = ("mu_scale", "sd_scale", "alpha_pi", "noise_scale", "q0")
 
 
 def _quantile_edges(upper: torch.Tensor, lower: torch.Tensor):
@@ -58,11 +58,15 @@ class HipSVI:
         guide_offset: int = 0,
         target_offset: int = 0,
         n_guides_total: int = 0,
+        mu_negctrl=(0.0, 0.1),
     ):
         if family not in _lib.FAMILY:
             raise ValueError(f"unknown model family {family!r}")
-        if getattr(data, "selection", "sorting") != "sorting":
-            raise NotImplementedError("survival screens are not implemented in the HIP engine yet")
+        survival = getattr(data, "selection", "sorting") == "survival"
+        if survival and family not in ("ControlNormal", "MixtureNormal"):
+            raise NotImplementedError(
+                f"survival {family} is not implemented in the HIP engine yet (ControlNormal, MixtureNormal are)")
+        self.survival = survival
         if not torch.cuda.is_available():
             raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
         self.lib = _lib.load()
@@ -126,14 +130,17 @@ class HipSVI:
         self.lrd = float(gamma) ** (1.0 / self.num_steps)
         self.initial_lr = float(initial_lr)
         n_ctrl = int(data.allele_counts_control.shape[1]) if mixture else 0
+        if survival and family == "ControlNormal":
+            flags |= _lib.FLAG_PRIOR_NORMAL_MU  # mu_targets ~ Normal(0, 1) (survival_model.py:142)
         shape = _lib.bean_hip_shape(
-            family=_lib.FAMILY[family], selection=0, flags=flags, n_reps=R, n_condits=B, n_guides=G,
+            family=_lib.FAMILY[family], selection=1 if survival else 0, flags=flags, n_reps=R, n_condits=B, n_guides=G,
             n_targets=T, n_max_alleles=A, n_edits=T if tiling else 0, n_ctrl=n_ctrl, mask_thres=int(mask_thres),
             max_target_len=max_len, guide_offset=int(guide_offset), target_offset=int(target_offset),
             n_guides_total=int(n_guides_total), n_a2e_nnz=nnz,
             # the reference holds the prior scale in a float32 tensor (model.py:406)
             sd_prior_scale=1.0 if family == "ControlNormal" else float(np.float32(sd_scale)),
             initial_lr=self.initial_lr, lrd=self.lrd, clip_norm=10.0,
+            negctrl_loc=float(mu_negctrl[0]), negctrl_scale=float(mu_negctrl[1]),
         )
         self._shape = shape
         handle = ctypes.c_void_p()
@@ -145,14 +152,27 @@ class HipSVI:
 
         f32 = lambda t: t.to(dev, torch.float32).contiguous()
         f64 = lambda t: t.to(dev, torch.float64).contiguous()
-        z_hi, z_lo = _quantile_edges(data.upper_bounds, data.lower_bounds)
         self._bind("X", f32(data.X_masked))
         self._bind("REPGUIDE", data.repguide_mask.to(dev, torch.uint8).contiguous())
         self._bind("SIZE_FACTOR", f64(data.size_factor))
         self._bind("SAMPLE_MASK", f64(data.sample_mask))
         self._bind("A0", f64(data.a0))
-        self._bind("Z_HI", f64(z_hi))
-        self._bind("Z_LO", f64(z_lo))
+        if survival:
+            self._bind("TIMEPOINTS", f64(data.timepoints))
+            if mixture:
+                if int(data.control_timepoint.numel()) != n_ctrl:
+                    raise ValueError("control_timepoint must list one time per control condition")
+                self._bind("CONTROL_TIME", f64(data.control_timepoint))
+                # observed initial abundance (survival_model.py:310), formed in float32 as the reference does
+                x_t0 = data.X[:, 0, :].to(torch.float32) + 1
+                obs0 = x_t0 / x_t0.sum(-1, keepdim=True)
+                if n_guides_total and n_guides_total != G:
+                    raise NotImplementedError("guide-sharded survival fits need the all-reduced t0 totals")
+                self._bind("LOG_OBS0", f64(torch.log(obs0.double())))
+        else:
+            z_hi, z_lo = _quantile_edges(data.upper_bounds, data.lower_bounds)
+            self._bind("Z_HI", f64(z_hi))
+            self._bind("Z_LO", f64(z_lo))
         if tiling:
             self._bind("A2E_PTR", a2e_ptr.to(dev).contiguous())
             self._bind("E2A_PTR", e2a_ptr.to(dev).contiguous())
@@ -185,10 +205,12 @@ class HipSVI:
 
         # ---- parameters (unconstrained), as pyro.param initialises them
         pshape = () if family == "ControlNormal" else ((T,) if tiling else (T, 1))
-        init = {
-            "mu_loc": torch.zeros(pshape), "mu_scale": torch.zeros(pshape),
-            "sd_loc": torch.zeros(pshape), "sd_scale": torch.zeros(pshape),
-        }
+        init = {"mu_loc": torch.zeros(pshape), "mu_scale": torch.zeros(pshape)}
+        if not survival:  # survival models have no sd latent (bean/cli/run.py:305)
+            init["sd_loc"] = torch.zeros(pshape)
+            init["sd_scale"] = torch.zeros(pshape)
+        if survival and mixture:  # q0 = ones(G) / G (survival_model.py:660-664)
+            init["q0"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(G))))
         if mixture:
             init["alpha_pi"] = torch.zeros((G, A))
             if tiling:  # alpha_pi0[~allele_mask] = epsilon (model.py:643)
@@ -218,9 +240,15 @@ class HipSVI:
         self._noise_out: Dict[str, torch.Tensor] = {}
         if dump_noise:
             self._noise_out["eps_mu"] = torch.zeros(T, dtype=torch.float64, device=dev)
-            self._noise_out["eps_sd"] = torch.zeros(T, dtype=torch.float64, device=dev)
             self._bind("EPS_MU_OUT", self._noise_out["eps_mu"])
-            self._bind("EPS_SD_OUT", self._noise_out["eps_sd"])
+            if not survival:
+                self._noise_out["eps_sd"] = torch.zeros(T, dtype=torch.float64, device=dev)
+                self._bind("EPS_SD_OUT", self._noise_out["eps_sd"])
+            if survival and mixture:
+                self._noise_out["initial_abundance"] = torch.zeros((R, G), dtype=torch.float64, device=dev)
+                self._noise_out["eps_u"] = torch.zeros(G, dtype=torch.float64, device=dev)
+                self._bind("X0_OUT", self._noise_out["initial_abundance"])
+                self._bind("EPS_U_OUT", self._noise_out["eps_u"])
             if mixture:
                 self._noise_out["pi"] = torch.zeros((R, G, A), dtype=torch.float64, device=dev)
                 self._bind("PI_OUT", self._noise_out["pi"])
@@ -282,7 +310,12 @@ class HipSVI:
         """Inject the draws of the next evaluation(s) (parity tests);
         ``None`` returns to the in-kernel generator."""
         dev = self.device
-        names = {"eps_mu": "EPS_MU_IN", "eps_sd": "EPS_SD_IN", "pi": "PI_IN", "eps_noise": "EPS_NOISE_IN"}
+        names = {"eps_mu": "EPS_MU_IN", "eps_sd": "EPS_SD_IN", "pi": "PI_IN", "eps_noise": "EPS_NOISE_IN",
+                 "initial_abundance": "X0_IN", "eps_u": "EPS_U_IN"}
+        if noise is not None and "mu_negctrl" in noise and "eps_u" not in noise:
+            m0, s0 = float(np.float32(self._shape.negctrl_loc)), float(np.float32(self._shape.negctrl_scale))
+            noise = dict(noise)
+            noise["eps_u"] = (torch.as_tensor(noise["mu_negctrl"]).double() - m0) / s0
         for key, slot in names.items():
             t = None if noise is None else noise.get(key)
             if t is None:
@@ -312,6 +345,9 @@ class HipSVI:
         out = {k: v.clone() for k, v in self._noise_out.items()}
         if "pi" in out:
             out["pi"] = out["pi"].unsqueeze(1)  # (R, 1, G, A) as the reference shapes it
+        if "eps_u" in out:  # the oracle takes the baseline draw itself: u = m0 + s0 * eps (float32 constants)
+            m0, s0 = np.float32(self._shape.negctrl_loc), np.float32(self._shape.negctrl_scale)
+            out["mu_negctrl"] = float(m0) + out.pop("eps_u") * float(s0)
         if self.family == "MultiMixtureNormal":
             pass  # per-edit draws are 1-D, as the reference shapes them
         elif self.family != "ControlNormal":
@@ -320,7 +356,8 @@ class HipSVI:
                     out[k] = out[k].reshape(self.T, 1)
         else:
             for k in ("eps_mu", "eps_sd"):
-                out[k] = out[k].reshape(())
+                if k in out:
+                    out[k] = out[k].reshape(())
         return out
 
     def adam(self, t: int):

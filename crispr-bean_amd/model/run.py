@@ -66,8 +66,12 @@ def build_engine(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000,
     m, g = _resolve(model), _resolve(guide)
     if m.family != g.family and not (m.family == "MixtureNormalConstPi"):
         raise ValueError(f"model family {m.family} does not match guide family {g.family}")
-    if m.selection != "sorting":
-        raise NotImplementedError("survival models are not implemented in the HIP engine yet")
+    if m.selection != getattr(data, "selection", "sorting"):
+        raise ValueError(f"{m.selection} model used with a {getattr(data, 'selection', 'sorting')} screen")
+    if m.selection == "survival":
+        neg = m.get("mu_negctrl", (0.0, 0.1))
+        if m.family == "MixtureNormal":
+            engine_kw = dict(engine_kw, mu_negctrl=(float(neg[0]), float(neg[1])))
     return HipSVI(
         m.family,
         data,

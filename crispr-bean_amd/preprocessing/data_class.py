@@ -205,6 +205,8 @@ class ScreenTensors:
             assert tuple(self.X_bcmatch.shape) == (R, B, G)
             assert tuple(self.size_factor_bcmatch.shape) == (R, B)
             assert tuple(self.a0_bcmatch.shape) == (G,)
+        if self.selection == "survival":
+            assert tuple(self.timepoints.shape) == (B,)
         if getattr(self, "allele_counts_control", None) is not None:
             acc = self.allele_counts_control
             assert acc.shape[0] == R and acc.shape[2] == G

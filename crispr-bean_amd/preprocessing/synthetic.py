@@ -306,3 +306,90 @@ def make_sorting_tiling_screen(
     data.truth = {"mu_edits": mu_e, "pi": pi_true}
     data.validate()
     return data
+
+
+def make_survival_variant_screen(
+    n_guides: int = 100_000,
+    n_reps: int = 3,
+    times=(0.0, 3.0, 6.0, 9.0, 12.0, 15.0),
+    control_index: int = 1,
+    guides_per_target: int = 5,
+    depth_per_guide: float = 500.0,
+    seed: int = BASE_SEED + 5,
+    with_accessibility: bool = False,
+    frac_effect: float = 0.1,
+    mask_fraction: float = 0.0,
+) -> ScreenTensors:
+    """Variant survival / proliferation screen (BASELINE config 5): guide
+    abundance grows as ``exp(mu * t)`` over timepoints normalised by the last one
+    (``data_class.py:1034-1053``); the control condition is timepoint
+    ``control_index`` and, as in the reference, stays among the ``n_condits``
+    timepoints of ``X``.  The likelihood is Dirichlet-Multinomial over
+    timepoints (the reference has no Negative-Binomial model)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    R, G = n_reps, n_guides
+    t = np.asarray(times, dtype=np.float64)
+    t = t / t.max()
+    B = len(t)
+    T, lengths, g2t = _target_layout(G, guides_per_target)
+    mu_true = np.where(rng.random(T) < frac_effect, rng.normal(0.0, 1.0, T), 0.0)
+    is_negctrl = rng.random(T) < 0.05
+    mu_true[is_negctrl] = 0.0
+    pi_true = rng.beta(2.0, 5.0, G)
+    base = rng.normal(0.0, 0.1, G)  # per-guide baseline growth of unedited cells
+    abundance = np.exp(rng.normal(0.0, 0.5, G))
+    abundance /= abundance.mean()
+    acc = np.exp(rng.normal(1.0, 0.8, G)) if with_accessibility else None
+    mu_g = mu_true[g2t]
+    growth = (1 - pi_true)[None, :] * np.exp(base[None, :] * t[:, None]) + pi_true[None, :] * np.exp(
+        (base + mu_g)[None, :] * t[:, None]
+    )  # (B, G)
+    depth = rng.uniform(0.7, 1.3, (R, B))
+    prop = growth[None] * depth[:, :, None]
+    prop_g = prop / prop.sum(1, keepdims=True)
+    n_rg = rng.poisson(depth_per_guide * abundance[None, :] * prop.sum(1))
+    a0_true = np.exp(-1.510 + 0.7861 * np.log(np.maximum(n_rg, 1)))
+    alpha = np.moveaxis(prop_g, 1, -1) * a0_true[:, :, None]
+    X = np.moveaxis(_dirmult_counts(rng, n_rg, alpha), -1, 1).astype(np.float64)
+    X_bc = rng.binomial(X.astype(np.int64), 0.8).astype(np.float64)
+    c = control_index
+    X_bc_ctrl = X_bc[:, c : c + 1, :]
+    # edited fraction at the control timepoint reflects selection up to t_c
+    w1 = pi_true * np.exp((base + mu_g) * t[c])
+    w0 = (1 - pi_true) * np.exp(base * t[c])
+    edited = rng.binomial(X_bc_ctrl.astype(np.int64), (w1 / (w0 + w1))[None, None, :]).astype(np.float64)
+    ac = np.stack([X_bc_ctrl - edited, edited], axis=-1)
+
+    sample_mask = np.ones((R, B), dtype=np.int64)
+    repguide = np.ones((R, G), dtype=bool)
+    if mask_fraction > 0:
+        repguide &= rng.random((R, G)) >= mask_fraction
+        sample_mask[R - 1, B - 1] = 0
+    sf = _size_factor(X.reshape(R * B, G).T).reshape(R, B)
+    sf_bc = _size_factor(X_bc.reshape(R * B, G).T).reshape(R, B)
+    a0, popt = fitted_alpha0(X, sf, sample_mask)
+    a0_bc = pred_alpha0(X_bc, sf_bc, popt, sample_mask)
+    pi_a0, _ = fitted_pi_alpha0(ac, sf[:, c : c + 1])
+
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32)
+    f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64)
+    sm = torch.as_tensor(sample_mask)
+    Xt, Xbt = f32(X), f32(X_bc)
+    data = ScreenTensors(
+        n_reps=R, n_condits=B, n_guides=G, n_targets=T, n_max_alleles=2,
+        X=Xt, X_masked=Xt * sm[:, :, None], X_bcmatch=Xbt, X_bcmatch_masked=Xbt * sm[:, :, None],
+        X_control=Xt[:, c : c + 1, :].clone(), X_bcmatch_control=Xbt[:, c : c + 1, :].clone(),
+        sample_mask=sm, control_sample_mask=sm[:, c : c + 1].clone(),
+        repguide_mask=torch.as_tensor(repguide) & ~(Xt == 0).any(dim=1),
+        size_factor=f64(sf), size_factor_bcmatch=f64(sf_bc), size_factor_control=f64(sf[:, c : c + 1]),
+        size_factor_bcmatch_control=f64(sf_bc[:, c : c + 1]),
+        a0=f64(a0), a0_bcmatch=f64(a0_bc), pi_a0=f64(pi_a0), allele_counts_control=f32(ac),
+        timepoints=f64(t), control_timepoint=f64(t[c : c + 1]),
+        upper_bounds=None, lower_bounds=None, target_lengths=torch.as_tensor(lengths),
+        guide_accessibility=f64(acc) if acc is not None else None, popt=popt,
+    )
+    data.selection, data.library_design = "survival", "variant"
+    data.truth = {"mu": mu_true, "pi": pi_true, "negctrl_target": is_negctrl}
+    data.negctrl_guide_idx = np.nonzero(is_negctrl[g2t])[0]
+    data.validate()
+    return data

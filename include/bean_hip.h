@@ -89,6 +89,10 @@ typedef struct bean_hip_shape {
     double initial_lr;     /* ClippedAdam lr (0.01) */
     double lrd;            /* per-step lr decay gamma ** (1 / num_steps) */
     double clip_norm;      /* 10 */
+    /* survival MixtureNormal: prior of the per-guide baseline growth mu_negctrl
+     * (survival_model.py:225,271-274); fed from the neg-ctrl fit by bean run */
+    double negctrl_loc;    /* 0.0 */
+    double negctrl_scale;  /* 0.1 */
 } bean_hip_shape;
 
 /* Buffer slots.  dtype / shape in brackets; "opt" = only for some families. */
@@ -119,6 +123,10 @@ enum bean_hip_buf {
     BEAN_BUF_E2A_PTR,         /* i32 (E+1)                                       opt  */
     BEAN_BUF_E2A_IDX,         /* i32 (nnz)  allele slots containing the edit     opt  */
     BEAN_BUF_ALLELE_MASK,     /* u8  (G,A)  allele_mask                          opt  */
+    /* survival: timepoints divided by the last one (data_class.py:1034-1053) */
+    BEAN_BUF_TIMEPOINTS,      /* f64 (B)                                         opt  */
+    BEAN_BUF_CONTROL_TIME,    /* f64 (C)   timepoint(s) of the control condition opt  */
+    BEAN_BUF_LOG_OBS0,        /* f64 (R,G) log((X[:,0,:]+1)/sum): observed initial abundance opt */
     /* ---- parameters: unconstrained values as Pyro's param store keeps them */
     BEAN_BUF_P_MU_LOC = 32,   /* f32 (T)                                              */
     BEAN_BUF_P_MU_SCALE,      /* f32 (T)   log mu_scale                               */
@@ -127,6 +135,7 @@ enum bean_hip_buf {
     BEAN_BUF_P_ALPHA_PI,      /* f32 (G,A) log alpha_pi                          opt  */
     BEAN_BUF_P_NOISE_LOC,     /* f32 (G)                                         opt  */
     BEAN_BUF_P_NOISE_SCALE,   /* f32 (G)   log noise_scale                       opt  */
+    BEAN_BUF_P_Q0,            /* f32 (G)   log q0 (survival MixtureNormal)       opt  */
     /* ---- gradients w.r.t. the unconstrained parameters (bean_hip_elbo_grad) */
     BEAN_BUF_G_MU_LOC = 48,
     BEAN_BUF_G_MU_SCALE,
@@ -135,6 +144,7 @@ enum bean_hip_buf {
     BEAN_BUF_G_ALPHA_PI,
     BEAN_BUF_G_NOISE_LOC,
     BEAN_BUF_G_NOISE_SCALE,
+    BEAN_BUF_G_Q0,
     /* ---- ClippedAdam first / second moments, same shapes as the parameters */
     BEAN_BUF_M_MU_LOC = 64,
     BEAN_BUF_M_MU_SCALE,
@@ -143,6 +153,7 @@ enum bean_hip_buf {
     BEAN_BUF_M_ALPHA_PI,
     BEAN_BUF_M_NOISE_LOC,
     BEAN_BUF_M_NOISE_SCALE,
+    BEAN_BUF_M_Q0,
     BEAN_BUF_V_MU_LOC = 80,
     BEAN_BUF_V_MU_SCALE,
     BEAN_BUF_V_SD_LOC,
@@ -150,6 +161,7 @@ enum bean_hip_buf {
     BEAN_BUF_V_ALPHA_PI,
     BEAN_BUF_V_NOISE_LOC,
     BEAN_BUF_V_NOISE_SCALE,
+    BEAN_BUF_V_Q0,
     /* ---- injected / exported noise (parity tests) */
     BEAN_BUF_EPS_MU_IN = 96,  /* f64 (T)   standard-normal draws for mu_targets  opt  */
     BEAN_BUF_EPS_SD_IN,       /* f64 (T)                                         opt  */
@@ -159,6 +171,10 @@ enum bean_hip_buf {
     BEAN_BUF_EPS_SD_OUT,      /* f64 (T)                                         opt  */
     BEAN_BUF_PI_OUT,          /* f64 (R,G,A)                                     opt  */
     BEAN_BUF_EPS_NOISE_OUT,   /* f64 (G)                                         opt  */
+    BEAN_BUF_X0_IN,           /* f64 (R,G) survival: Dirichlet(q0) draws         opt  */
+    BEAN_BUF_EPS_U_IN,        /* f64 (G)   survival: mu_negctrl standard normals opt  */
+    BEAN_BUF_X0_OUT,          /* f64 (R,G)                                       opt  */
+    BEAN_BUF_EPS_U_OUT,       /* f64 (G)                                         opt  */
     /* ---- loss */
     BEAN_BUF_LOSS_HIST = 112, /* f64 (capacity) one entry per SVI step                */
     BEAN_BUF_COUNT = 128

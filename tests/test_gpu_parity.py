@@ -455,3 +455,101 @@ def test_tiling_run_inference_recovers_edit_effects(engine):
     mu, truth = out["params"]["mu_loc"].numpy(), data.truth["mu_edits"]
     big = np.abs(truth) > 1.0
     assert big.sum() > 10 and np.mean(np.sign(mu[big]) == np.sign(truth[big])) > 0.8
+
+
+# ------------------------------------------------------------------ survival
+from bean_amd.preprocessing.synthetic import make_survival_variant_screen  # noqa: E402
+from oracle import survival as osurv  # noqa: E402
+
+
+def _compare_survival(engine, family, data, kw, seed=7, step=2):
+    torch.manual_seed(seed)
+    eng = engine.HipSVI(family, data.to(DEV), dump_noise=True, num_steps=50, **kw)
+    for v in eng.unconstrained.values():
+        v.add_(0.3 * torch.randn_like(v))
+    loss, grads = eng.elbo_grad(step=step, seed=seed)
+    draws = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+    for mode, tl, tg in (("f64", 1e-9, 5e-7), ("ref", 2e-6, 2e-5)):
+        params = {k: v.detach().cpu().clone() for k, v in eng.unconstrained.items()}
+        d = data
+        if mode == "f64":
+            params = {k: v.double() for k, v in params.items()}
+            d = elbo.as_float64(data)
+        params = {k: v.requires_grad_(True) for k, v in params.items()}
+        ref_loss, ref_grads, _ = svi.loss_and_grads(osurv.LOSSES[family], d, params, noise=draws, **kw)
+        assert abs(loss - ref_loss) <= tl * abs(ref_loss), (mode, loss, ref_loss)
+        for k, g in grads.items():
+            ref = ref_grads[k].double().reshape(-1)
+            err = (g.cpu().double().reshape(-1) - ref).abs().max().item()
+            # torch evaluates the implicit gradient of the float32 Dirichlet(q0) site in float32
+            tol = 2e-4 if (k == "q0" and mode == "ref") else tg
+            assert err <= tol * (ref.abs().max().item() + 1e-30), (mode, k, err)
+    eng.set_noise(draws)
+    loss_b, grads_b = eng.elbo_grad(step=step, seed=seed)
+    assert abs(loss_b - loss) <= 1e-12 * abs(loss)
+    for k in grads:
+        assert torch.equal(grads[k], grads_b[k]), k
+    eng.close()
+
+
+@pytest.mark.parametrize("gen_kw,kw", [
+    (dict(n_guides=700, n_reps=3, mask_fraction=0.05), {}),
+    (dict(n_guides=400, n_reps=2, with_accessibility=True), dict(scale_by_accessibility=True)),
+    (dict(n_guides=130, n_reps=9, times=(0.0, 7.0, 14.0)), {}),
+    (dict(n_guides=300, n_reps=2), dict(mu_negctrl=(0.05, 0.2))),
+    (dict(n_guides=65, n_reps=1, times=(0.0, 2.0, 4.0, 6.0, 8.0, 10.0, 12.0, 14.0)), {}),
+])
+def test_survival_mixture_matches_oracle(engine, gen_kw, kw):
+    data = make_survival_variant_screen(seed=4, **gen_kw)
+    assert data.n_condits == len(gen_kw.get("times", range(6)))
+    _compare_survival(engine, "MixtureNormal", data, kw)
+
+
+def test_survival_control_normal_matches_oracle(engine):
+    data = make_survival_variant_screen(3000, 3, seed=5)
+    _compare_survival(engine, "ControlNormal", data[data.negctrl_guide_idx], {})
+
+
+def test_survival_trajectory_fused_loop_and_interface(engine):
+    from types import SimpleNamespace
+
+    from bean_amd.model.run import identify_model_guide, identify_negctrl_model_guide, run_inference
+
+    data = make_survival_variant_screen(800, 3, seed=6, frac_effect=0.5)
+    n = 15
+    eng = engine.HipSVI("MixtureNormal", data.to(DEV), dump_noise=True, num_steps=2000)
+    params = osurv.init_params("MixtureNormal", data)
+    optim = svi.ClippedAdam(params, lr=0.01, lrd=0.1 ** (1 / 2000))
+    for t in range(n):
+        loss, _ = eng.elbo_grad(step=t, seed=5, loss_index=t)
+        draws = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+        eng.adam(t + 1)
+        ref = svi.svi_step(osurv.mixture_normal_loss, data, params, optim, noise=draws)
+        assert abs(loss - ref) <= 5e-6 * abs(ref), (t, loss, ref)
+    torch.cuda.synchronize()
+    for k, v in eng.unconstrained.items():
+        ref = params[k].detach()
+        err = (v.cpu() - ref).abs().max().item()
+        assert err <= 2e-4 * max(1.0, ref.abs().max().item()), (k, err)
+    fused = engine.HipSVI("MixtureNormal", data.to(DEV), num_steps=2000)
+    fused.run(n, seed=5, graph_chunk=4)
+    for k in eng.unconstrained:
+        assert torch.equal(eng.unconstrained[k], fused.unconstrained[k]), k
+    eng.close()
+    fused.close()
+    # the bean run sequence for survival: neg-ctrl fit feeds mu_negctrl into the main model
+    args = SimpleNamespace(selection="survival", library_design="variant", scale_by_acc=False,
+                           ignore_bcmatch=False, dont_fit_noise=False, uniform_edit=False, const_pi=False,
+                           guide_activity_col=None)
+    label, model, guide = identify_model_guide(args)
+    nm, ng = identify_negctrl_model_guide(args, True)
+    assert label == "MixtureNormal"
+    store_n, _ = run_inference(nm, ng, data[data.negctrl_guide_idx], num_steps=200, verbose=False)
+    from functools import partial
+    model = partial(model, mu_negctrl=(store_n["mu_loc"].detach().mean(), store_n["mu_scale"].detach().mean()))
+    store, out = run_inference(model, guide, data, num_steps=400, verbose=False)
+    assert set(store.keys()) == {"mu_loc", "mu_scale", "alpha_pi", "q0"}
+    assert out["loss"][-1] < out["loss"][0]
+    mu, truth = out["params"]["mu_loc"].numpy().ravel(), data.truth["mu"]
+    big = np.abs(truth) > 1.0
+    assert big.sum() > 5 and np.mean(np.sign(mu[big]) == np.sign(truth[big])) > 0.8
