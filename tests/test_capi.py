@@ -59,24 +59,30 @@ def test_slot_numbers_match_header():
     assert table["BEAN_BUF_V_MU_LOC"] == _lib.BUF["V"]
     assert table["BEAN_BUF_EPS_NOISE_OUT"] == _lib.BUF["EPS_NOISE_OUT"]
     assert table["BEAN_BUF_LOSS_HIST"] == _lib.BUF["LOSS_HIST"]
-    assert table["BEAN_BUF_P_NOISE_SCALE"] - table["BEAN_BUF_P_MU_LOC"] == len(_lib.PARAM_ORDER) - 1
+    assert table["BEAN_BUF_P_Q0"] - table["BEAN_BUF_P_MU_LOC"] == len(_lib.PARAM_ORDER) - 1
+    assert table["BEAN_BUF_V_Q0"] - table["BEAN_BUF_V_MU_LOC"] == len(_lib.PARAM_ORDER) - 1
+    for name in ("A2E_PTR", "ALLELE_MASK", "TIMEPOINTS", "LOG_OBS0", "X0_IN", "EPS_U_OUT"):
+        assert table["BEAN_BUF_" + name] == _lib.BUF[name], name
 
 
 def _shape(**kw):
     base = dict(family=2, selection=0, flags=1, n_reps=2, n_condits=5, n_guides=10, n_targets=2,
                 n_max_alleles=2, n_edits=0, n_ctrl=1, mask_thres=10, max_target_len=5, guide_offset=0,
                 target_offset=0, n_guides_total=0, reserved=0, sd_prior_scale=0.01,
-                initial_lr=0.01, lrd=0.999, clip_norm=10.0)
+                initial_lr=0.01, lrd=0.999, clip_norm=10.0, negctrl_loc=0.0, negctrl_scale=0.1)
     base.update(kw)
     return _lib.bean_hip_shape(**base)
 
 
 @pytest.mark.parametrize("kw,msg", [
     (dict(family=7), "family"),
-    (dict(selection=1), "sorting"),
+    (dict(selection=2), "selection"),
+    (dict(selection=1, family=0), "survival screens support"),
+    (dict(family=3, n_max_alleles=9, n_edits=2, n_targets=2), "n_max_alleles"),
+    (dict(family=3, n_max_alleles=4, n_edits=3, n_targets=2), "n_targets == n_edits"),
     (dict(n_condits=9), "n_condits"),
     (dict(n_guides=0), ">= 1"),
-    (dict(n_max_alleles=3), "n_max_alleles"),
+    (dict(n_max_alleles=3), "n_max_alleles == 2"),
     (dict(family=1, n_targets=2), "ControlNormal"),
     (dict(lrd=0.0), "lrd"),
     (dict(guide_offset=5, n_guides_total=12), "shard offsets"),
