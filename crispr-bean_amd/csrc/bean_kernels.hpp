@@ -737,15 +737,8 @@ void k_guide(DevArgs c) {
                     pi[1] = c.pi_in[((long)r * G + g) * 2 + 1];
                 } else {
                     Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
-                    // rolled loop (one copy of the sampler in the code); selects instead of
-                    // runtime-indexed arrays, which would live in scratch
-                    double gm0 = 0.0, gm1 = 0.0;
-#pragma unroll 1
-                    for (int a = 0; a < 2; ++a) {
-                        const double gv = fmax(sample_gamma(a ? cq[1] : cq[0], rng), kDblMin);
-                        gm0 = a ? gm0 : gv;
-                        gm1 = a ? gv : gm1;
-                    }
+                    const GammaPair gp = sample_gamma_pair(cq[0], cq[1], rng);
+                    const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
                     const double rs = frcp(gm0 + gm1);
                     pi[0] = fmin(fmax(gm0 * rs, kDblMin), kOneMinus);
                     pi[1] = fmin(fmax(gm1 * rs, kDblMin), kOneMinus);
@@ -962,13 +955,8 @@ void k_guide_survival(DevArgs c) {
                     pi[1] = c.pi_in[((long)r * G + g) * 2 + 1];
                 } else {
                     Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
-                    double gm0 = 0.0, gm1 = 0.0;
-#pragma unroll 1
-                    for (int a = 0; a < 2; ++a) {
-                        const double gv = fmax(sample_gamma(a ? cq[1] : cq[0], rng), kDblMin);
-                        gm0 = a ? gm0 : gv;
-                        gm1 = a ? gv : gm1;
-                    }
+                    const GammaPair gp = sample_gamma_pair(cq[0], cq[1], rng);
+                    const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
                     const double rs = frcp(gm0 + gm1);
                     pi[0] = fmin(fmax(gm0 * rs, kDblMin), kOneMinus);
                     pi[1] = fmin(fmax(gm1 * rs, kDblMin), kOneMinus);
@@ -1245,11 +1233,18 @@ void k_guide_tiling(DevArgs c) {
                 Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
                 double sum = 0.0;
 #pragma unroll
-                for (int a = 0; a < kAMax; ++a) {
+                for (int a = 0; a < kAMax; a += 2) {
                     pi[a] = 0.0;
-                    if (a < A) {
-                        pi[a] = fmax(sample_gamma(cq[a], rng), kDblMin);
+                    pi[a + 1] = 0.0;
+                    if (a < A) {  // components are drawn two at a time (one rejection loop per pair)
+                        const GammaPair gp = sample_gamma_pair(cq[a], a + 1 < A ? cq[a + 1] : 1.0, rng);
+                        rng.k = gp.k;
+                        pi[a] = fmax(gp.g0, kDblMin);
                         sum += pi[a];
+                        if (a + 1 < A) {
+                            pi[a + 1] = fmax(gp.g1, kDblMin);
+                            sum += pi[a + 1];
+                        }
                     }
                 }
                 const double rs = frcp(sum);
@@ -1525,8 +1520,9 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
         unsigned long long seed;
         memcpy(&seed, &x[0], 8);
         Rng rng(seed, kSiteAux, (unsigned long long)i, 0ull);
-        double g0 = fmax(sample_gamma(a[i], rng), kDblMin);
-        double g1 = fmax(sample_gamma(b[i], rng), kDblMin);
+        const GammaPair gp = sample_gamma_pair(a[i], b[i], rng);
+        double g0 = fmax(gp.g0, kDblMin);
+        double g1 = fmax(gp.g1, kDblMin);
         const double s = g0 + g1;
         o0[i] = fmin(fmax(g0 / s, kDblMin), kOneMinus);
         o1[i] = fmin(fmax(g1 / s, kDblMin), kOneMinus);

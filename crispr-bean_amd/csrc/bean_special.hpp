@@ -301,66 +301,125 @@ __device__ BEAN_NOINLINE double dirichlet_grad_one(double x, double alpha, doubl
 // ---------------------------------------------------------------------------
 enum RngSite : unsigned long long { kSiteTarget = 1, kSitePi = 2, kSiteNoise = 3, kSiteAux = 4, kSiteQ0 = 5 };
 
+// Stateless view of one Philox subsequence: draw k is counter (offset/4 + k), so
+// the generator lives in 7 registers and never touches memory.
 struct Rng {
-    rocrand_state_philox4x32_10 st;
-    double spare;
-    bool has_spare;
-    __device__ __forceinline__ Rng(unsigned long long seed, RngSite site,
-                                   unsigned long long element, unsigned long long offset) {
-        rocrand_init(seed, ((unsigned long long)site << 48) + element, offset, &st);
-        has_spare = false;
-        spare = 0.0;
-    }
-    __device__ __forceinline__ double normal() {
-        if (has_spare) {
-            has_spare = false;
-            return spare;
-        }
-        // Box-Muller on two 53-bit uniforms built from one Philox counter (4 words)
-        const uint4 v = rocrand4(&st);
-        const double u1 = to_unit(v.x, v.y), u2 = to_unit(v.z, v.w);
-        const double rad = sqrt(-2.0 * flog(u1));
-        double sn, cs;
-        sincospi(2.0 * u2, &sn, &cs);
-        spare = rad * sn;
-        has_spare = true;
-        return rad * cs;
-    }
+    unsigned long long seed, sub, off;
+    unsigned int k;
+    __device__ __forceinline__ Rng(unsigned long long seed_, RngSite site, unsigned long long element,
+                                   unsigned long long offset)
+        : seed(seed_), sub(((unsigned long long)site << 48) + element), off(offset), k(0) {}
+    // four fresh 32-bit words
     // (0, 1] from 53 random bits
     static __device__ __forceinline__ double to_unit(unsigned int a, unsigned int b) {
         const unsigned long long bits = (((unsigned long long)a << 32) | b) >> 11;
         return ((double)bits + 1.0) * 1.1102230246251565e-16;  // 2^-53
     }
-    __device__ __forceinline__ double uniform() {
-        const unsigned int a = rocrand(&st), b = rocrand(&st);
-        return to_unit(a, b);
-    }
 };
 
-// Gamma(alpha, 1) by Marsaglia & Tsang (2000) with the alpha < 1 boost
-// (the method torch's sample_gamma uses for Dirichlet draws).
-__device__ BEAN_NOINLINE double sample_gamma(double alpha, Rng& rng) {
-    double scale = 1.0;
-    if (alpha < 1.0) {
-        if (alpha == 0.0) return 0.0;
-        scale = exp(flog(rng.uniform()) * frcp(alpha));
-        alpha += 1.0;
+struct Pair {
+    double a, b;
+};
+
+// Philox4x32-10 block at an absolute position; out of line so that its ~35
+// registers are not multiplied by inlining into the rejection loop.
+__device__ __noinline__ uint4 philox_at(unsigned long long seed, unsigned long long sub,
+                                        unsigned long long offset) {
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed, sub, offset, &st);
+    return rocrand4(&st);
+}
+
+// two standard normals (Box-Muller on two 53-bit uniforms) from one Philox counter
+__device__ __noinline__ Pair normal_pair_at(unsigned long long seed, unsigned long long sub,
+                                            unsigned long long offset) {
+    const uint4 v = philox_at(seed, sub, offset);
+    const double u1 = Rng::to_unit(v.x, v.y), u2 = Rng::to_unit(v.z, v.w);
+    const double rad = sqrt(-2.0 * flog(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    Pair p;
+    p.a = rad * cs;
+    p.b = rad * sn;
+    return p;
+}
+__device__ __forceinline__ Pair normal_pair(Rng& rng) {
+    const Pair p = normal_pair_at(rng.seed, rng.sub, rng.off + 4ull * rng.k);
+    ++rng.k;
+    return p;
+}
+__device__ __forceinline__ Pair uniform_pair(Rng& rng) {
+    const uint4 v = philox_at(rng.seed, rng.sub, rng.off + 4ull * rng.k);
+    ++rng.k;
+    Pair p;
+    p.a = Rng::to_unit(v.x, v.y);
+    p.b = Rng::to_unit(v.z, v.w);
+    return p;
+}
+
+struct GammaPair {
+    double g0, g1;
+    unsigned int k;  // generator position after the draw
+};
+
+// Two independent Gamma(alpha_i, 1) draws by Marsaglia & Tsang (2000) with the
+// alpha < 1 boost (the method behind torch's sample_gamma), sharing one
+// rejection loop: each round costs two Philox counters for both components, and
+// a wave only iterates until its slowest lane has accepted both.
+__device__ BEAN_NOINLINE GammaPair sample_gamma_pair(double a0, double a1, Rng rng) {
+    double scale0 = 1.0, scale1 = 1.0;
+    if (a0 < 1.0 || a1 < 1.0) {
+        const Pair u = uniform_pair(rng);
+        if (a0 < 1.0) {
+            scale0 = a0 == 0.0 ? 0.0 : exp(flog(u.a) * frcp(a0 == 0.0 ? 1.0 : a0));
+            a0 += 1.0;
+        }
+        if (a1 < 1.0) {
+            scale1 = a1 == 0.0 ? 0.0 : exp(flog(u.b) * frcp(a1 == 0.0 ? 1.0 : a1));
+            a1 += 1.0;
+        }
     }
-    const double d = alpha - 1.0 / 3.0;
-    const double c = frcp(sqrt(9.0 * d));
-    for (int it = 0; it < 64; ++it) {  // acceptance >= 95 % per round; bounded for safety
-        double x, y;
-        do {
-            x = rng.normal();
-            y = 1.0 + c * x;
-        } while (y <= 0.0);
-        const double v = y * y * y;
-        const double u = rng.uniform();
-        const double xx = x * x;
-        if (u < 1.0 - 0.0331 * xx * xx) return scale * d * v;
-        if (flog(u) < 0.5 * xx + d * (1.0 - v + flog(v))) return scale * d * v;
+    const double d0 = a0 - 1.0 / 3.0, d1 = a1 - 1.0 / 3.0;
+    const double c0 = frcp(sqrt(9.0 * d0)), c1 = frcp(sqrt(9.0 * d1));
+    bool done0 = false, done1 = false;
+    double g0 = d0, g1 = d1;
+#pragma unroll 1
+    for (int it = 0; it < 64 && !(done0 && done1); ++it) {  // >= 95 % acceptance per round
+        const Pair n = normal_pair(rng);
+        const Pair u = uniform_pair(rng);
+        if (!done0) {
+            const double y = 1.0 + c0 * n.a;
+            if (y > 0.0) {
+                const double v = y * y * y, xx = n.a * n.a;
+                if (u.a < 1.0 - 0.0331 * xx * xx || flog(u.a) < 0.5 * xx + d0 * (1.0 - v + flog(v))) {
+                    g0 = d0 * v;
+                    done0 = true;
+                }
+            }
+        }
+        if (!done1) {
+            const double y = 1.0 + c1 * n.b;
+            if (y > 0.0) {
+                const double v = y * y * y, xx = n.b * n.b;
+                if (u.b < 1.0 - 0.0331 * xx * xx || flog(u.b) < 0.5 * xx + d1 * (1.0 - v + flog(v))) {
+                    g1 = d1 * v;
+                    done1 = true;
+                }
+            }
+        }
     }
-    return scale * d;  // unreachable in practice (p < 1e-80)
+    GammaPair out;
+    out.g0 = scale0 * g0;
+    out.g1 = scale1 * g1;
+    out.k = rng.k;
+    return out;
+}
+
+// single draw (second component unused)
+__device__ __forceinline__ double sample_gamma(double alpha, Rng& rng) {
+    const GammaPair p = sample_gamma_pair(alpha, 1.0, rng);
+    rng.k = p.k;
+    return p.g0;
 }
 
 }  // namespace bean
