@@ -1,6 +1,7 @@
 // libbean_hip.so: C ABI over the BEAN SVI kernels (see include/bean_hip.h).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -32,6 +33,7 @@ struct bean_hip_ctx {
     uint64_t workspace_bytes;
     uint64_t loss_capacity;
     bool prepared;
+    bool fused_guide;  // default; BEAN_HIP_SPLIT_GUIDE=1 selects the sample / lik / pi-terms launches
     // graph cache
     hipGraphExec_t graph_exec;
     int graph_chunk;
@@ -202,6 +204,10 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     memset(c->slot_bytes, 0, sizeof(c->slot_bytes));
     c->shape = *s;
     c->prepared = false;
+    {
+        const char* env = getenv("BEAN_HIP_SPLIT_GUIDE");
+        c->fused_guide = !(env && env[0] == '1');
+    }
     c->graph_exec = nullptr;
     c->graph_chunk = 0;
     c->graph_seed = 0;
@@ -228,7 +234,15 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const uint64_t n_gblk = (G + 255) / 256;
     d.n_gamma_blocks = (int)n_gblk;
     const uint64_t n_surv = surv_mix ? 2 * G + Rr * G + n_gblk * (Rr + 1) + (Rr + 1) : 0;
-    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 1 + 8 + n_surv;
+    const bool split_ok = !is_survival(*s) && !is_tiling(*s);
+    const bool use_split = split_ok && !c->fused_guide;
+    const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G : 0;
+#ifdef BEAN_STAMP
+    const uint64_t n_dbg = 8 * 2 * Rr * ((G + 63) / 64);
+#else
+    const uint64_t n_dbg = 0;
+#endif
+    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 1 + 8 + n_surv + n_split + n_dbg;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
     if (e != hipSuccess) {
@@ -256,6 +270,16 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.lpn = w; w += G;
     d.eps_noise = w; w += G;
     d.loss_const = w; w += 1;
+    if (n_dbg) {
+        d.dbg = (unsigned long long*)w; w += n_dbg;
+    }
+    if (use_split) {
+        d.rrow = w; w += 3 * Rr * G;
+        if (is_mixture(*s)) {
+            d.pi_ws = w; w += 2 * Rr * G;
+            d.gpi_ws = w; w += 2 * Rr * G;
+        }
+    }
     if (surv_mix) {
         d.u_g = w; w += G;
         d.eps_u = w; w += G;
@@ -392,8 +416,54 @@ static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 
 
 static int waves_per_block(const bean_hip_ctx* c) { return c->d.R < 8 ? c->d.R : 8; }
 
+static void launch_lik(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 block, size_t lds) {
+    const DevArgs& d = c->d;
+    if (d.family == kMixture) {
+        if (d.flags & kAcc)
+            hipLaunchKernelGGL((k_lik<true, true>), grid, block, lds, stream, d);
+        else
+            hipLaunchKernelGGL((k_lik<true, false>), grid, block, lds, stream, d);
+    } else {
+        hipLaunchKernelGGL((k_lik<false, false>), grid, block, lds, stream, d);
+    }
+}
+
+// sorting variant families as three launches (see bean_kernels.hpp, "split form")
+static void launch_guide_split(bean_hip_ctx* c, hipStream_t stream) {
+    const DevArgs& d = c->d;
+    const bool mix = d.family == kMixture;
+    const int nlik = (d.flags & kUseBc) ? 2 : 1;
+    const int rep_waves = d.R < 8 ? d.R : 8;
+    const dim3 grid((d.G + 63) / 64);
+    if (mix) {
+        const long n = (long)d.R * d.G;
+        hipLaunchKernelGGL(k_sample_pi, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
+    }
+    const bool prof = c->profile && c->ev.size() < 8192;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, stream);
+    }
+    launch_lik(c, stream, dim3((d.G + 63) / 64, d.R), dim3(64 * nlik), 0);
+    if (prof) {
+        (void)hipEventRecord(e1, stream);
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+    }
+    if (mix) {
+        const size_t l3 = ((size_t)rep_waves * 7 * 64 + 16) * sizeof(double);
+        hipLaunchKernelGGL(k_pi_terms, grid, dim3(64 * rep_waves), l3, stream, d);
+    }
+}
+
 static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
+    if (!c->fused_guide && !d.survival && d.family != kMultiMixture) {
+        launch_guide_split(c, stream);
+        return;
+    }
     const int nw = waves_per_block(c);
     if (d.survival && d.family == kMixture)  // normalisers of the Dirichlet(q0) draw
         hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, stream, d);
@@ -531,7 +601,8 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
 
 extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
     if (c && c->d.survival) return "k_guide_survival";
-    return (c && c->d.family == kMultiMixture) ? "k_guide_tiling" : "k_guide";
+    if (c && c->d.family == kMultiMixture) return "k_guide_tiling";
+    return (c && c->fused_guide) ? "k_guide" : "k_lik";
 }
 
 extern "C" int bean_hip_set_profile(bean_hip_ctx* c, int32_t enable) {
@@ -558,6 +629,15 @@ extern "C" int bean_hip_get_profile(bean_hip_ctx* c, double* avg_ms, uint64_t* l
     *launches = n;
     return 0;
 }
+
+#ifdef BEAN_STAMP
+// diagnostic builds only: copy the per-wave cycle stamps of the last k_lik launch to the host
+extern "C" int bean_hip_debug_stamps(bean_hip_ctx* c, unsigned long long* host, uint64_t n_words) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(host, c->d.dbg, n_words * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 
 extern "C" int bean_hip_test_special(int32_t op, uint64_t n, const double* a, const double* x,
                                      const double* b, double* out0, double* out1, void* stream_) {

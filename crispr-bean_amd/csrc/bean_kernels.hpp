@@ -28,6 +28,18 @@
 
 namespace bean {
 
+// In-kernel cycle stamps for diagnostic builds only (-DBEAN_STAMP); the shipped kernels contain none.
+#ifdef BEAN_STAMP
+#define BEAN_STAMP_AT(slot)                                                                      \
+    do {                                                                                         \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        if (lane == 0) c.dbg[wave_gid * 8 + (slot)] = t_;                                        \
+    } while (0)
+#else
+#define BEAN_STAMP_AT(slot) do {} while (0)
+#endif
+
 constexpr double kEps = 1e-5;         // epsilon of get_alpha (utils.py:11)
 // utils.py:133; the reference builds Normal(0, 0.655) from Python floats, i.e. float32 tensors
 constexpr double kPiNoiseSd = (double)0.655f;
@@ -81,6 +93,9 @@ struct DevArgs {
     double* part;                      // (kNumPart, G)
     double *lpn, *eps_noise;           // (G)
     double* loss_const;                // (1)
+    double *pi_ws, *gpi_ws;            // (R, G, 2) split-kernel hand-off: draws, d nll / d pi
+    unsigned long long* dbg;           // diagnostic builds (-DBEAN_STAMP): per-wave cycle stamps
+    double* rrow;                      // (3, R, G) split form: d/dmu_t, d/dy_t, d/dnoise per (rep, guide)
     StepCtr *ctrA, *ctrB;
     // tiling (MultiMixtureNormal): CSR allele slot -> edits and its transpose
     int E;
@@ -104,6 +119,7 @@ struct DevArgs {
 
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
 constexpr int kAMax = 8;
+constexpr int kBMax = 8;  // n_condits <= 8 (bean_hip_create)
 enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2 * kAMax,
              kTGsig = 2 + 2 * kAMax + (kAMax - 1), kTNumPart = 2 + 2 * kAMax + 2 * (kAMax - 1) };
 
@@ -125,6 +141,15 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     if (threadIdx.x == 0)
         for (int i = 0; i < nw; ++i) tot += scratch[i];
     return tot;
+}
+
+// likelihood-gradient row q (kPGmu, kPGy or kPGnoise) of guide g: the fused kernels reduce
+// over replicates in LDS, the split form leaves one value per replicate (fixed-order sum)
+__device__ __forceinline__ double lik_row(const DevArgs& c, int q, int g) {
+    if (!c.rrow) return c.part[(long)q * c.G + g];
+    double s = 0.0;
+    for (int r = 0; r < c.R; ++r) s += c.rrow[((long)q * c.R + r) * c.G + g];
+    return s;
 }
 
 // ------------------------------------------------------------- ClippedAdam
@@ -309,8 +334,8 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                 const int g0 = c.toff[t], g1 = c.toff[t + 1];
                 double a = 0.0, b = 0.0;
                 for (int g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
-                    a += c.part[(long)kPGmu * c.G + g];
-                    b += c.part[(long)kPGy * c.G + g];
+                    a += lik_row(c, kPGmu, g);
+                    b += lik_row(c, kPGy, g);
                 }
                 gmu = block_sum(a, scratch);
                 gy = block_sum(b, scratch);
@@ -334,8 +359,8 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                 } else {
                     const int g0 = c.toff[t], g1 = c.toff[t + 1];
                     for (int g = g0; g < g1; ++g) {
-                        gmu += c.part[(long)kPGmu * c.G + g];
-                        gy += c.part[(long)kPGy * c.G + g];
+                        gmu += lik_row(c, kPGmu, g);
+                        gy += lik_row(c, kPGy, g);
                     }
                 }
             }
@@ -533,7 +558,7 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                 emit_grad<ADAM>(c, 4, 2 * g + 1, pa0 / s * (gc[1] - dot) * al1, ak);
                 if (acc_on) {
                     const double lpn = c.lpn[g], eps = c.eps_noise[g];
-                    const double gl = c.part[(long)kPGnoise * c.G + g];
+                    const double gl = lik_row(c, kPGnoise, g);
                     const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
                     // Normal(0, 0.655) prior held in float32 by the reference (utils.py:158-161)
                     const float nsf = 0.655f;
@@ -886,6 +911,335 @@ void k_guide(DevArgs c) {
         atomicAdd(&c.loss_hist[ctr.slot], tot);
         if (blockIdx.x == 0) *c.ctrA = ctr;
     }
+}
+
+// ------------------------------------------------- split form of k_guide (variant)
+// The fused k_guide runs at 2 waves/SIMD (its live state plus the out-of-line
+// samplers) and is latency bound.  The same work as three launches, each at its
+// own occupancy:
+//   k_sample_pi   per (rep, guide): Dirichlet draw                      -> pi_ws
+//   k_lik         per (rep, likelihood, guide): one Dirichlet-Multinomial term
+//                 with analytic gradients (X and X_bcmatch run as separate
+//                 waves; everything downstream is linear in d nll / d e[b])
+//                 -> per-guide d/dmu_t, d/dy_t rows, d nll / d pi per (rep, guide)
+//   k_pi_terms    per (rep, guide): Multinomial on control allele counts,
+//                 Dirichlet log-prob pieces, implicit-reparameterisation gradient
+__global__ __launch_bounds__(256) void k_sample_pi(DevArgs c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)c.R * c.G) return;
+    const int r = (int)(idx / c.G), g = (int)(idx % c.G);
+    double pi0, pi1;
+    if (c.pi_in) {
+        pi0 = c.pi_in[idx * 2];
+        pi1 = c.pi_in[idx * 2 + 1];
+    } else {
+        const double al0 = (double)expf(c.p[4][2 * g]), al1 = (double)expf(c.p[4][2 * g + 1]);
+        const double rs = frcp(al0 + al1) * c.pi_a0[g];
+        const double cq0 = fmax(al0 * rs, 1e-5), cq1 = fmax(al1 * rs, 1e-5);
+        Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), c.ctrB->step * 256ull);
+        const GammaPair gp = sample_gamma_pair(cq0, cq1, rng);
+        const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
+        const double rsum = frcp(gm0 + gm1);
+        pi0 = fmin(fmax(gm0 * rsum, kDblMin), kOneMinus);
+        pi1 = fmin(fmax(gm1 * rsum, kDblMin), kOneMinus);
+    }
+    c.pi_ws[idx * 2] = pi0;
+    c.pi_ws[idx * 2 + 1] = pi1;
+    if (c.flags & kDumpPi) {
+        c.pi_out[idx * 2] = pi0;
+        c.pi_out[idx * 2 + 1] = pi1;
+    }
+}
+
+// grid = (ceil(G / 64), R); blockDim.x = 64 * nlik: one wave per likelihood (X, X_bcmatch) of
+// 64 consecutive guides of one replicate.  Small blocks keep the CUs evenly filled (a block of
+// all replicates x likelihoods would be 10 waves and fit once per CU at 128 VGPRs).
+//
+// Register diet: the loops over conditions are ROLLED and keep scalar state only.
+// alpha_b is recomputed from (pi, P[b], sf[b]) where needed, and because
+// d nll / d alpha_b = psi-diff(A0, n) - psi-diff(alpha_b, x_b) enters every output
+// linearly, the A0 term is factored out and applied after the loop; so one pass
+// yields the likelihood and all gradients without per-condition arrays.
+template <bool MIX, bool ACC>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4)))
+void k_lik(DevArgs c) {
+    __shared__ double ex[2][5][64];  // per wave: gpi0, gpi1, d/dmu, d/dy, d/dnoise
+    __shared__ double scratch[16];
+    // Every global read of the block is issued in one batch up front (the kernel is latency
+    // bound: one exposed memory round trip instead of one per loop iteration) and staged in LDS,
+    // from where the rolled loops read: the Phi tables of the 64 guides' targets, shared by
+    // the likelihood waves, and each thread's own counts.
+    __shared__ double tabs[3][kBMax][64];   // P, dP/dmu, dP/dy of this guide's target
+    __shared__ float xs[2][kBMax][64];
+    const int lane = threadIdx.x & 63;
+    const int lik = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nlik = blockDim.x >> 6;
+    const int g = blockIdx.x * 64 + lane;
+    const int r = blockIdx.y;
+    const bool valid = g < c.G;
+    const int G = c.G, T = c.T, B = c.B;
+    const long rgi = (long)r * G + g;
+    double a_mu = 0.0, a_y = 0.0, a_noise = 0.0, loss = 0.0, gp0 = 0.0, gp1 = 0.0;
+#ifdef BEAN_STAMP
+    const long wave_gid = ((long)blockIdx.y * gridDim.x + blockIdx.x) * nlik + lik;
+#endif
+    BEAN_STAMP_AT(0);
+
+    {
+        const int t = valid ? c.g2t[g] : 0;
+        const float* xq = (lik ? c.Xbc : c.X) + (long)r * B * G + g;
+        // the 3 * B table entries of a guide are split between the likelihood waves
+        const int nq = 3 * B, q0 = lik * ((nq + nlik - 1) / nlik);
+        const int q1 = nlik == 1 ? nq : (lik == 0 ? (nq + 1) / 2 : nq);
+        if (valid) {
+            // fully unrolled and predicated so that all loads are in flight together
+            float xv[kBMax];
+            double tv[3 * kBMax];  // nlik == 1 stages all 3 B entries; two waves split them
+#pragma unroll
+            for (int b = 0; b < kBMax; ++b) xv[b] = b < B ? xq[(long)b * G] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3 * kBMax; ++k) {
+                const int q = q0 + k;
+                tv[k] = 0.0;
+                if (q < q1) {
+                    const int which = q / B, b = q - which * B;
+                    const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
+                    tv[k] = tab[(long)b * T + t];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < kBMax; ++b)
+                if (b < B) xs[lik][b][lane] = xv[b];
+#pragma unroll
+            for (int k = 0; k < 3 * kBMax; ++k) {
+                const int q = q0 + k;
+                if (q < q1) {
+                    const int which = q / B, b = q - which * B;
+                    tabs[which][b][lane] = tv[k];
+                }
+            }
+        }
+    }
+    BEAN_STAMP_AT(1);
+    __syncthreads();
+    BEAN_STAMP_AT(2);
+    if (valid) {
+        const double a0 = lik ? c.a0_bc[g] : c.a0[g];
+        const double* sf = (lik ? c.sf_bc : c.sf) + r * B;
+        const double* sm = c.smask + r * B;
+        const double epsB = kEps / (double)B;
+        double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0, dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
+        if (MIX) {
+            pi0 = c.pi_ws[rgi * 2];
+            pi1 = c.pi_ws[rgi * 2 + 1];
+            pe1 = pi1;
+            if (ACC) {
+                // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
+                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double s1 = pi1 * kacc;
+                const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+                const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+                const double l = flog(p1c * frcp(1.0 - p1c)) + c.lpn[g];
+                const double el = exp(l);
+                const double pn = el * frcp(1.0 + el);
+                const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+                pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+                dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
+                dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+            }
+        }
+        const double w0 = MIX ? (ACC ? 1.0 - pe1 : pi0) : 0.0;  // weight of the wild-type component
+        const double w1 = MIX ? (ACC ? pe1 : pi1) : 1.0;        // weight of the edited component
+        // pass 1: n = sum x_b, S = sum e_b sf_b
+        double S = 0.0, nn = 0.0;
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            const double p1 = tabs[0][b][lane];
+            nn += (double)xs[lik][b][lane];
+            S += (w0 * c.P0[b] + w1 * p1) * sf[b];
+        }
+        BEAN_STAMP_AT(3);
+        const bool obs = c.rg[rgi] != 0 && nn > (double)c.mask_thres;
+        double g0 = 0.0, g1 = 0.0;
+        if (obs) {
+            const double inv = frcp(S + kEps);
+            // pass 2.  With k_b = a0 m_b inv sf_b (0 where alpha_b sits on its floor):
+            //   U_Q = sum k_b Q_b, V_Q = sum dpsi_b k_b Q_b, t_Q = sum sf_b Q_b   (Q in {Pmu, Py, P0, P1})
+            //   Ua = sum_unfloored alpha_b,           Va = sum dpsi_b alpha_b
+            double A0 = 0.0, nll = 0.0, Ua = 0.0, Va = 0.0;
+            double U_mu = 0.0, U_y = 0.0, U_0 = 0.0, U_1 = 0.0;
+            double V_mu = 0.0, V_y = 0.0, V_0 = 0.0, V_1 = 0.0;
+            double t_mu = 0.0, t_y = 0.0, t_0 = 0.0, t_1 = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const double p1 = tabs[0][b][lane], pmu = tabs[1][b][lane], py = tabs[2][b][lane];
+                const double p0 = MIX ? c.P0[b] : 0.0;
+                const double x = (double)xs[lik][b][lane];
+                const double sfb = sf[b], smb = sm[b];
+                const double araw = ((w0 * p0 + w1 * p1) * sfb + epsB) * inv * a0 * smb;
+                const bool floored = araw < kEps;
+                const double alpha = floored ? kEps : araw;
+                A0 += alpha;
+                const DD db = lgamma_digamma_diff_inl(alpha, x);
+                nll -= db.d;
+                const double kb = floored ? 0.0 : a0 * smb * inv * sfb;
+                const double kd = kb * db.dp;
+                Ua += floored ? 0.0 : araw;
+                Va += floored ? 0.0 : db.dp * araw;
+                U_mu += kb * pmu;
+                V_mu += kd * pmu;
+                t_mu += sfb * pmu;
+                U_y += kb * py;
+                V_y += kd * py;
+                t_y += sfb * py;
+                U_1 += kb * p1;
+                V_1 += kd * p1;
+                t_1 += sfb * p1;
+                if (MIX) {
+                    U_0 += kb * p0;
+                    V_0 += kd * p0;
+                    t_0 += sfb * p0;
+                }
+            }
+            BEAN_STAMP_AT(4);
+            const DD d0 = lgamma_digamma_diff_inl(A0, nn);
+            nll += d0.d;
+            // ga_b = d0.dp - dpsi_b  =>  sum ga_b k_b Q_b = d0.dp U_Q - V_Q,  W = (d0.dp Ua - Va) inv
+            const double W = (d0.dp * Ua - Va) * inv;
+            a_mu = w1 * (d0.dp * U_mu - V_mu - W * t_mu);
+            a_y = w1 * (d0.dp * U_y - V_y - W * t_y);
+            g0 = d0.dp * U_0 - V_0 - W * t_0;
+            g1 = d0.dp * U_1 - V_1 - W * t_1;
+            loss = nll;
+        }
+        if (MIX) {
+            gp0 = g0;
+            gp1 = g1;
+            if (ACC) {
+                gp0 = 0.0;
+                gp1 = (g1 - g0) * dpe1_dpi1;
+                a_noise = (g1 - g0) * dpe1_dl;
+            }
+        }
+    }
+    BEAN_STAMP_AT(5);
+    // ---- sum the likelihood waves (fixed order) and write this replicate's rows
+    if (nlik == 2) {
+        ex[lik][0][lane] = gp0;
+        ex[lik][1][lane] = gp1;
+        ex[lik][2][lane] = a_mu;
+        ex[lik][3][lane] = a_y;
+        ex[lik][4][lane] = a_noise;
+        __syncthreads();
+        if (lik == 0) {
+            gp0 += ex[1][0][lane];
+            gp1 += ex[1][1][lane];
+            a_mu += ex[1][2][lane];
+            a_y += ex[1][3][lane];
+            a_noise += ex[1][4][lane];
+        }
+    }
+    if (lik == 0 && valid) {
+        if (MIX) {
+            c.gpi_ws[rgi * 2] = gp0;
+            c.gpi_ws[rgi * 2 + 1] = gp1;
+        }
+        c.rrow[((long)kPGmu * c.R + r) * G + g] = a_mu;
+        c.rrow[((long)kPGy * c.R + r) * G + g] = a_y;
+        if (MIX && ACC) c.rrow[((long)kPGnoise * c.R + r) * G + g] = a_noise;
+    }
+    BEAN_STAMP_AT(6);
+    const double tot = block_sum(loss, scratch);
+    BEAN_STAMP_AT(7);
+    if (threadIdx.x == 0) {
+        atomicAdd(&c.loss_hist[c.ctrB->slot], tot);
+        if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = *c.ctrB;
+    }
+}
+
+// blockDim.x = 64 * nw (replicates); dynamic LDS = nw * 7 * 64 doubles + 16.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
+void k_pi_terms(DevArgs c) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int g = blockIdx.x * 64 + lane;
+    const bool valid = g < c.G;
+    const int G = c.G;
+    // rows: nrg, path0, path1, Lp0, Lp1, Lq0, Lq1
+    double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double loss = 0.0;
+    if (valid) {
+        const double al0 = (double)expf(c.p[4][2 * g]), al1 = (double)expf(c.p[4][2 * g + 1]);
+        const double rs = frcp(al0 + al1) * c.pi_a0[g];
+        const double cp[2] = {al0 * rs, al1 * rs};
+        const bool cl[2] = {cp[0] < 1e-5, cp[1] < 1e-5};
+        const double cq[2] = {cl[0] ? 1e-5 : cp[0], cl[1] ? 1e-5 : cp[1]};
+        const double total = cq[0] + cq[1];
+        for (int r = w; r < c.R; r += nw) {
+            const long rgi = (long)r * G + g;
+            const bool rgm = c.rg[rgi] != 0;
+            const double pi[2] = {c.pi_ws[rgi * 2], c.pi_ws[rgi * 2 + 1]};
+            double gpi[2] = {c.gpi_ws[rgi * 2], c.gpi_ws[rgi * 2 + 1]};
+            const double lpi[2] = {flog(pi[0]), flog(pi[1])};
+            const double rpi[2] = {frcp(pi[0]), frcp(pi[1])};
+            if (rgm) {
+                const double s = pi[0] + pi[1];
+                const double ls = s == 1.0 ? 0.0 : flog(s);
+                const double rsum = s == 1.0 ? 1.0 : frcp(s);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const double pr = pi[a] * rsum;
+                    const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+                    const double lg = inside ? lpi[a] - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                    double cnt = 0.0;
+                    for (int cc = 0; cc < c.C; ++cc)
+                        cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * 2 + a];
+                    loss -= cnt * lg;
+                    if (inside) gpi[a] -= cnt * rpi[a];
+                }
+                acc[0] += 1.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (rgm) {
+                    acc[3 + a] += lpi[a];
+                    gpi[a] -= (cp[a] - 1.0) * rpi[a];
+                }
+                acc[5 + a] += lpi[a];
+                gpi[a] += (cq[a] - 1.0) * rpi[a];
+            }
+            const double proj = pi[0] * gpi[0] + pi[1] * gpi[1];
+            double path0 = 0.0, path1 = 0.0;
+#pragma unroll 1
+            for (int a = 0; a < 2; ++a) {
+                const bool skip = a ? cl[1] : cl[0];
+                if (skip) continue;
+                const double v = dirichlet_grad_one(a ? pi[1] : pi[0], a ? cq[1] : cq[0], total) *
+                                 ((a ? gpi[1] : gpi[0]) - proj);
+                path0 = a ? path0 : v;
+                path1 = a ? v : path1;
+            }
+            acc[1] += path0;
+            acc[2] += path1;
+        }
+    }
+    double* red = lds;  // [nw][7][64]
+#pragma unroll
+    for (int q = 0; q < 7; ++q) red[((long)w * 7 + q) * 64 + lane] = acc[q];
+    __syncthreads();
+    if (valid) {
+        for (int q = w; q < 7; q += nw) {
+            double s = 0.0;
+            for (int ww = 0; ww < nw; ++ww) s += red[((long)ww * 7 + q) * 64 + lane];
+            const int row = q == 0 ? kPNrg : (q < 3 ? kPPath + (q - 1) : (q < 5 ? kPLp + (q - 3) : kPLq + (q - 5)));
+            c.part[(long)row * G + g] = s;
+        }
+    }
+    double* scratch = lds + (long)nw * 7 * 64;
+    const double tot = block_sum(loss, scratch);
+    if (threadIdx.x == 0) atomicAdd(&c.loss_hist[c.ctrB->slot], tot);
 }
 
 // ------------------------------------------------------------ survival kernels

@@ -113,7 +113,7 @@ __device__ __forceinline__ double digamma(double z) {
 // x >= 0.  Counts are integer-valued, so small x uses the exact product form
 // prod_{i<x}(a + i); everything else is a difference of Stirling series, with
 // both arguments first raised to >= kShift.
-__device__ BEAN_NOINLINE DD lgamma_digamma_diff(double a, double x) {
+__device__ __forceinline__ DD lgamma_digamma_diff_inl(double a, double x) {
     DD out;
     if (x == 0.0) {
         out.d = 0.0;
@@ -154,6 +154,9 @@ __device__ BEAN_NOINLINE DD lgamma_digamma_diff(double a, double x) {
     out.dp = dp;
     return out;
 }
+
+// out-of-line copy for the kernels that call it from many sites
+__device__ BEAN_NOINLINE DD lgamma_digamma_diff(double a, double x) { return lgamma_digamma_diff_inl(a, x); }
 
 // Standard normal cdf / pdf as torch.distributions.Normal computes them
 // (torch/distributions/normal.py:105-113): 0.5 * (1 + erf(u / sqrt 2)).

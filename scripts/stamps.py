@@ -1,0 +1,21 @@
+import os, sys, ctypes
+sys.path.insert(0, ".")
+import numpy as np, torch
+import bean_amd
+from bean_amd import engine, _lib
+from bean_amd.preprocessing.synthetic import make_sorting_variant_screen
+data = make_sorting_variant_screen(50000, 5, seed=20240502).to("cuda:0")
+eng = engine.HipSVI("MixtureNormal", data, num_steps=100)
+eng.run(20, graph_chunk=0); torch.cuda.synchronize()
+n_waves = 2 * 5 * ((50000 + 63) // 64)
+buf = np.zeros(n_waves * 8, dtype=np.uint64)
+lib = _lib.load()
+lib.bean_hip_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+assert lib.bean_hip_debug_stamps(eng._h, buf.ctypes.data, buf.size) == 0
+s = buf.reshape(n_waves, 8).astype(np.int64)
+d = np.diff(s, axis=1)
+names = ["prologue loads+LDS store", "barrier", "pass1 (+pi loads)", "pass2", "d0+final math", "exchange+writes", "block_sum"]
+print("median cycles per segment:")
+for i, n in enumerate(names):
+    print(f"  {n:28s} median {np.median(d[:, i]):9.0f}  mean {d[:, i].mean():9.0f}")
+print("total median", np.median(s[:, 7] - s[:, 0]), "kernel span cycles", s[:, 7].max() - s[:, 0].min())
