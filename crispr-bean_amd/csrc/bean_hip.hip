@@ -375,7 +375,7 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
 // ------------------------------------------------------------------ launches
 static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_blocks) {
     const DevArgs& d = c->d;
-    n_target_blocks = d.wide_targets ? d.T : (d.T + 255) / 256;
+    n_target_blocks = d.wide_targets ? d.T : (int)(((long)d.T * kLanesPerTarget + 255) / 256);
     n_blocks = n_target_blocks + ((d.family == kMixture || d.family == kMultiMixture) ? (d.G + 255) / 256 : 0);
 }
 

@@ -118,6 +118,7 @@ struct DevArgs {
 };
 
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
+constexpr int kLanesPerTarget = 8;  // k_param: lanes sharing one target's Phi table entries
 constexpr int kAMax = 8;
 constexpr int kBMax = 8;  // n_condits <= 8 (bean_hip_create)
 enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2 * kAMax,
@@ -306,6 +307,33 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_targe
     }
 }
 
+// One entry of the per-target Phi tables (a2): P[b, t] = Phi(u_hi) - Phi(u_lo) and its
+// derivatives in mu_t and y_t = log sd_t, for the draw (mu, y) of target t.
+__device__ __forceinline__ void write_phi_entry(const DevArgs& c, int t, int b, double mu, double y) {
+    // NormalModel uses sqrt(sd) as the scale (model.py:92-98)
+    const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
+    const double dsig_dy = c.family == kNormal ? 0.5 * sigma : sigma;
+    const double inv = 1.0 / sigma;
+    const double zh = c.z_hi[b], zl = c.z_lo[b];
+    double ch = 1.0, cl = 0.0, fh = 0.0, fl = 0.0, ufh = 0.0, ufl = 0.0;
+    if (!isinf(zh)) {
+        const double u = (zh - mu) * inv;
+        ch = norm_cdf(u);
+        fh = norm_pdf(u);
+        ufh = u * fh;
+    }
+    if (!isinf(zl)) {
+        const double u = (zl - mu) * inv;
+        cl = norm_cdf(u);
+        fl = norm_pdf(u);
+        ufl = u * fl;
+    }
+    const long o = (long)b * c.T + t;
+    c.tabP[o] = ch - cl;
+    c.tabPmu[o] = -(fh - fl) * inv;
+    c.tabPy[o] = -(ufh - ufl) * inv * dsig_dy;
+}
+
 // -------------------------------------------------------------------- k_param
 // grid = n_target_blocks + n_guide_blocks, 256 threads.
 template <bool FINISH, bool ADAM, bool PREP>
@@ -326,7 +354,7 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
         // ------------------------------------------------ target part
         int t;
         bool active;
-        double gmu = 0.0, gy = 0.0;
+        double gmu = 0.0, gy = 0.0, tab_mu = 0.0, tab_y = 0.0;
         if (c.wide_targets) {
             t = blockIdx.x;
             active = threadIdx.x == 0;
@@ -341,8 +369,8 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                 gy = block_sum(b, scratch);
             }
         } else {
-            t = blockIdx.x * blockDim.x + threadIdx.x;
-            active = t < c.T;
+            t = (blockIdx.x * blockDim.x + threadIdx.x) / kLanesPerTarget;
+            active = t < c.T && (threadIdx.x & (kLanesPerTarget - 1)) == 0;
             if (FINISH && active) {
                 if (c.family == kMultiMixture) {
                     // edit <- alleles containing it (transposed CSR): the backward of
@@ -478,32 +506,27 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                     c.eps_mu_out[t] = eps1;
                     c.eps_sd_out[t] = eps2;
                 }
-                if (c.family != kMultiMixture) {  // tiling tabulates per allele in k_allele
-                // NormalModel uses sqrt(sd) as the scale (model.py:92-98)
-                const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
-                const double dsig_dy = c.family == kNormal ? 0.5 * sigma : sigma;
-                const double inv = 1.0 / sigma;
-                for (int b = 0; b < c.B; ++b) {
-                    const double zh = c.z_hi[b], zl = c.z_lo[b];
-                    double ch = 1.0, cl = 0.0, fh = 0.0, fl = 0.0, ufh = 0.0, ufl = 0.0;
-                    if (!isinf(zh)) {
-                        const double u = (zh - mu) * inv;
-                        ch = norm_cdf(u);
-                        fh = norm_pdf(u);
-                        ufh = u * fh;
-                    }
-                    if (!isinf(zl)) {
-                        const double u = (zl - mu) * inv;
-                        cl = norm_cdf(u);
-                        fl = norm_pdf(u);
-                        ufl = u * fl;
-                    }
-                    const long o = (long)b * c.T + t;
-                    c.tabP[o] = ch - cl;
-                    c.tabPmu[o] = -(fh - fl) * inv;
-                    c.tabPy[o] = -(ufh - ufl) * inv * dsig_dy;
+                tab_mu = mu;
+                tab_y = y;
+            }
+        }
+        // ---- Phi tables: the B entries of a target are spread over the lanes of its group
+        // (thin mode: kLanesPerTarget consecutive lanes; wide mode: the block's first threads)
+        if (PREP && !c.survival && c.family != kMultiMixture) {
+            if (c.wide_targets) {
+                if (threadIdx.x == 0) {
+                    scratch[0] = tab_mu;
+                    scratch[1] = tab_y;
                 }
-                }
+                __syncthreads();
+                if ((int)threadIdx.x < c.B) write_phi_entry(c, t, threadIdx.x, scratch[0], scratch[1]);
+                __syncthreads();
+            } else {
+                const int lead = (threadIdx.x & 63) & ~(kLanesPerTarget - 1);
+                const double mu = __shfl(tab_mu, lead, 64), y = __shfl(tab_y, lead, 64);
+                const int j = threadIdx.x & (kLanesPerTarget - 1);
+                if (t < c.T)
+                    for (int b = j; b < c.B; b += kLanesPerTarget) write_phi_entry(c, t, b, mu, y);
             }
         }
     } else if (c.family == kMultiMixture) {
