@@ -1,0 +1,123 @@
+"""``bean run``: screen -> tensors -> (negative-control fit) -> main fit -> tables.
+
+Follows ``bean/cli/run.py:66-311`` step for step for the variant library design;
+every step delegates to the module that mirrors the reference's.  The fit itself
+runs on the MI355X through ``run_inference`` (``libbean_hip``).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import pickle as pkl
+from copy import deepcopy
+from functools import partial
+
+import numpy as np
+
+from ..framework import read_h5ad
+from ..model.readwrite import write_result_table
+from ..model.run import (_check_prior_params, _get_guide_info, _get_guide_target_info, check_args,
+                         identify_model_guide, identify_negctrl_model_guide, run_inference)
+from ..preprocessing.screen_data import DATACLASS_DICT
+from ..preprocessing.utils import prepare_bdata
+
+logging.basicConfig(level=logging.INFO, format="%(levelname)-5s @ %(asctime)s:\n\t %(message)s \n",
+                    datefmt="%a, %d %b %Y %H:%M:%S")
+logger = logging.getLogger("bean_run")
+info, warn = logger.info, logger.warning
+
+
+def main(args, return_data=False):
+    print(r"""
+    _ _
+  /  \ '\                       
+  |   \  \      _ _ _  _ _ ___  
+   \   \  |    | '_| || | ' \   
+    `.__|/     |_|  \_,_|_||_|  [crispr-bean_amd / MI355X]
+    """)
+    print("bean-run: Run model to identify targeted variants and their impact.")
+    bdata = read_h5ad(args.bdata_path)
+    args, bdata = check_args(args, bdata)
+    prefix = args.outdir + "/bean_run_result." + os.path.basename(args.bdata_path).rsplit(".h5ad", 1)[0]
+    os.makedirs(prefix, exist_ok=True)
+    handler = logging.FileHandler(f"{prefix}/bean_run.log")
+    handler.setLevel(logging.INFO)
+    logger.addHandler(handler)
+    model_label, model, guide = identify_model_guide(args)
+    info("Done loading data. Preprocessing...")
+    bdata = prepare_bdata(bdata, args, warn, prefix)
+    is_neg = lambda scr: np.where(scr.guides[args.negctrl_col].map(lambda v: str(v).lower())  # noqa: E731
+                                  == args.negctrl_col_value.lower())[0]
+    negctrl_idx = is_neg(bdata) if args.negctrl_col in bdata.guides.columns else np.zeros(0, dtype=int)
+    ndata = DATACLASS_DICT[args.selection][model_label](
+        bdata,
+        repguide_mask=args.repguide_mask,
+        sample_mask_column=args.sample_mask_col,
+        accessibility_col=args.acc_col,
+        accessibility_bw_path=args.acc_bw_path,
+        condition_column=args.condition_col,
+        time_column=args.time_col,
+        control_condition=args.control_condition,
+        lower_quantile_column=args.sorting_bin_lower_quantile_col,
+        upper_quantile_column=args.sorting_bin_upper_quantile_col,
+        target_col=args.target_col,
+        shrink_alpha=args.shrink_alpha,
+        popt=args.popt,
+        use_bcmatch=(not args.ignore_bcmatch),
+        negctrl_guide_idx=negctrl_idx,
+    )
+    if args.save_raw:
+        pkl.dump(bdata, open(f"{prefix}/ndata.pkl", "wb"))
+    if return_data:
+        return ndata
+    if args.library_design != "variant":
+        raise NotImplementedError("`bean run ... tiling` from an .h5ad is not implemented yet")
+    adj_negctrl_idx = None
+    control = args.control_condition.split(",")[0]
+    if not args.uniform_edit and "edit_rate" not in ndata.screen.guides.columns:
+        ndata.screen.get_guide_edit_rate(unsorted_condition_label=control, condition_col=args.condition_col)
+    target_info_df = _get_guide_target_info(ndata.screen, args, cols_include=[args.negctrl_col])
+    if args.adjust_confidence_by_negative_control:
+        adj_negctrl_idx = np.where(target_info_df[args.negctrl_col].map(lambda v: str(v).lower())
+                                   == args.negctrl_col_value.lower())[0]
+    guide_info_df = _get_guide_info(ndata.screen, args, guide_lfc_pseudocount=args.guide_lfc_pseudocount)
+    if args.prior_params is not None:
+        model = partial(model, prior_params=_check_prior_params(args.prior_params, ndata))
+
+    info(f"Running inference for {model_label}...")
+    save_dict = dict()
+    param_history_dict_negctrl = None
+    if args.fit_negctrl:
+        negctrl_model, negctrl_guide = identify_negctrl_model_guide(args, "X_bcmatch" in bdata.layers)
+        idx = is_neg(ndata.screen)
+        info(f"Using {len(idx)} negative control elements to adjust phenotypic effect sizes...")
+        ndata_negctrl = ndata[idx]
+        param_history_dict_negctrl, save_dict["negctrl"] = deepcopy(
+            run_inference(negctrl_model, negctrl_guide, ndata_negctrl, num_steps=args.n_iter))
+        if args.selection == "survival":
+            model = partial(model, mu_negctrl=(param_history_dict_negctrl["mu_loc"].detach().mean(),
+                                               param_history_dict_negctrl["mu_scale"].detach().mean()))
+    param_history_dict, save_dict_model = deepcopy(run_inference(model, guide, ndata, num_steps=args.n_iter))
+    save_dict.update(save_dict_model)
+    outfile = f"{prefix}/bean_element[sgRNA]_result.{model_label}{args.result_suffix}.csv"
+    info(f"Done running inference. Writing result at {outfile}...")
+    if args.save_raw:
+        with open(f"{prefix}/{model_label}.result{args.result_suffix}.pkl", "wb") as handle:
+            pkl.dump(save_dict, handle)
+    write_result_table(
+        target_info_df,
+        guide_info_df,
+        param_history_dict,
+        negctrl_params=param_history_dict_negctrl,
+        model_label=model_label,
+        prefix=f"{prefix}/",
+        suffix=args.result_suffix,
+        guide_acc=(ndata.guide_accessibility.cpu().numpy() if ndata.guide_accessibility is not None else None),
+        adjust_confidence_by_negative_control=args.adjust_confidence_by_negative_control,
+        adjust_confidence_negatives=adj_negctrl_idx,
+        sd_is_fitted=(args.selection == "sorting"),
+        sample_covariates=None,
+        is_survival_screen=(args.selection == "survival"),
+    )
+    info("Done!")
+    return prefix

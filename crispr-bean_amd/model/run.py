@@ -216,3 +216,193 @@ def identify_negctrl_model_guide(args, data_has_bcmatch):
     negctrl_model = partial(m.ControlNormalModel, use_bcmatch=(not args.ignore_bcmatch and data_has_bcmatch))
     negctrl_guide = partial(m.ControlNormalGuide, use_bcmatch=(not args.ignore_bcmatch and data_has_bcmatch))
     return negctrl_model, negctrl_guide
+
+
+# --------------------------------------------------------------------------
+# argument validation and table helpers of `bean run`
+# (bean/model/run.py:39-178 check_args, 181-216 _get_guide_target_info,
+#  219-308 _get_guide_info, 480-542 _check_prior_params)
+# --------------------------------------------------------------------------
+import os  # noqa: E402
+
+import numpy as np  # noqa: E402
+import pandas as pd  # noqa: E402
+
+warn = logger.warning
+
+
+def check_args(args, bdata):
+    """Validate the parsed arguments against the screen and derive ``args.popt``,
+    ``args.adjust_confidence_by_negative_control`` and a default ``repguide_mask``."""
+    g, s = bdata.guides, bdata.samples
+    if args.scale_by_acc:
+        if args.acc_col is None and args.acc_bw_path is None:
+            raise ValueError(
+                "--scale-by-acc not accompanied by --acc-col nor --acc-bw-path to use. Pass either one.")
+        if args.acc_col is not None and args.acc_bw_path is not None:
+            warn("Both --acc-col and --acc-bw-path is specified. --acc-bw-path is ignored.")
+            args.acc_bw_path = None
+        elif args.acc_bw_path is not None and "genomic_pos" not in g.columns:
+            if "start_pos" not in g.columns:
+                raise ValueError("Guides' positions not provided in ReporterScreen.guides['start_pos']. "
+                                 "Please check the input.")
+            g["genomic_pos"] = g["start_pos"]
+            warn("'genomic_pos' not in ReporterScreen.guides.columns, using 'start_pos' to retrieve "
+                 "accessibility from the bigWig file.")
+    if args.outdir is None:
+        args.outdir = os.path.dirname(args.bdata_path)
+    if args.fit_negctrl and args.negctrl_col not in g.columns:
+        raise ValueError(f"--negctrl-col argument '{args.negctrl_col}' not in ReporterScreen.guides.columns "
+                         f"{g.columns}. Please check the input or do not provide --fit-negctrl flag if you don't "
+                         "have the negative controls.")
+    if args.selection == "sorting":
+        for flag, col in (("--sorting-bin-upper-quantile-col", args.sorting_bin_upper_quantile_col),
+                          ("--sorting-bin-lower-quantile-col", args.sorting_bin_lower_quantile_col)):
+            if col not in s.columns:
+                raise ValueError(f"{flag} argument '{col}' not in ReporterScreen.samples.columns {s.columns}. "
+                                 "Please check the input.")
+    elif args.selection == "survival":
+        if args.time_col not in s.columns:
+            raise ValueError(f"--time-col argument '{args.time_col}' not in ReporterScreen.samples.columns "
+                             f"{s.columns}. Please check the input.")
+        try:
+            pd.to_numeric(s[args.time_col])
+        except ValueError as exc:
+            raise ValueError(f"ReporterScreen.samples['{args.time_col}'] provided is not numeric "
+                             f"({s[args.time_col]}). Please check the input .h5ad file or your --time-col "
+                             "argument.") from exc
+    if args.library_design == "variant":
+        args.adjust_confidence_by_negative_control = args.fit_negctrl and (
+            not args.dont_adjust_confidence_by_negative_control)
+    elif args.library_design == "tiling":
+        args.adjust_confidence_by_negative_control = not args.dont_adjust_confidence_by_negative_control
+        if args.allele_df_key is None:
+            key, n = "allele_counts", len(bdata.uns["allele_counts"])
+            for k, df in bdata.uns.items():
+                if "allele_counts" in k and isinstance(df, pd.DataFrame) and len(df) < n:
+                    key, n = k, len(df)
+            warn(f"--allele-df-key not provided for tiling screen. Using the most filtered allele counts with "
+                 f"{n} alleles stored in '{key}'.")
+            args.allele_df_key = key
+        elif args.allele_df_key not in bdata.uns:
+            raise ValueError(f"--allele-df-key '{args.allele_df_key}' not in ReporterScreen.uns. Check your input.")
+    else:
+        raise ValueError("Invalid library_design provided. Select either 'variant' or 'tiling'.")
+    if args.fit_negctrl:
+        n_neg = int((g[args.negctrl_col].map(lambda v: str(v).lower()) == args.negctrl_col_value.lower()).sum())
+        if not n_neg >= 10:
+            raise ValueError(f"Not enough negative control guide in the input data: {n_neg}. "
+                             "Please check your input arguments.")
+    if args.repguide_mask is not None and args.repguide_mask not in bdata.uns.keys():
+        bdata.uns[args.repguide_mask] = pd.DataFrame(
+            1, index=g.index, columns=pd.unique(s[args.replicate_col]))
+        warn(f"{args.bdata_path} does not have replicate x guide outlier mask. All guides are included in analysis.")
+    if args.sample_mask_col == "":
+        args.sample_mask_col = None
+    if args.sample_mask_col is not None and args.sample_mask_col not in s.columns.tolist():
+        raise ValueError(f"{args.bdata_path} does not have specified sample mask column "
+                         f"`{args.sample_mask_col}` in .samples")
+    if args.condition_col not in s.columns:
+        raise ValueError(f"Condition column `{args.condition_col}` set by `--condition-col` not in "
+                         f"ReporterScreen.samples.columns:{s.columns}. Check your input.")
+    if args.selection == "survival" and args.condition_col == args.time_col:
+        raise ValueError(f"Invalid to have the same `--condition-col` ({args.condition_col}) and `--time-col` "
+                         f"({args.time_col}).")
+    present = s[args.condition_col].astype(str).tolist()
+    for c in args.control_condition.split(","):
+        if c not in present:
+            raise ValueError(f"No sample has control label `{args.control_condition}` (set by "
+                             f"`--control-condition`)  in ReporterScreen.samples[{args.condition_col}]: "
+                             f"{s[args.condition_col]}. Check your input.")
+    if args.replicate_col not in s.columns:
+        raise ValueError(f"Condition column set by `--replicate-col` {args.replicate_col} not in "
+                         f"ReporterScreen.samples.columns:{s.columns}. Check your input.")
+    if args.control_guide_tag is not None:
+        if args.library_design == "variant":
+            raise ValueError("`--control-guide-tag` is not used for the variant mode. Make sure you provide the "
+                             "separate `target` column for negative control guide that targets different negative "
+                             "control variant.")
+        if not g.index.map(lambda n: args.control_guide_tag in n).any():
+            raise ValueError(f"Negative control guide label `{args.control_guide_tag}` provided by "
+                             "`--control-guide-tag` doesn't appear in any of the guide names. Check your input.")
+    args.popt = None
+    if args.alpha_if_overdispersion_fitting_fails is not None:
+        try:
+            b0, b1 = args.alpha_if_overdispersion_fitting_fails.split(",")
+            args.popt = (float(b0), float(b1))
+        except (TypeError, ValueError):
+            raise ValueError(f"Input --alpha-if-overdispersion-fitting-fails "
+                             f"`{args.alpha_if_overdispersion_fitting_fails}` is malformatted! "
+                             "Provide [float].[float] format.")
+    return args, bdata
+
+
+def _get_guide_target_info(bdata, args, cols_include=()):
+    """One row per target: the guide columns that are constant within a target
+    (``target_*``) plus ``cols_include``, ``n_guides`` and the editing-rate summary."""
+    guides = bdata.guides.copy()
+    tcol = args.target_col
+    n_targets = guides[tcol].nunique()
+    keep = [c for c in guides.columns
+            if c != tcol and (c in cols_include or (c.startswith("target_")
+                                                   and len(guides[[tcol, c]].drop_duplicates()) == n_targets))]
+    info_df = guides[[tcol] + keep].drop_duplicates().set_index(tcol, drop=True)
+    info_df["n_guides"] = guides.groupby("target", observed=True).size()  # literal "target", as the reference
+    if "edit_rate" in guides.columns:
+        er = guides[[tcol, "edit_rate"]].groupby(tcol, sort=False, observed=True).agg({"edit_rate": ["mean", "std"]})
+        er.columns = ["edit_rate_mean", "edit_rate_std"]
+        info_df = info_df.join(er)
+    return info_df
+
+
+def _get_guide_info(bdata, args, guide_lfc_pseudocount: int = 5):
+    """sgRNA table: editing rate and per-replicate log fold change between the extreme
+    sorting bins (sorting) or the latest and earliest timepoints (survival)."""
+    s = bdata.samples
+    kw = dict(rep_col=args.replicate_col, compare_col=args.condition_col, pseudocount=guide_lfc_pseudocount)
+    if args.selection == "sorting":
+        uq, lq = args.sorting_bin_upper_quantile_col, args.sorting_bin_lower_quantile_col
+        cond = s[[args.condition_col, lq, uq]].drop_duplicates()
+        top = cond.loc[cond[uq] == cond[uq].max()]
+        highest = top.loc[top[lq] == top[lq].max(), args.condition_col].item()
+        bottom = cond.loc[cond[uq] == cond[uq].min()]
+        lowest = bottom.loc[bottom[lq] == bottom[lq].min(), args.condition_col].item()
+        lfc = bdata.log_fold_change_reps(highest, lowest, **kw)
+    else:
+        cond = s[[args.condition_col, args.time_col]].drop_duplicates()
+        t = cond[args.time_col].astype(float)
+        latest = cond.loc[t == t.max(), args.condition_col].item()
+        earliest = cond.loc[t == t.min(), args.condition_col].item()
+        lfc = bdata.log_fold_change_reps(latest, earliest, **kw)
+        if args.plasmid_condition is not None:
+            sel = cond.loc[cond[args.condition_col].astype(str) != args.plasmid_condition]
+            ts = sel[args.time_col].astype(float)
+            first_sel = sel.loc[ts == ts.min(), args.condition_col].item()
+            if first_sel != earliest:
+                lfc = pd.concat([lfc, bdata.log_fold_change_reps(latest, first_sel, **kw)], axis=1)
+    if "edit_rate" in bdata.guides.columns:
+        return pd.concat([bdata.guides[["edit_rate"]], lfc], axis=1)
+    return lfc
+
+
+def _check_prior_params(param_path: str, ndata):
+    """Load ``--prior-params`` and bring its entries to shape ``(n_targets, 1)``."""
+    if not os.path.exists(param_path):
+        raise ValueError(f"Specified prior parameter file --prior-params {param_path} is not found.")
+    with open(param_path, "rb") as f:
+        prior = pkl.load(f)
+    T = ndata.n_targets
+    keys = ("sd_loc", "sd_scale", "mu_loc", "mu_scale") if ndata.selection == "sorting" else ("mu_loc", "mu_scale")
+    for k in keys:
+        if k not in prior or not hasattr(prior[k], "__len__"):
+            continue
+        if tuple(prior[k].shape) == (T,):
+            prior[k] = prior[k].reshape(-1, 1)
+        elif tuple(prior[k].shape) != (T, 1):
+            raise ValueError(f"Specified prior parameter --prior-params {param_path}: prior_params['{k}'].shape "
+                             f"{tuple(prior[k].shape)} does not match the number of target variants {(T, 1)}.")
+    if ndata.selection != "sorting" and "initial_abundance" in prior:
+        if tuple(prior["initial_abundance"].shape) != (T,):
+            raise ValueError(f"Specified prior parameter --prior-params {param_path}: "
+                             "prior_params['initial_abundance'].shape does not match.")
+    return prior
