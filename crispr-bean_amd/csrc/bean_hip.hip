@@ -33,7 +33,8 @@ struct bean_hip_ctx {
     uint64_t workspace_bytes;
     uint64_t loss_capacity;
     bool prepared;
-    bool fused_guide;  // default; BEAN_HIP_SPLIT_GUIDE=1 selects the sample / lik / pi-terms launches
+    bool fused_guide;  // false: BEAN_HIP_GUIDE=split selects the sample / lik / pi-terms launches
+    bool wave_guide;   // sorting variant families, default: one wave per (guide tile, replicate)
     // graph cache
     hipGraphExec_t graph_exec;
     int graph_chunk;
@@ -205,8 +206,11 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->shape = *s;
     c->prepared = false;
     {
+        // diagnostic A/B switch for the sorting variant families: the split (three launch) form
         const char* env = getenv("BEAN_HIP_SPLIT_GUIDE");
-        c->fused_guide = !(env && env[0] == '1');
+        const char* mode = getenv("BEAN_HIP_GUIDE");
+        c->fused_guide = !((env && env[0] == '1') || (mode && !strcmp(mode, "split")));
+        c->wave_guide = c->fused_guide;
     }
     c->graph_exec = nullptr;
     c->graph_chunk = 0;
@@ -236,7 +240,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const uint64_t n_surv = surv_mix ? 2 * G + Rr * G + n_gblk * (Rr + 1) + (Rr + 1) : 0;
     const bool split_ok = !is_survival(*s) && !is_tiling(*s);
     const bool use_split = split_ok && !c->fused_guide;
-    const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G : 0;
+    c->wave_guide = c->wave_guide && split_ok;
+    const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G
+                                       : (c->wave_guide ? (uint64_t)(kNumPart + 2) * Rr * G : 0);
 #ifdef BEAN_STAMP
     const uint64_t n_dbg = 8 * 2 * Rr * ((G + 63) / 64);
 #else
@@ -272,6 +278,10 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.loss_const = w; w += 1;
     if (n_dbg) {
         d.dbg = (unsigned long long*)w; w += n_dbg;
+    }
+    if (c->wave_guide) {
+        d.wrow = w; w += (uint64_t)kNumPart * Rr * G;
+        d.nobs = w; w += 2 * Rr * G;
     }
     if (use_split) {
         d.rrow = w; w += 3 * Rr * G;
@@ -404,13 +414,6 @@ static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 
             hipLaunchKernelGGL((k_guide_tiling<B, true>), grid, block, tl, stream, d);
         else
             hipLaunchKernelGGL((k_guide_tiling<B, false>), grid, block, tl, stream, d);
-    } else if (d.family == kMixture) {
-        if (d.flags & kAcc)
-            hipLaunchKernelGGL((k_guide<B, kMixture, true>), grid, block, lds, stream, d);
-        else
-            hipLaunchKernelGGL((k_guide<B, kMixture, false>), grid, block, lds, stream, d);
-    } else {
-        hipLaunchKernelGGL((k_guide<B, kNormal, false>), grid, block, lds, stream, d);
     }
 }
 
@@ -458,10 +461,41 @@ static void launch_guide_split(bean_hip_ctx* c, hipStream_t stream) {
     }
 }
 
+// sorting variant families, one wave per (guide tile, replicate)
+static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
+    const DevArgs& d = c->d;
+    const dim3 grid((d.G + 63) / 64, d.R), block(64);
+    const size_t lds = (size_t)3 * d.B * 64 * sizeof(double);
+    const bool prof = c->profile && c->ev.size() < 8192;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, stream);
+    }
+    if (d.family == kMixture) {
+        if (d.flags & kAcc)
+            hipLaunchKernelGGL((k_guide_wave<kMixture, true>), grid, block, lds, stream, d);
+        else
+            hipLaunchKernelGGL((k_guide_wave<kMixture, false>), grid, block, lds, stream, d);
+    } else {
+        hipLaunchKernelGGL((k_guide_wave<kNormal, false>), grid, block, lds, stream, d);
+    }
+    if (prof) {
+        (void)hipEventRecord(e1, stream);
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+    }
+}
+
 static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     if (!c->fused_guide && !d.survival && d.family != kMultiMixture) {
         launch_guide_split(c, stream);
+        return;
+    }
+    if (c->wave_guide) {
+        launch_guide_wave(c, stream);
         return;
     }
     const int nw = waves_per_block(c);
@@ -602,7 +636,8 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
 extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
     if (c && c->d.survival) return "k_guide_survival";
     if (c && c->d.family == kMultiMixture) return "k_guide_tiling";
-    return (c && c->fused_guide) ? "k_guide" : "k_lik";
+    if (c && c->wave_guide) return "k_guide_wave";
+    return "k_lik";
 }
 
 extern "C" int bean_hip_set_profile(bean_hip_ctx* c, int32_t enable) {

@@ -10,13 +10,15 @@
 //               edited-component bin probabilities P[b, t] and their
 //               derivatives (the Normal-CDF work depends only on the target).
 //
-//   k_guide  (per (rep, guide), heavy: >95 % of the time)
-//       one wave = 64 consecutive guides of one replicate (coalesced reads of
-//       the (R, B, G) count tensors); the waves of a block cover the R
-//       replicates of the same 64 guides, so the reduction over replicates is
-//       an LDS reduction.  Per thread: Dirichlet draw, mixture, both
-//       Dirichlet-Multinomial likelihoods with analytic gradients, Multinomial
-//       on control allele counts, implicit-reparameterisation gradient.
+//   k_guide_wave  (per (rep, guide), heavy: ~80 % of the time)
+//       one single-wave workgroup = 64 consecutive guides of one replicate
+//       (coalesced reads of the (R, B, G) count tensors).  Per thread:
+//       Dirichlet draw, mixture, both Dirichlet-Multinomial likelihoods with
+//       analytic gradients, Multinomial on control allele counts, implicit-
+//       reparameterisation gradient.  Per-replicate rows go to wrow; k_param
+//       sums them over replicates in fixed order.
+//   (survival and tiling screens: k_guide_survival / k_allele + k_guide_tiling,
+//    blocks of R waves with an LDS reduction over replicates.)
 //
 // Reference semantics: bean/model/model.py (models/guides), bean/model/utils.py
 // (get_alpha, get_std_normal_prob), SURVEY.md Appendix A/D for the algebra.
@@ -96,6 +98,8 @@ struct DevArgs {
     double *pi_ws, *gpi_ws;            // (R, G, 2) split-kernel hand-off: draws, d nll / d pi
     unsigned long long* dbg;           // diagnostic builds (-DBEAN_STAMP): per-wave cycle stamps
     double* rrow;                      // (3, R, G) split form: d/dmu_t, d/dy_t, d/dnoise per (rep, guide)
+    double* wrow;                      // (kNumPart, R, G) wave form: every per-guide row, per replicate
+    double* nobs;                      // (2, R, G) wave form: count totals of X / X_bcmatch, -1 where masked
     StepCtr *ctrA, *ctrB;
     // tiling (MultiMixtureNormal): CSR allele slot -> edits and its transpose
     int E;
@@ -124,6 +128,13 @@ constexpr int kBMax = 8;  // n_condits <= 8 (bean_hip_create)
 enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2 * kAMax,
              kTGsig = 2 + 2 * kAMax + (kAMax - 1), kTNumPart = 2 + 2 * kAMax + 2 * (kAMax - 1) };
 
+// Wave-uniform read of kernel-invariant data through the scalar cache (s_load): the constant
+// address space tells the compiler that nothing in this launch writes the location.
+__device__ __forceinline__ double uniform_ld(const double* p, int i) {
+    typedef const double __attribute__((address_space(4))) * cptr;
+    return ((cptr)(unsigned long long)p)[i];
+}
+
 // ---------------------------------------------------------------- reductions
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -146,8 +157,14 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 
 // likelihood-gradient row q (kPGmu, kPGy or kPGnoise) of guide g: the fused kernels reduce
 // over replicates in LDS, the split form leaves one value per replicate (fixed-order sum)
+__device__ __forceinline__ double part_row(const DevArgs& c, int q, int g) {
+    if (!c.wrow) return c.part[(long)q * c.G + g];
+    double s = 0.0;
+    for (int r = 0; r < c.R; ++r) s += c.wrow[((long)q * c.R + r) * c.G + g];
+    return s;
+}
 __device__ __forceinline__ double lik_row(const DevArgs& c, int q, int g) {
-    if (!c.rrow) return c.part[(long)q * c.G + g];
+    if (!c.rrow) return part_row(c, q, g);
     double s = 0.0;
     for (int r = 0; r < c.R; ++r) s += c.rrow[((long)q * c.R + r) * c.G + g];
     return s;
@@ -559,16 +576,16 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                     lgamma_digamma(cq[0], lg_q[0], dg_q[0]);
                     lgamma_digamma(cq[1], lg_q[1], dg_q[1]);
                 }
-                const double nrg = c.part[(long)kPNrg * c.G + g];
+                const double nrg = part_row(c, kPNrg, g);
                 const double Rf = (double)c.R;
                 double gc[2];
                 double lp = nrg * (lgS_p - lg_p[0] - lg_p[1]);
                 double lq = Rf * (lgS_q - lg_q[0] - lg_q[1]);
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    const double Lp = c.part[(long)(kPLp + a) * c.G + g];
-                    const double Lq = c.part[(long)(kPLq + a) * c.G + g];
-                    const double gpath = c.part[(long)(kPPath + a) * c.G + g];
+                    const double Lp = part_row(c, kPLp + a, g);
+                    const double Lq = part_row(c, kPLq + a, g);
+                    const double gpath = part_row(c, kPPath + a, g);
                     lp += (cp[a] - 1.0) * Lp;
                     lq += (cq[a] - 1.0) * Lq;
                     const double g_cp = -(Lp + nrg * (dgS_p - dg_p[a]));
@@ -727,219 +744,276 @@ __device__ __forceinline__ double dirmult_nll(const float* __restrict__ xp, long
     return nll;
 }
 
-// blockDim.x = 64 * nw (nw waves cover the replicates of 64 guides); dynamic
-// LDS = nw * kNumPart * 64 doubles + 16.
 #ifndef BEAN_GUIDE_WAVES_PER_EU
 #define BEAN_GUIDE_WAVES_PER_EU 2
 #endif
-template <int B, int FAM, bool ACC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BEAN_GUIDE_WAVES_PER_EU)))
-void k_guide(DevArgs c) {
-    extern __shared__ double lds[];
-    constexpr bool MIX = FAM == kMixture;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;
-    const int g = blockIdx.x * 64 + lane;
-    const bool valid = g < c.G;
-    const StepCtr ctr = *c.ctrB;
-    const int G = c.G, T = c.T;
 
-    double acc[kNumPart];
-#pragma unroll
-    for (int q = 0; q < kNumPart; ++q) acc[q] = 0.0;
+// ------------------------------------------------------------ k_guide_wave (sorting, variant)
+// One single-wave workgroup per (64-guide tile, replicate): the whole per-(rep, guide) chain
+// (Dirichlet draw, both Dirichlet-Multinomial terms, pi terms, implicit
+// reparameterisation gradient) with the likelihood written as rolled loops over the bins
+// whose state is a handful of scalars (the d nll / d e[b] vector is never materialised:
+// everything downstream is linear in it, see k_lik).  No LDS, no barrier; table entries and
+// counts of bin b + 1 are fetched while bin b is computed.  The per-replicate rows go to
+// wrow[(q, r, g)]; k_param sums them over r in fixed order (part_row).
+template <int FAM, bool ACC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void k_guide_wave(DevArgs c) {
+    constexpr bool MIX = FAM == kMixture;
+    extern __shared__ double tabs[];  // [3][B][64]: P, dP/dmu, dP/dy columns of the tile's targets
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x * 64 + lane;
+    const int r = blockIdx.y;
+    const bool valid = g < c.G;
+    const int G = c.G, T = c.T, B = c.B;
+    const StepCtr ctr = *c.ctrB;
     double loss = 0.0;
+#ifdef BEAN_STAMP
+    const long wave_gid = (long)blockIdx.y * gridDim.x + blockIdx.x;
+#endif
+#ifdef BEAN_STAMP
+    {   // slot 0: start time with the XCD id in the low 3 bits (s_memtime counters are per XCD)
+        unsigned long long t_;
+        unsigned xcc_;
+        asm volatile("s_memtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(xcc_)::"memory");
+        if (lane == 0) c.dbg[wave_gid * 8] = (t_ & ~7ull) | (xcc_ & 7u);
+    }
+#endif
+
+    // Guides are target-sorted, so the tile's targets are one contiguous range of at most 64:
+    // lane i stages the 3 B table entries of target t0 + i (coalesced); every lane then reads its
+    // own target's column from LDS.  Indices are clamped instead of predicated so that all loads
+    // are in flight before the first wait.
+    const int g_first = blockIdx.x * 64;
+    const int g_last = (g_first + 63 < G ? g_first + 63 : G - 1);
+    const int t0 = __builtin_amdgcn_readfirstlane(c.g2t[g_first]);
+    const int nt = __builtin_amdgcn_readfirstlane(c.g2t[g_last]) - t0 + 1;
+    if (lane < nt) {
+        double tv[3][kBMax];
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) {
+            const long o = (long)(b < B ? b : B - 1) * T + t0 + lane;
+            tv[0][b] = c.tabP[o];
+            tv[1][b] = c.tabPmu[o];
+            tv[2][b] = c.tabPy[o];
+        }
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) {
+            const int bb = b < B ? b : B - 1;
+            tabs[(0 * B + bb) * 64 + lane] = tv[0][b];
+            tabs[(1 * B + bb) * 64 + lane] = tv[1][b];
+            tabs[(2 * B + bb) * 64 + lane] = tv[2][b];
+        }
+    }
+    __syncthreads();
 
     if (valid) {
-        const int t = c.g2t[g];
+        const long rgi = (long)r * G + g;
+        const long RG = (long)c.R * G;
+        const double* tp = tabs + (c.g2t[g] - t0);  // this guide's column: tp[(which * B + b) * 64]
+        const bool rgm = c.rg[rgi] != 0;
         const bool use_bc = (c.flags & kUseBc) != 0;
-        double cp[2] = {1.0, 1.0}, cq[2] = {1.0, 1.0};
-        bool cl[2] = {false, false};
-        double kacc = 0.0, lpn = 0.0;
+        double cp0 = 1.0, cp1 = 1.0, cq0 = 1.0, cq1 = 1.0;
+        bool cl0 = false, cl1 = false;
+        double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0;
+        double dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
         if (MIX) {
             const double al0 = (double)expf(c.p[4][2 * g]), al1 = (double)expf(c.p[4][2 * g + 1]);
             const double rs = frcp(al0 + al1) * c.pi_a0[g];
-            cp[0] = al0 * rs;
-            cp[1] = al1 * rs;
-            cl[0] = cp[0] < 1e-5;
-            cl[1] = cp[1] < 1e-5;
-            cq[0] = cl[0] ? 1e-5 : cp[0];
-            cq[1] = cl[1] ? 1e-5 : cp[1];
+            cp0 = al0 * rs;
+            cp1 = al1 * rs;
+            cl0 = cp0 < 1e-5;
+            cl1 = cp1 < 1e-5;
+            cq0 = cl0 ? 1e-5 : cp0;
+            cq1 = cl1 ? 1e-5 : cp1;
+            if (c.pi_in) {
+                pi0 = c.pi_in[rgi * 2];
+                pi1 = c.pi_in[rgi * 2 + 1];
+            } else {
+                BEAN_STAMP_AT(1);
+                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+                const GammaPair gp = sample_gamma_pair(cq0, cq1, rng);
+                const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
+                const double rs2 = frcp(gm0 + gm1);
+                pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
+                pi1 = fmin(fmax(gm1 * rs2, kDblMin), kOneMinus);
+            }
+            if (c.flags & kDumpPi) {
+                c.pi_out[rgi * 2] = pi0;
+                c.pi_out[rgi * 2 + 1] = pi1;
+            }
+            pe1 = pi1;
             if (ACC) {
-                kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
-                lpn = c.lpn[g];
+                // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
+                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double s1 = pi1 * kacc;
+                const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+                const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+                const double l = flog(p1c * frcp(1.0 - p1c)) + c.lpn[g];
+                const double el = exp(l);
+                const double pn = el * frcp(1.0 + el);
+                const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+                pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+                dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
+                dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
             }
         }
-        for (int r = w; r < c.R; r += nw) {
-            const bool rgm = c.rg[(long)r * G + g] != 0;
-            double pi[2] = {0.0, 1.0}, pe1 = 1.0;  // pe1: effective weight of the edited component
-            double dpe1_dpi1 = 0.0;                // ACC: d pe1 / d pi1 (0 when clamped)
-            double dpe1_dl = 0.0;                  // ACC: d pe1 / d logit noise
-            if (MIX) {
-#ifdef BEAN_SKIP_SAMPLING
-                if (true) {
-#else
-                if (c.pi_in) {
-#endif
-                    pi[0] = c.pi_in[((long)r * G + g) * 2];
-                    pi[1] = c.pi_in[((long)r * G + g) * 2 + 1];
-                } else {
-                    Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
-                    const GammaPair gp = sample_gamma_pair(cq[0], cq[1], rng);
-                    const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
-                    const double rs = frcp(gm0 + gm1);
-                    pi[0] = fmin(fmax(gm0 * rs, kDblMin), kOneMinus);
-                    pi[1] = fmin(fmax(gm1 * rs, kDblMin), kOneMinus);
-                }
-                if (c.flags & kDumpPi) {
-                    c.pi_out[((long)r * G + g) * 2] = pi[0];
-                    c.pi_out[((long)r * G + g) * 2 + 1] = pi[1];
-                }
-                pe1 = pi[1];
-                if (ACC) {
-                    // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
-                    const double s1 = pi[1] * kacc;
-                    const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
-                    const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
-                    const double l = flog(p1c * frcp(1.0 - p1c)) + lpn;
-                    const double el = exp(l);
-                    const double pn = el * frcp(1.0 + el);
-                    const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
-                    pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
-                    dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
-                    dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
-                }
-            }
-            double e[B], ge[B];
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                const double p1 = c.tabP[(long)b * T + t];
-                e[b] = MIX ? (ACC ? (1.0 - pe1) * c.P0[b] + pe1 * p1 : pi[0] * c.P0[b] + pi[1] * p1) : p1;
-                ge[b] = 0.0;
-            }
-            double nll = 0.0;
-            const double* sm = c.smask + r * B;
+        const double w0 = MIX ? (ACC ? 1.0 - pe1 : pi0) : 0.0;  // weight of the wild-type component
+        const double w1 = MIX ? (ACC ? pe1 : pi1) : 1.0;        // weight of the edited component
+        const double* sm = c.smask + r * B;
+        const double epsB = kEps / (double)B;
+        double a_mu = 0.0, a_y = 0.0, g0 = 0.0, g1 = 0.0, nll = 0.0;
 #pragma unroll 1
-            for (int lik = 0; lik < 2; ++lik) {
-                if (lik == 1 && !use_bc) break;
-                const float* xp = (lik ? c.Xbc : c.X) + (long)r * B * G + g;
-                float n = 0.f;
+        for (int lik = 0; lik < 2; ++lik) {
+            if (lik == 1 && !use_bc) break;
+            if (lik == 0) BEAN_STAMP_AT(2);
+            else BEAN_STAMP_AT(5);
+            const float* xp = (lik ? c.Xbc : c.X) + (long)r * B * G + g;
+            const double* sf = (lik ? c.sf_bc : c.sf) + r * B;
+            // n = sum x_b is data: k_prepare leaves it in nobs (-1 where the (rep, guide) is masked)
+            const double nn = c.nobs[((long)lik * c.R + r) * G + g];
+            if (nn < 0.0) continue;
+            // pass 1: S = sum e_b sf_b
+            double S = 0.0;
+            {
+                double pv[kBMax], sv[kBMax], qv[kBMax];
 #pragma unroll
-                for (int b = 0; b < B; ++b) n += xp[(long)b * G];
-#ifdef BEAN_SKIP_DIRMULT
-                if (n < 0.f)
-#else
-                if (rgm && n > (float)c.mask_thres)
-#endif
-                    nll += dirmult_nll<B>(xp, (long)G, (lik ? c.sf_bc : c.sf) + r * B, sm,
-                                          lik ? c.a0_bc[g] : c.a0[g], e, ge);
+                for (int b = 0; b < kBMax; ++b) {
+                    const int bb = b < B ? b : B - 1;
+                    pv[b] = tp[bb * 64];
+                    sv[b] = uniform_ld(sf, bb);
+                    qv[b] = MIX ? uniform_ld(c.P0, bb) : 0.0;
+                }
+#pragma unroll
+                for (int b = 0; b < kBMax; ++b) S += b < B ? (w0 * qv[b] + w1 * pv[b]) * sv[b] : 0.0;
             }
-            // likelihood gradient w.r.t. the table entries of this guide's target
-            double dmu = 0.0, dy = 0.0, g0 = 0.0, g1 = 0.0;
-#pragma unroll
+            if (lik == 0) BEAN_STAMP_AT(3);
+            const double a0 = lik ? c.a0_bc[g] : c.a0[g];
+            const double inv = frcp(S + kEps);
+            // pass 2 (see k_lik): U_Q = sum k_b Q_b, V_Q = sum dpsi_b k_b Q_b, t_Q = sum sf_b Q_b
+            double A0 = 0.0, lsum = 0.0, Ua = 0.0, Va = 0.0;
+            double U_mu = 0.0, U_y = 0.0, U_0 = 0.0, U_1 = 0.0;
+            double V_mu = 0.0, V_y = 0.0, V_0 = 0.0, V_1 = 0.0;
+            double t_mu = 0.0, t_y = 0.0, t_0 = 0.0, t_1 = 0.0;
+            float xn = xp[0];
+            double p0n = MIX ? uniform_ld(c.P0, 0) : 0.0, sfn = uniform_ld(sf, 0), smn = uniform_ld(sm, 0);
+#pragma unroll 1
             for (int b = 0; b < B; ++b) {
-                const long o = (long)b * T + t;
-                dmu += ge[b] * c.tabPmu[o];
-                dy += ge[b] * c.tabPy[o];
+                const double x = (double)xn;
+                const double p0 = p0n, sfb = sfn, smb = smn;
+                const double p1 = tp[b * 64], pmu = tp[(B + b) * 64], py = tp[(2 * B + b) * 64];
+                if (b + 1 < B) {
+                    xn = xp[(long)(b + 1) * G];
+                    if (MIX) p0n = uniform_ld(c.P0, b + 1);
+                    sfn = uniform_ld(sf, b + 1);
+                    smn = uniform_ld(sm, b + 1);
+                }
+                const double araw = ((w0 * p0 + w1 * p1) * sfb + epsB) * inv * a0 * smb;
+                const bool floored = araw < kEps;
+                const double alpha = floored ? kEps : araw;
+                A0 += alpha;
+                const DD db = lgamma_digamma_diff_inl(alpha, x);
+                lsum += db.d;
+                const double kb = floored ? 0.0 : a0 * smb * inv * sfb;
+                const double kd = kb * db.dp;
+                Ua += floored ? 0.0 : araw;
+                Va += floored ? 0.0 : db.dp * araw;
+                U_mu += kb * pmu;
+                V_mu += kd * pmu;
+                t_mu += sfb * pmu;
+                U_y += kb * py;
+                V_y += kd * py;
+                t_y += sfb * py;
+                U_1 += kb * p1;
+                V_1 += kd * p1;
+                t_1 += sfb * p1;
                 if (MIX) {
-                    g0 += ge[b] * c.P0[b];
-                    g1 += ge[b] * c.tabP[o];
+                    U_0 += kb * p0;
+                    V_0 += kd * p0;
+                    t_0 += sfb * p0;
                 }
             }
-            acc[kPGmu] += pe1 * dmu;
-            acc[kPGy] += pe1 * dy;
-            if (MIX) {
-                // d loss / d pi through the likelihood
-                double gpi[2] = {g0, g1};
-                if (ACC) {
-                    gpi[0] = 0.0;
-                    gpi[1] = (g1 - g0) * dpe1_dpi1;
-                    acc[kPGnoise] += (g1 - g0) * dpe1_dl;
+            if (lik == 0) BEAN_STAMP_AT(4);
+            const DD d0 = lgamma_digamma_diff_inl(A0, nn);
+            nll += d0.d - lsum;
+            const double W = (d0.dp * Ua - Va) * inv;
+            a_mu += w1 * (d0.dp * U_mu - V_mu - W * t_mu);
+            a_y += w1 * (d0.dp * U_y - V_y - W * t_y);
+            g0 += d0.dp * U_0 - V_0 - W * t_0;
+            g1 += d0.dp * U_1 - V_1 - W * t_1;
+        }
+        BEAN_STAMP_AT(6);
+        double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
+        row[kPGmu * RG] = a_mu;
+        row[kPGy * RG] = a_y;
+        if (MIX) {
+            // d loss / d pi through the likelihood
+            double gpi0 = g0, gpi1 = g1;
+            if (ACC) {
+                gpi0 = 0.0;
+                gpi1 = (g1 - g0) * dpe1_dpi1;
+            }
+            row[kPGnoise * RG] = ACC ? (g1 - g0) * dpe1_dl : 0.0;
+            const double lpi0 = flog(pi0), lpi1 = flog(pi1);
+            const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
+            if (rgm) {
+                // Multinomial(probs = pi) on control allele counts (model.py:470-474):
+                // torch renormalises the probabilities and clamps them to [eps, 1 - eps]
+                const double s = pi0 + pi1;
+                const double ls = s == 1.0 ? 0.0 : flog(s);
+                const double rs = s == 1.0 ? 1.0 : frcp(s);
+                double cnt0 = 0.0, cnt1 = 0.0;
+                for (int cc = 0; cc < c.C; ++cc) {
+                    const float* al = c.allele + (((long)r * c.C + cc) * G + g) * 2;
+                    cnt0 += (double)al[0];
+                    cnt1 += (double)al[1];
                 }
-                const double lpi[2] = {flog(pi[0]), flog(pi[1])};
-                const double rpi[2] = {frcp(pi[0]), frcp(pi[1])};
-                if (rgm) {
-                    // Multinomial(probs = pi) on control allele counts (model.py:470-474):
-                    // torch renormalises the probabilities and clamps them to [eps, 1 - eps]
-                    const double s = pi[0] + pi[1];
-                    const double ls = s == 1.0 ? 0.0 : flog(s);
-                    const double rs = s == 1.0 ? 1.0 : frcp(s);
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const double pr = pi[a] * rs;
-                        const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
-                        const double lg = inside ? lpi[a] - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
-                        double cnt = 0.0;
-                        for (int cc = 0; cc < c.C; ++cc)
-                            cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * 2 + a];
-                        nll -= cnt * lg;
-                        if (inside) gpi[a] -= cnt * rpi[a];
-                    }
-                    acc[kPNrg] += 1.0;
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    if (rgm) {
-                        acc[kPLp + a] += lpi[a];
-                        gpi[a] -= (cp[a] - 1.0) * rpi[a];
-                    }
-                    acc[kPLq + a] += lpi[a];
-                    gpi[a] += (cq[a] - 1.0) * rpi[a];
-                }
-                const double proj = pi[0] * gpi[0] + pi[1] * gpi[1];
-                const double total = cq[0] + cq[1];
-                double path0 = 0.0, path1 = 0.0;
+                const double pr0 = pi0 * rs, pr1 = pi1 * rs;
+                const bool in0 = pr0 > kProbEps && pr0 < 1.0 - kProbEps;
+                const bool in1 = pr1 > kProbEps && pr1 < 1.0 - kProbEps;
+                const double lg0 = in0 ? lpi0 - ls : flog(fmin(fmax(pr0, kProbEps), 1.0 - kProbEps));
+                const double lg1 = in1 ? lpi1 - ls : flog(fmin(fmax(pr1, kProbEps), 1.0 - kProbEps));
+                nll -= cnt0 * lg0;
+                nll -= cnt1 * lg1;
+                if (in0) gpi0 -= cnt0 * rpi0;
+                if (in1) gpi1 -= cnt1 * rpi1;
+                gpi0 -= (cp0 - 1.0) * rpi0;
+                gpi1 -= (cp1 - 1.0) * rpi1;
+            }
+            row[kPNrg * RG] = rgm ? 1.0 : 0.0;
+            row[kPLp * RG] = rgm ? lpi0 : 0.0;
+            row[(kPLp + 1) * RG] = rgm ? lpi1 : 0.0;
+            row[kPLq * RG] = lpi0;
+            row[(kPLq + 1) * RG] = lpi1;
+            gpi0 += (cq0 - 1.0) * rpi0;
+            gpi1 += (cq1 - 1.0) * rpi1;
+            const double proj = pi0 * gpi0 + pi1 * gpi1;
+            const double total = cq0 + cq1;
+            double path0 = 0.0, path1 = 0.0;
 #pragma unroll 1
-                for (int a = 0; a < 2; ++a) {
-                    const bool skip = a ? cl[1] : cl[0];
-                    if (skip) continue;
-#ifdef BEAN_SKIP_DIRGRAD
-                    continue;
-#endif
-                    const double v = dirichlet_grad_one(a ? pi[1] : pi[0], a ? cq[1] : cq[0], total) *
-                                     ((a ? gpi[1] : gpi[0]) - proj);
-                    path0 = a ? path0 : v;
-                    path1 = a ? v : path1;
-                }
-                acc[kPPath] += path0;
-                acc[kPPath + 1] += path1;
+            for (int a = 0; a < 2; ++a) {
+                if (a ? cl1 : cl0) continue;
+                const double v = dirichlet_grad_one(a ? pi1 : pi0, a ? cq1 : cq0, total) *
+                                 ((a ? gpi1 : gpi0) - proj);
+                path0 = a ? path0 : v;
+                path1 = a ? v : path1;
             }
-            loss += nll;
+            row[kPPath * RG] = path0;
+            row[(kPPath + 1) * RG] = path1;
         }
+        loss = nll;
     }
-
-    // ---- reduce over the block's waves (replicates) and write per-guide rows
-    double* red = lds;  // [nw][kNumPart][64]
-    if (nw > 1) {
-#pragma unroll
-        for (int q = 0; q < kNumPart; ++q) red[((long)w * kNumPart + q) * 64 + lane] = acc[q];
-        __syncthreads();
-        if (w == 0) {
-#pragma unroll
-            for (int q = 0; q < kNumPart; ++q) {
-                double s = acc[q];
-                for (int ww = 1; ww < nw; ++ww) s += red[((long)ww * kNumPart + q) * 64 + lane];
-                acc[q] = s;
-            }
-        }
-    }
-    if (w == 0 && valid) {
-#pragma unroll
-        for (int q = 0; q < kNumPart; ++q)
-            if (MIX || q < 2) c.part[(long)q * G + g] = acc[q];
-    }
-    double* scratch = lds + (long)nw * kNumPart * 64;
-    const double tot = block_sum(loss, scratch);
-    if (threadIdx.x == 0) {
+    const double tot = wave_sum(loss);
+    if (lane == 0) {
         atomicAdd(&c.loss_hist[ctr.slot], tot);
-        if (blockIdx.x == 0) *c.ctrA = ctr;
+        if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = ctr;
     }
+    BEAN_STAMP_AT(7);
 }
 
-// ------------------------------------------------- split form of k_guide (variant)
-// The fused k_guide runs at 2 waves/SIMD (its live state plus the out-of-line
-// samplers) and is latency bound.  The same work as three launches, each at its
-// own occupancy:
+// ------------------------------------------------- split form (variant, diagnostic A/B)
+// BEAN_HIP_GUIDE=split: the same work as k_guide_wave in three launches, each at
+// its own occupancy:
 //   k_sample_pi   per (rep, guide): Dirichlet draw                      -> pi_ws
 //   k_lik         per (rep, likelihood, guide): one Dirichlet-Multinomial term
 //                 with analytic gradients (X and X_bcmatch run as separate
@@ -1832,6 +1906,10 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
         }
         if (rgm && n > (double)c.mask_thres) v -= lgamma(1.0 + n) - lf;
         if ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) v -= lgamma(1.0 + nb) - lfb;
+        if (c.nobs) {
+            c.nobs[idx] = (rgm && n > (double)c.mask_thres) ? n : -1.0;
+            c.nobs[n_rg + idx] = ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) ? nb : -1.0;
+        }
         if ((c.family == kMixture || c.family == kMultiMixture) && rgm) {
             for (int cc = 0; cc < c.C; ++cc) {
                 double tot = 0.0, l = 0.0;

@@ -7,15 +7,31 @@ from bean_amd.preprocessing.synthetic import make_sorting_variant_screen
 data = make_sorting_variant_screen(50000, 5, seed=20240502).to("cuda:0")
 eng = engine.HipSVI("MixtureNormal", data, num_steps=100)
 eng.run(20, graph_chunk=0); torch.cuda.synchronize()
-n_waves = 2 * 5 * ((50000 + 63) // 64)
+WAVE = os.environ.get("BEAN_HIP_GUIDE") != "split"
+n_waves = (1 if WAVE else 2) * 5 * ((50000 + 63) // 64)
 buf = np.zeros(n_waves * 8, dtype=np.uint64)
 lib = _lib.load()
 lib.bean_hip_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
 assert lib.bean_hip_debug_stamps(eng._h, buf.ctypes.data, buf.size) == 0
 s = buf.reshape(n_waves, 8).astype(np.int64)
 d = np.diff(s, axis=1)
-names = ["prologue loads+LDS store", "barrier", "pass1 (+pi loads)", "pass2", "d0+final math", "exchange+writes", "block_sum"]
+if WAVE:
+    names = ["setup loads", "pi draw", "lik X pass 1", "lik X bin loop", "lik X total term", "lik X_bcmatch", "pi terms + dirichlet grads + rows"]
+else:
+  names = ["prologue loads+LDS store", "barrier", "pass1 (+pi loads)", "pass2", "d0+final math", "exchange+writes", "block_sum"]
 print("median cycles per segment:")
 for i, n in enumerate(names):
     print(f"  {n:28s} median {np.median(d[:, i]):9.0f}  mean {d[:, i].mean():9.0f}")
 print("total median", np.median(s[:, 7] - s[:, 0]), "kernel span cycles", s[:, 7].max() - s[:, 0].min())
+t0 = s[:, 0].min()
+for nm, col in (("start", 0), ("end", 7)):
+    v = s[:, col] - t0
+    print(nm, "percentiles 0/10/50/90/100:", [int(np.percentile(v, q)) for q in (0, 10, 50, 90, 100)])
+# s_memtime counters are per XCD; workgroups go to XCDs round-robin by linear id
+ids = (buf.reshape(n_waves, 8)[:, 0] & 7).astype(np.int64) if WAVE else np.arange(n_waves) % 8
+for x in range(8):
+    m = ids == x
+    if not m.any():
+        continue
+    st, en = s[m, 0], s[m, 7]
+    print(f"xcd {x}: span {en.max() - st.min():8d} cycles; start spread p50 {int(np.median(st - st.min())):7d} p100 {int((st - st.min()).max()):7d}; wave total p50 {int(np.median(en - st)):7d} p95 {int(np.percentile(en - st, 95)):7d}")
