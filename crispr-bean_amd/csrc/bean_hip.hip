@@ -35,6 +35,7 @@ struct bean_hip_ctx {
     bool prepared;
     bool fused_guide;  // false: BEAN_HIP_GUIDE=split selects the sample / lik / pi-terms launches
     bool wave_guide;   // sorting variant families, default: one wave per (guide tile, replicate)
+    int* tile_targets_dev;
     // graph cache
     hipGraphExec_t graph_exec;
     int graph_chunk;
@@ -248,7 +249,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
 #else
     const uint64_t n_dbg = 0;
 #endif
-    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 1 + 8 + n_surv + n_split + n_dbg;
+    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + n_surv + n_split + n_dbg;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
     if (e != hipSuccess) {
@@ -276,6 +277,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.lpn = w; w += G;
     d.eps_noise = w; w += G;
     d.loss_const = w; w += 1;
+    c->tile_targets_dev = (int*)w; w += 1;
+    d.tile_targets = 64;
     if (n_dbg) {
         d.dbg = (unsigned long long*)w; w += n_dbg;
     }
@@ -378,6 +381,20 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
     const long n = (long)c->d.R * c->d.G;
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c->d);
     HIP_OK(hipGetLastError());
+    if (c->wave_guide) {
+        // LDS sizing of k_guide_wave: the one host read-back of the library (4 bytes, setup only)
+        HIP_OK(hipMemsetAsync(c->tile_targets_dev, 0, sizeof(int), stream));
+        const int tiles = (c->d.G + 63) / 64;
+        hipLaunchKernelGGL(k_tile_targets, dim3((tiles + 255) / 256), dim3(256), 0, stream, c->d.g2t, c->d.G,
+                           c->tile_targets_dev);
+        HIP_OK(hipGetLastError());
+        int nt = 0;
+        HIP_OK(hipMemcpyAsync(&nt, c->tile_targets_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (nt < 1 || nt > 64) return fail("bean_hip_prepare: guides are not sorted by target (BEAN_BUF_GUIDE_TO_TARGET)");
+        if (nt != c->d.tile_targets) drop_graph(c);
+        c->d.tile_targets = nt;
+    }
     c->prepared = true;
     return 0;
 }
@@ -465,7 +482,7 @@ static void launch_guide_split(bean_hip_ctx* c, hipStream_t stream) {
 static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     const dim3 grid((d.G + 63) / 64, d.R), block(64);
-    const size_t lds = (size_t)3 * d.B * 64 * sizeof(double);
+    const size_t lds = (size_t)3 * d.B * d.tile_targets * sizeof(double) + (size_t)2 * d.B * 64 * sizeof(float);
     const bool prof = c->profile && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {

@@ -99,6 +99,7 @@ struct DevArgs {
     unsigned long long* dbg;           // diagnostic builds (-DBEAN_STAMP): per-wave cycle stamps
     double* rrow;                      // (3, R, G) split form: d/dmu_t, d/dy_t, d/dnoise per (rep, guide)
     double* wrow;                      // (kNumPart, R, G) wave form: every per-guide row, per replicate
+    int tile_targets;                  // wave form: most targets spanned by any 64-guide tile (<= 64)
     double* nobs;                      // (2, R, G) wave form: count totals of X / X_bcmatch, -1 where masked
     StepCtr *ctrA, *ctrB;
     // tiling (MultiMixtureNormal): CSR allele slot -> edits and its transpose
@@ -401,13 +402,35 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                         // d sigma_a / d y_e = sd_e^2 / sigma_a
                         gy += c.part[(long)kTGsig * c.G + o] * sd * sd / c.sig_a[o];
                     }
-                } else {
+                } else if (!c.wrow) {
                     const int g0 = c.toff[t], g1 = c.toff[t + 1];
                     for (int g = g0; g < g1; ++g) {
                         gmu += lik_row(c, kPGmu, g);
                         gy += lik_row(c, kPGy, g);
                     }
                 }
+            }
+            if (FINISH && c.wrow) {
+                // wave form: the (guide, replicate) rows of the target are spread over its lane
+                // group and summed by a fixed shuffle tree (deterministic, shard independent)
+                const int lg = threadIdx.x & (kLanesPerTarget - 1);
+                double a = 0.0, b = 0.0;
+                if (t < c.T) {
+                    const int g0 = c.toff[t], ng = c.toff[t + 1] - g0;
+                    const int n = ng * c.R;
+                    for (int i = lg; i < n; i += kLanesPerTarget) {
+                        const int r = i / ng, g = g0 + (i - r * ng);
+                        a += c.wrow[((long)kPGmu * c.R + r) * c.G + g];
+                        b += c.wrow[((long)kPGy * c.R + r) * c.G + g];
+                    }
+                }
+#pragma unroll
+                for (int off = kLanesPerTarget / 2; off > 0; off >>= 1) {
+                    a += __shfl_xor(a, off, kLanesPerTarget);
+                    b += __shfl_xor(b, off, kLanesPerTarget);
+                }
+                gmu = a;
+                gy = b;
             }
         }
         if (active && c.survival) {
@@ -576,16 +599,38 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                     lgamma_digamma(cq[0], lg_q[0], dg_q[0]);
                     lgamma_digamma(cq[1], lg_q[1], dg_q[1]);
                 }
-                const double nrg = part_row(c, kPNrg, g);
+                // per-replicate rows of the wave form: independent loads, four replicates in flight
+                double Lp_[2] = {0.0, 0.0}, Lq_[2] = {0.0, 0.0}, path_[2] = {0.0, 0.0}, nrg = 0.0;
+                if (c.wrow) {
+                    const long RG = (long)c.R * c.G;
+                    const double* w = c.wrow + g;
+#pragma unroll 4
+                    for (int r = 0; r < c.R; ++r) {
+                        const double* wr = w + (long)r * c.G;
+                        nrg += wr[kPNrg * RG];
+                        Lp_[0] += wr[kPLp * RG];
+                        Lp_[1] += wr[(kPLp + 1) * RG];
+                        Lq_[0] += wr[kPLq * RG];
+                        Lq_[1] += wr[(kPLq + 1) * RG];
+                        path_[0] += wr[kPPath * RG];
+                        path_[1] += wr[(kPPath + 1) * RG];
+                    }
+                } else {
+                    nrg = c.part[(long)kPNrg * c.G + g];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        Lp_[a] = c.part[(long)(kPLp + a) * c.G + g];
+                        Lq_[a] = c.part[(long)(kPLq + a) * c.G + g];
+                        path_[a] = c.part[(long)(kPPath + a) * c.G + g];
+                    }
+                }
                 const double Rf = (double)c.R;
                 double gc[2];
                 double lp = nrg * (lgS_p - lg_p[0] - lg_p[1]);
                 double lq = Rf * (lgS_q - lg_q[0] - lg_q[1]);
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    const double Lp = part_row(c, kPLp + a, g);
-                    const double Lq = part_row(c, kPLq + a, g);
-                    const double gpath = part_row(c, kPPath + a, g);
+                    const double Lp = Lp_[a], Lq = Lq_[a], gpath = path_[a];
                     lp += (cp[a] - 1.0) * Lp;
                     lq += (cq[a] - 1.0) * Lq;
                     const double g_cp = -(Lp + nrg * (dgS_p - dg_p[a]));
@@ -760,7 +805,9 @@ template <int FAM, bool ACC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void k_guide_wave(DevArgs c) {
     constexpr bool MIX = FAM == kMixture;
-    extern __shared__ double tabs[];  // [3][B][64]: P, dP/dmu, dP/dy columns of the tile's targets
+    // dynamic LDS: [3][B][ntm] doubles (P, dP/dmu, dP/dy columns of the tile's targets; ntm =
+    // c.tile_targets, the largest number of targets any tile spans) + [2][B][64] floats (counts)
+    extern __shared__ double tabs[];
     const int lane = threadIdx.x;
     const int g = blockIdx.x * 64 + lane;
     const int r = blockIdx.y;
@@ -772,11 +819,11 @@ void k_guide_wave(DevArgs c) {
     const long wave_gid = (long)blockIdx.y * gridDim.x + blockIdx.x;
 #endif
 #ifdef BEAN_STAMP
-    {   // slot 0: start time with the XCD id in the low 3 bits (s_memtime counters are per XCD)
+    {   // slot 0: start on the device-wide 100 MHz clock (s_memtime counters are not comparable
+        // across the chip)
         unsigned long long t_;
-        unsigned xcc_;
-        asm volatile("s_memtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(xcc_)::"memory");
-        if (lane == 0) c.dbg[wave_gid * 8] = (t_ & ~7ull) | (xcc_ & 7u);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        if (lane == 0) c.dbg[wave_gid * 8] = t_;
     }
 #endif
 
@@ -788,11 +835,22 @@ void k_guide_wave(DevArgs c) {
     const int g_last = (g_first + 63 < G ? g_first + 63 : G - 1);
     const int t0 = __builtin_amdgcn_readfirstlane(c.g2t[g_first]);
     const int nt = __builtin_amdgcn_readfirstlane(c.g2t[g_last]) - t0 + 1;
-    if (lane < nt) {
+    const int ntm = c.tile_targets;
+    float* xs = (float*)(tabs + 3 * B * ntm);  // this thread's counts: xs[(lik * B + b) * 64 + lane]
+    const bool use_bc = (c.flags & kUseBc) != 0;
+    {
+        // counts of both likelihoods and table columns: one batch of loads, then LDS
+        const int gc = valid ? g : G - 1;
+        const int tl = lane < nt ? lane : nt - 1;
+        float xv[2][kBMax];
         double tv[3][kBMax];
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
-            const long o = (long)(b < B ? b : B - 1) * T + t0 + lane;
+            const int bb = b < B ? b : B - 1;
+            const long xo = ((long)r * B + bb) * G + gc;
+            xv[0][b] = c.X[xo];
+            xv[1][b] = use_bc ? c.Xbc[xo] : 0.f;
+            const long o = (long)bb * T + t0 + tl;
             tv[0][b] = c.tabP[o];
             tv[1][b] = c.tabPmu[o];
             tv[2][b] = c.tabPy[o];
@@ -800,9 +858,13 @@ void k_guide_wave(DevArgs c) {
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
             const int bb = b < B ? b : B - 1;
-            tabs[(0 * B + bb) * 64 + lane] = tv[0][b];
-            tabs[(1 * B + bb) * 64 + lane] = tv[1][b];
-            tabs[(2 * B + bb) * 64 + lane] = tv[2][b];
+            xs[(0 * B + bb) * 64 + lane] = xv[0][b];
+            xs[(1 * B + bb) * 64 + lane] = xv[1][b];
+            if (lane < nt) {
+                tabs[(0 * B + bb) * ntm + lane] = tv[0][b];
+                tabs[(1 * B + bb) * ntm + lane] = tv[1][b];
+                tabs[(2 * B + bb) * ntm + lane] = tv[2][b];
+            }
         }
     }
     __syncthreads();
@@ -810,9 +872,8 @@ void k_guide_wave(DevArgs c) {
     if (valid) {
         const long rgi = (long)r * G + g;
         const long RG = (long)c.R * G;
-        const double* tp = tabs + (c.g2t[g] - t0);  // this guide's column: tp[(which * B + b) * 64]
+        const double* tp = tabs + (c.g2t[g] - t0);  // this guide's column: tp[(which * B + b) * ntm]
         const bool rgm = c.rg[rgi] != 0;
-        const bool use_bc = (c.flags & kUseBc) != 0;
         double cp0 = 1.0, cp1 = 1.0, cq0 = 1.0, cq1 = 1.0;
         bool cl0 = false, cl1 = false;
         double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0;
@@ -868,7 +929,7 @@ void k_guide_wave(DevArgs c) {
             if (lik == 1 && !use_bc) break;
             if (lik == 0) BEAN_STAMP_AT(2);
             else BEAN_STAMP_AT(5);
-            const float* xp = (lik ? c.Xbc : c.X) + (long)r * B * G + g;
+            const float* xp = xs + lik * B * 64 + lane;  // xp[b * 64]
             const double* sf = (lik ? c.sf_bc : c.sf) + r * B;
             // n = sum x_b is data: k_prepare leaves it in nobs (-1 where the (rep, guide) is masked)
             const double nn = c.nobs[((long)lik * c.R + r) * G + g];
@@ -880,7 +941,7 @@ void k_guide_wave(DevArgs c) {
 #pragma unroll
                 for (int b = 0; b < kBMax; ++b) {
                     const int bb = b < B ? b : B - 1;
-                    pv[b] = tp[bb * 64];
+                    pv[b] = tp[bb * ntm];
                     sv[b] = uniform_ld(sf, bb);
                     qv[b] = MIX ? uniform_ld(c.P0, bb) : 0.0;
                 }
@@ -895,15 +956,13 @@ void k_guide_wave(DevArgs c) {
             double U_mu = 0.0, U_y = 0.0, U_0 = 0.0, U_1 = 0.0;
             double V_mu = 0.0, V_y = 0.0, V_0 = 0.0, V_1 = 0.0;
             double t_mu = 0.0, t_y = 0.0, t_0 = 0.0, t_1 = 0.0;
-            float xn = xp[0];
             double p0n = MIX ? uniform_ld(c.P0, 0) : 0.0, sfn = uniform_ld(sf, 0), smn = uniform_ld(sm, 0);
 #pragma unroll 1
             for (int b = 0; b < B; ++b) {
-                const double x = (double)xn;
+                const double x = (double)xp[b * 64];
                 const double p0 = p0n, sfb = sfn, smb = smn;
-                const double p1 = tp[b * 64], pmu = tp[(B + b) * 64], py = tp[(2 * B + b) * 64];
+                const double p1 = tp[b * ntm], pmu = tp[(B + b) * ntm], py = tp[(2 * B + b) * ntm];
                 if (b + 1 < B) {
-                    xn = xp[(long)(b + 1) * G];
                     if (MIX) p0n = uniform_ld(c.P0, b + 1);
                     sfn = uniform_ld(sf, b + 1);
                     smn = uniform_ld(sm, b + 1);
@@ -1008,7 +1067,13 @@ void k_guide_wave(DevArgs c) {
         atomicAdd(&c.loss_hist[ctr.slot], tot);
         if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = ctr;
     }
-    BEAN_STAMP_AT(7);
+#ifdef BEAN_STAMP
+    {
+        unsigned long long t_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        if (lane == 0) c.dbg[wave_gid * 8 + 7] = t_;
+    }
+#endif
 }
 
 // ------------------------------------------------- split form (variant, diagnostic A/B)
@@ -1930,6 +1995,14 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
         const double cl = isinf(zl) ? 0.0 : norm_cdf(zl);
         c.P0[threadIdx.x] = ch - cl;
     }
+}
+
+// most targets spanned by one 64-guide tile (guides are target-sorted); *out must start at 0
+__global__ __launch_bounds__(256) void k_tile_targets(const int* g2t, int G, int* out) {
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile * 64 >= G) return;
+    const int first = tile * 64, last = first + 63 < G ? first + 63 : G - 1;
+    atomicMax(out, g2t[last] - g2t[first] + 1);
 }
 
 __global__ void k_set_step(StepCtr* a, StepCtr* b, unsigned long long step, unsigned long long slot) {

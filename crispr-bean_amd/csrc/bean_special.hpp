@@ -360,6 +360,29 @@ __device__ __forceinline__ Pair uniform_pair(Rng& rng) {
     return p;
 }
 
+// Random inputs of one Marsaglia-Tsang rejection round for two components, from ONE Philox
+// counter: words (x, y) give two standard normals by Box-Muller evaluated in float32 (the
+// reference draws in float32; a 32-bit radius uniform reaches 6.7 sigma), words (z, w) the two
+// acceptance uniforms in (0, 1).
+struct GammaRound {
+    double na, nb, ua, ub;
+};
+__device__ __noinline__ GammaRound gamma_round_at(unsigned long long seed, unsigned long long sub,
+                                                  unsigned long long offset) {
+    const uint4 v = philox_at(seed, sub, offset);
+    const float u1 = ((float)v.x + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
+    const float u2 = (float)v.y * 2.3283064365386963e-10f;           // [0, 1]
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    GammaRound q;
+    q.na = (double)(rad * cs);
+    q.nb = (double)(rad * sn);
+    q.ua = ((double)v.z + 0.5) * 2.3283064365386963e-10;
+    q.ub = ((double)v.w + 0.5) * 2.3283064365386963e-10;
+    return q;
+}
+
 struct GammaPair {
     double g0, g1;
     unsigned int k;  // generator position after the draw
@@ -367,8 +390,8 @@ struct GammaPair {
 
 // Two independent Gamma(alpha_i, 1) draws by Marsaglia & Tsang (2000) with the
 // alpha < 1 boost (the method behind torch's sample_gamma), sharing one
-// rejection loop: each round costs two Philox counters for both components, and
-// a wave only iterates until its slowest lane has accepted both.
+// rejection loop: each round costs one Philox counter for both components (gamma_round_at),
+// and a wave only iterates until its slowest lane has accepted both.
 __device__ BEAN_NOINLINE GammaPair sample_gamma_pair(double a0, double a1, Rng rng) {
     double scale0 = 1.0, scale1 = 1.0;
     if (a0 < 1.0 || a1 < 1.0) {
@@ -388,23 +411,23 @@ __device__ BEAN_NOINLINE GammaPair sample_gamma_pair(double a0, double a1, Rng r
     double g0 = d0, g1 = d1;
 #pragma unroll 1
     for (int it = 0; it < 64 && !(done0 && done1); ++it) {  // >= 95 % acceptance per round
-        const Pair n = normal_pair(rng);
-        const Pair u = uniform_pair(rng);
+        const GammaRound q = gamma_round_at(rng.seed, rng.sub, rng.off + 4ull * rng.k);
+        ++rng.k;
         if (!done0) {
-            const double y = 1.0 + c0 * n.a;
+            const double y = 1.0 + c0 * q.na;
             if (y > 0.0) {
-                const double v = y * y * y, xx = n.a * n.a;
-                if (u.a < 1.0 - 0.0331 * xx * xx || flog(u.a) < 0.5 * xx + d0 * (1.0 - v + flog(v))) {
+                const double v = y * y * y, xx = q.na * q.na;
+                if (q.ua < 1.0 - 0.0331 * xx * xx || flog(q.ua) < 0.5 * xx + d0 * (1.0 - v + flog(v))) {
                     g0 = d0 * v;
                     done0 = true;
                 }
             }
         }
         if (!done1) {
-            const double y = 1.0 + c1 * n.b;
+            const double y = 1.0 + c1 * q.nb;
             if (y > 0.0) {
-                const double v = y * y * y, xx = n.b * n.b;
-                if (u.b < 1.0 - 0.0331 * xx * xx || flog(u.b) < 0.5 * xx + d1 * (1.0 - v + flog(v))) {
+                const double v = y * y * y, xx = q.nb * q.nb;
+                if (q.ub < 1.0 - 0.0331 * xx * xx || flog(q.ub) < 0.5 * xx + d1 * (1.0 - v + flog(v))) {
                     g1 = d1 * v;
                     done1 = true;
                 }
