@@ -1,0 +1,130 @@
+"""Posterior parity at BASELINE.json configs[1] (5k guides x 4 sort bins (+bulk) x 3
+replicates, MixtureNormal): the protocol of SURVEY.md section 8(d).  -m gpu.
+
+(ii)  exact-noise trajectory: 200 SVI steps on the draws the kernel generated, replayed
+      by the oracle; `mu_loc` within 1e-3 relative (of the largest |mu_loc|).
+(iii) free-running fits: the HIP fit (seed 101, Philox stream) against an oracle fit
+      (torch CPU generator) cannot agree draw by draw, so its distance to the oracle fit is
+      reported next to the oracle's own seed-to-seed spread and must not exceed it
+      materially.  Numbers go to gpurun_out/posterior_parity.json.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bean_amd  # noqa: F401
+from bean_amd.preprocessing.synthetic import make_sorting_variant_screen
+from oracle import elbo, svi
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from bean_amd import engine as eng
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return eng
+
+
+@pytest.fixture(scope="module")
+def screen():
+    return make_sorting_variant_screen(5000, 3, seed=20240502)
+
+
+def test_exact_noise_200_step_trajectory(engine, screen):
+    n = 200
+    eng = engine.HipSVI("MixtureNormal", screen.to(DEV), dump_noise=True, num_steps=2000)
+    params = elbo.init_params("MixtureNormal", screen)
+    optim = svi.ClippedAdam(params, lr=0.01, lrd=0.1 ** (1 / 2000))
+    for t in range(n):
+        loss, _ = eng.elbo_grad(step=t, seed=101, loss_index=t)
+        noise = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+        eng.adam(t + 1)
+        ref = svi.svi_step(elbo.mixture_normal_loss, screen, params, optim, noise=noise)
+        assert abs(loss - ref) <= 1e-5 * abs(ref), (t, loss, ref)
+        if t % 50 == 0:
+            print("trajectory step", t, flush=True)
+    torch.cuda.synchronize()
+    got = eng.unconstrained["mu_loc"].cpu().flatten()
+    ref = params["mu_loc"].detach().flatten()
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-3 * ref.abs().max().item(), err
+    for k in ("mu_scale", "sd_loc", "sd_scale", "alpha_pi"):
+        r = params[k].detach()
+        e = (eng.unconstrained[k].cpu() - r).abs().max().item()
+        assert e <= 1e-3 * max(1.0, r.abs().max().item()), (k, e)
+    eng.close()
+
+
+LR = 0.03  # both sides; shortens the fit the (slow) oracle has to run
+
+
+@pytest.fixture(autouse=True)
+def _few_threads():
+    # the eager oracle is overhead bound at this size: 4 threads are faster than 128
+    n = torch.get_num_threads()
+    torch.set_num_threads(4)
+    yield
+    torch.set_num_threads(n)
+
+
+def _oracle_fit(screen, seed, steps):
+    torch.manual_seed(seed)
+    params = elbo.init_params("MixtureNormal", screen)
+    params, losses = svi.run_svi(elbo.mixture_normal_loss, screen, params, num_steps=steps, initial_lr=LR)
+    print("oracle fit seed", seed, "done", flush=True)
+    c = elbo.constrained(params)
+    return c["mu_loc"].detach().flatten().double(), c["mu_scale"].detach().flatten().double(), losses
+
+
+def test_free_running_fit_within_oracle_seed_spread(engine, screen):
+    steps = 500
+    eng = engine.HipSVI("MixtureNormal", screen.to(DEV), num_steps=steps, initial_lr=LR)
+    eng.run(steps, seed=101)
+    torch.cuda.synchronize()
+    hip = eng.constrained()
+    mu_h = hip["mu_loc"].cpu().flatten().double()
+    sc_h = hip["mu_scale"].cpu().flatten().double()
+    loss_h = eng.losses()
+    eng.close()
+    mu_a, sc_a, loss_a = _oracle_fit(screen, 101, steps)
+    mu_b, sc_b, loss_b = _oracle_fit(screen, 202, steps)
+
+    def dist(x, y, sel):
+        rel = ((x - y).abs() / y.abs())[sel]
+        return float(rel.median()), float(rel.max())
+
+    strong = (mu_a / sc_a).abs() > 2.0  # variants with |mu_z| > 2 in the oracle fit
+    assert int(strong.sum()) >= 20
+    med_h, max_h = dist(mu_h, mu_a, strong)
+    med_s, max_s = dist(mu_b, mu_a, strong)
+    smed_h, _ = dist(sc_h, sc_a, strong)
+    smed_s, _ = dist(sc_b, sc_a, strong)
+    corr_h = float(np.corrcoef(mu_h.numpy(), mu_a.numpy())[0, 1])
+    corr_s = float(np.corrcoef(mu_b.numpy(), mu_a.numpy())[0, 1])
+    tail = slice(-100, None)
+    rep = {
+        "config": "5000 guides x (4 bins + bulk) x 3 reps, MixtureNormal, %d steps, initial_lr %g" % (steps, LR),
+        "n_strong": int(strong.sum()),
+        "mu_loc_rel_err_median": {"hip_vs_oracle": med_h, "oracle_seed_vs_seed": med_s},
+        "mu_loc_rel_err_max": {"hip_vs_oracle": max_h, "oracle_seed_vs_seed": max_s},
+        "mu_scale_rel_err_median": {"hip_vs_oracle": smed_h, "oracle_seed_vs_seed": smed_s},
+        "mu_loc_corr_all_targets": {"hip_vs_oracle": corr_h, "oracle_seed_vs_seed": corr_s},
+        "final_loss_mean_last100": {"hip": float(np.mean(loss_h[tail])), "oracle_a": float(np.mean(loss_a[tail])),
+                                    "oracle_b": float(np.mean(loss_b[tail]))},
+    }
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(rep, open(os.path.join(out, "posterior_parity.json"), "w"), indent=1)
+    print(json.dumps(rep))
+    # the HIP fit is as close to an oracle fit as another oracle seed is (SVI noise), not worse
+    assert med_h <= 1.5 * med_s + 1e-3, rep
+    assert smed_h <= 1.5 * smed_s + 1e-3, rep
+    assert corr_h >= corr_s - 0.01, rep
+    la, lh = rep["final_loss_mean_last100"]["oracle_a"], rep["final_loss_mean_last100"]["hip"]
+    assert abs(lh - la) <= 2e-3 * abs(la), rep
