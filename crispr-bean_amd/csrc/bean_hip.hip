@@ -51,6 +51,11 @@ extern "C" const char* bean_hip_last_error(void) { return g_err.c_str(); }
 static bool is_survival(const bean_hip_shape& s) { return s.selection == BEAN_SELECTION_SURVIVAL; }
 static bool is_tiling(const bean_hip_shape& s) { return s.family == BEAN_FAMILY_MULTI_MIXTURE; }
 // families with a Dirichlet pi site (reporter models)
+// survival NormalModel: the drawn initial guide abundance q_0 ~ Dirichlet over ALL guides enters
+// the likelihood (survival_model.py:15-130, 629-648)
+static bool is_surv_normal(const bean_hip_shape& s) {
+    return s.selection == BEAN_SELECTION_SURVIVAL && s.family == BEAN_FAMILY_NORMAL;
+}
 static bool is_mixture(const bean_hip_shape& s) {
     return s.family == BEAN_FAMILY_MIXTURE_NORMAL || s.family == BEAN_FAMILY_MULTI_MIXTURE;
 }
@@ -63,7 +68,7 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         switch (i) {
             case 0: case 1: return T;
             case 2: case 3: return is_survival(s) ? 0 : T;  // survival models have no sd latent
-            case 7: return (is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) ? G : 0;
+            case 7: return ((is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) || is_surv_normal(s)) ? G : 0;
             case 4: return is_mixture(s) ? G * A : 0;
             case 5: case 6: return (is_mixture(s) && (s.flags & BEAN_FLAG_SCALE_BY_ACC) && (s.flags & BEAN_FLAG_FIT_NOISE)) ? G : 0;
         }
@@ -87,8 +92,10 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_Z_HI: case BEAN_BUF_Z_LO: return is_survival(s) ? 0 : 8 * B;
         case BEAN_BUF_TIMEPOINTS: return is_survival(s) ? 8 * B : 0;
         case BEAN_BUF_CONTROL_TIME: return (is_survival(s) && is_mixture(s)) ? 8 * C : 0;
-        case BEAN_BUF_LOG_OBS0: case BEAN_BUF_X0_IN: case BEAN_BUF_X0_OUT:
-            return (is_survival(s) && is_mixture(s)) ? 8 * R * G : 0;
+        case BEAN_BUF_LOG_OBS0: return (is_survival(s) && is_mixture(s)) ? 8 * R * G : 0;
+        case BEAN_BUF_X0_IN: case BEAN_BUF_X0_OUT:
+            return ((is_survival(s) && is_mixture(s)) || is_surv_normal(s)) ? 8 * R * G : 0;
+        case BEAN_BUF_NEGCTRL_MASK: return is_surv_normal(s) ? G : 0;
         case BEAN_BUF_EPS_U_IN: case BEAN_BUF_EPS_U_OUT: return (is_survival(s) && is_mixture(s)) ? 8 * G : 0;
         case BEAN_BUF_TARGET_OFFSETS: return is_tiling(s) ? 0 : 4 * (T + 1);
         case BEAN_BUF_GUIDE_TO_TARGET: return is_tiling(s) ? 0 : 4 * G;
@@ -152,6 +159,7 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.eps_noise_out = (double*)P(BEAN_BUF_EPS_NOISE_OUT);
     d.loss_hist = (double*)P(BEAN_BUF_LOSS_HIST);
     d.time = (const double*)P(BEAN_BUF_TIMEPOINTS);
+    d.negctrl = (const uint8_t*)P(BEAN_BUF_NEGCTRL_MASK);
     d.ctrl_time = (const double*)P(BEAN_BUF_CONTROL_TIME);
     d.log_obs0 = (const double*)P(BEAN_BUF_LOG_OBS0);
     d.x0_in = (const double*)P(BEAN_BUF_X0_IN);
@@ -174,8 +182,10 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (!s || !out) return fail("bean_hip_create: null argument");
     if (s->selection != BEAN_SELECTION_SORTING && s->selection != BEAN_SELECTION_SURVIVAL)
         return fail("bean_hip_create: unknown selection");
-    if (is_survival(*s) && s->family != BEAN_FAMILY_CONTROL_NORMAL && s->family != BEAN_FAMILY_MIXTURE_NORMAL)
-        return fail("bean_hip_create: survival screens support ControlNormal and MixtureNormal in this build");
+    if (is_survival(*s) && s->family == BEAN_FAMILY_MULTI_MIXTURE)
+        return fail("bean_hip_create: survival screens support Normal, ControlNormal and MixtureNormal in this build");
+    if (is_surv_normal(*s) && s->n_guides_total > 0 && s->n_guides_total != s->n_guides)
+        return fail("bean_hip_create: the survival NormalModel couples all guides and cannot be guide-sharded");
     if (is_survival(*s) && !(s->negctrl_scale > 0.0)) return fail("bean_hip_create: negctrl_scale must be > 0");
     if (s->family < BEAN_FAMILY_NORMAL || s->family > BEAN_FAMILY_MULTI_MIXTURE)
         return fail("bean_hip_create: unknown family");
@@ -235,10 +245,13 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const uint64_t n_tab = is_tiling(*s) ? A1 * G : T;  // table columns: allele slots or targets
     const uint64_t n_part = is_tiling(*s) ? (uint64_t)kTNumPart : (uint64_t)kNumPart;
     const bool surv_mix = is_survival(*s) && is_mixture(*s);
+    const bool surv_norm = is_surv_normal(*s);
+    d.surv_q0lik = surv_norm ? 1 : 0;
     const uint64_t Rr = d.R;
     const uint64_t n_gblk = (G + 255) / 256;
     d.n_gamma_blocks = (int)n_gblk;
-    const uint64_t n_surv = surv_mix ? 2 * G + Rr * G + n_gblk * (Rr + 1) + (Rr + 1) : 0;
+    const uint64_t n_surv = (surv_mix ? 2 * G + Rr * G + n_gblk * (Rr + 1) + (Rr + 1) : 0) +
+                            (surv_norm ? 2 * Rr * G + n_gblk * (Rr + 1) + (Rr + 1) + Rr : 0);
     const bool split_ok = !is_survival(*s) && !is_tiling(*s);
     const bool use_split = split_ok && !c->fused_guide;
     c->wave_guide = c->wave_guide && split_ok;
@@ -299,6 +312,13 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         d.gam = w; w += Rr * G;
         d.gpart = w; w += n_gblk * (Rr + 1);
         d.gsum = w; w += Rr + 1;
+    }
+    if (surv_norm) {
+        d.gam = w; w += Rr * G;
+        d.gpart = w; w += n_gblk * (Rr + 1);
+        d.gsum = w; w += Rr + 1;
+        d.gq = w; w += Rr * G;
+        d.sq = w; w += Rr;
     }
     d.ctrA = (StepCtr*)w; w += 2;
     d.ctrB = (StepCtr*)w; w += 2;
@@ -403,7 +423,8 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
 static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_blocks) {
     const DevArgs& d = c->d;
     n_target_blocks = d.wide_targets ? d.T : (int)(((long)d.T * kLanesPerTarget + 255) / 256);
-    n_blocks = n_target_blocks + ((d.family == kMixture || d.family == kMultiMixture) ? (d.G + 255) / 256 : 0);
+    n_blocks = n_target_blocks +
+               ((d.family == kMixture || d.family == kMultiMixture || d.surv_q0lik) ? (d.G + 255) / 256 : 0);
 }
 
 template <bool FINISH, bool ADAM, bool PREP>
@@ -516,7 +537,7 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         return;
     }
     const int nw = waves_per_block(c);
-    if (d.survival && d.family == kMixture)  // normalisers of the Dirichlet(q0) draw
+    if (d.survival && (d.family == kMixture || d.surv_q0lik))  // normalisers of the Dirichlet(q0) draw
         hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, stream, d);
     if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
         const long n = (long)(d.A - 1) * d.G;
@@ -541,6 +562,8 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         case 7: launch_guide_b<7>(c, stream, grid, block, lds); break;
         default: launch_guide_b<8>(c, stream, grid, block, lds); break;
     }
+    if (d.surv_q0lik)  // projection term of the G-dimensional Dirichlet's pathwise gradient
+        hipLaunchKernelGGL(k_sum_q, dim3(d.R), dim3(1024), 0, stream, d);
     if (prof) {
         (void)hipEventRecord(e1, stream);
         c->ev.push_back(e0);

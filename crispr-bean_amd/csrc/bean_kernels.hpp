@@ -119,6 +119,11 @@ struct DevArgs {
     double *gam;                     // (R, G) gamma draws of the Dirichlet(q0) site
     double *gpart;                   // (n_gamma_blocks, R + 1) block sums: gammas per rep, q0
     double *gsum;                    // (R + 1) totals: sum_g gamma[r, g], sum_g q0
+    // survival NormalModel: q_0 ~ Dirichlet(initial_abundance) over all guides enters the likelihood
+    int surv_q0lik;
+    const uint8_t* negctrl;          // (G) guides whose mu is forced to 0
+    double *gq;                      // (R, G) d loss / d q_0[r, g]
+    double *sq;                      // (R) sum_g q_0[r, g] * gq[r, g]
     int n_gamma_blocks;
 };
 
@@ -677,6 +682,65 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                 c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
                 if (c.eps_noise_out) c.eps_noise_out[g] = eps;
             }
+        }
+    }
+    if (c.surv_q0lik && (int)blockIdx.x >= n_target_blocks) {
+        // survival NormalModel: Dirichlet(initial_abundance) site over ALL guides, drawn per
+        // replicate and used by the likelihood (survival_model.py:62-67, 629-639).  The prior is
+        // Dirichlet(1 / G), so unlike the MixtureNormal q0 site nothing cancels.
+        const int gb = (int)blockIdx.x - n_target_blocks;
+        const int g = gb * blockDim.x + threadIdx.x;
+        const bool in = g < c.G;
+        float iau = in ? c.p[7][g] : 0.f;
+        if (FINISH && in) {
+            const double ia = (double)expf(iau);
+            const double tot = c.gsum[c.R];
+            double lg_tot, dg_tot, lg_a, dg_a;
+            lgamma_digamma(tot, lg_tot, dg_tot);
+            lgamma_digamma(ia, lg_a, dg_a);
+            const double Rf = (double)c.R;
+            // d/d ia of log q: direct term R (psi(tot) - psi(ia)) + sum_r log x, and the pathwise term
+            double grad = Rf * (dg_tot - dg_a) + c.part[(long)kPQ0 * c.G + g];
+            for (int r = 0; r < c.R; ++r) {
+                const double gm = c.gam[(long)r * c.G + g];
+                const double x = c.x0_in ? gm
+                                         : (double)fminf(fmaxf((float)(gm * frcp(c.gsum[r])), 1.17549435e-38f),
+                                                         0.99999994f);
+                grad += dirichlet_grad_one(x, ia, tot) * (c.gq[(long)r * c.G + g] - c.sq[r]);
+            }
+            emit_grad<ADAM>(c, 7, g, grad * ia, ak);
+            if (ADAM) iau = c.p[7][g];
+            // normalisers: + log q: R (lgamma(tot) - sum lgamma(ia)); - log p: the prior
+            // concentration is the float32 value of 1 / G on every guide (torch.ones(G) / G)
+            const double pr = (double)(1.0f / (float)c.G_tot);
+            double lg_p, dg_p;
+            lgamma_digamma(pr, lg_p, dg_p);
+            loss_fin += Rf * (lg_p - lg_a);
+            if (g == 0) {
+                double lg_ps, dg_ps;
+                lgamma_digamma(pr * (double)c.G_tot, lg_ps, dg_ps);
+                loss_fin += Rf * (lg_tot - lg_ps);
+            }
+        }
+        if (PREP) {
+            double ia = 0.0;
+            if (in) ia = (double)expf(iau);
+            for (int r = 0; r < c.R; ++r) {
+                double gm = 0.0;
+                if (in) {
+                    if (c.x0_in) {
+                        gm = c.x0_in[(long)r * c.G + g];  // injected draw: already normalised
+                    } else {
+                        Rng rng(c.seed, kSiteQ0, (unsigned long long)r * c.G_tot + (c.g_off + g), s_prep * 256ull);
+                        gm = (double)fmaxf((float)sample_gamma(ia, rng), 1.17549435e-38f);
+                    }
+                    c.gam[(long)r * c.G + g] = gm;
+                }
+                const double tot = block_sum(gm, scratch);
+                if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + r] = tot;
+            }
+            const double tq = block_sum(ia, scratch);
+            if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + c.R] = tq;
         }
     }
     if (c.survival && mixture && (int)blockIdx.x >= n_target_blocks) {
@@ -1417,6 +1481,21 @@ __global__ __launch_bounds__(256) void k_sum_parts(DevArgs c) {
     }
 }
 
+// survival NormalModel: sq[r] = sum_g q_0[r, g] * gq[r, g] (fixed order: strided partials, block tree)
+__global__ __launch_bounds__(1024) void k_sum_q(DevArgs c) {
+    __shared__ double scratch[16];
+    const int r = blockIdx.x;
+    double v = 0.0;
+    for (int g = threadIdx.x; g < c.G; g += blockDim.x) {
+        const double gm = c.gam[(long)r * c.G + g];
+        const double x = c.x0_in ? gm
+                                 : (double)fminf(fmaxf((float)(gm * frcp(c.gsum[r])), 1.17549435e-38f), 0.99999994f);
+        v += x * c.gq[(long)r * c.G + g];
+    }
+    const double tot = block_sum(v, scratch);
+    if (threadIdx.x == 0) c.sq[r] = tot;
+}
+
 // Survival analogue of k_guide (survival_model.py:133-424): component "bin
 // probabilities" are exp(mu_a * t_b) with mu = [u_g, u_g + mu_t]; the control
 // Multinomial sees the alleles after selection up to the control timepoint; the
@@ -1441,9 +1520,13 @@ void k_guide_survival(DevArgs c) {
 
     if (valid) {
         const bool use_bc = (c.flags & kUseBc) != 0;
-        const double mu_t = c.mu_t[c.g2t[g]];
+        const bool q0lik = !MIX && c.surv_q0lik;
+        // survival NormalModel: mu of negative-control guides is forced to 0 (survival_model.py:59-60)
+        const bool negc = q0lik && c.negctrl && c.negctrl[g] != 0;
+        const double mu_t = negc ? 0.0 : c.mu_t[c.g2t[g]];
         const double u = MIX ? c.u_g[g] : 0.0;
         const double mu1 = u + mu_t;
+        const double ia = q0lik ? (double)expf(c.p[7][g]) : 0.0;
         double cp[2] = {1.0, 1.0}, cq[2] = {1.0, 1.0};
         bool cl[2] = {false, false};
         double kacc = 0.0, lpn = 0.0, q0 = 0.0;
@@ -1495,13 +1578,21 @@ void k_guide_survival(DevArgs c) {
                     dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
                 }
             }
+            double x0 = 1.0;
+            if (q0lik) {
+                const double gm = c.gam[(long)r * G + g];
+                x0 = c.x0_in ? gm
+                             : (double)fminf(fmaxf((float)(gm * frcp(c.gsum[r])), 1.17549435e-38f), 0.99999994f);
+                if (c.x0_out) c.x0_out[(long)r * G + g] = x0;
+            }
             double e[B], ge[B], P0[B], P1[B];
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const double tb = c.time[b];
                 P1[b] = exp(mu1 * tb);
                 P0[b] = MIX ? exp(u * tb) : 0.0;
-                e[b] = MIX ? (ACC ? (1.0 - pe1) * P0[b] + pe1 * P1[b] : pi[0] * P0[b] + pi[1] * P1[b]) : P1[b];
+                e[b] = MIX ? (ACC ? (1.0 - pe1) * P0[b] + pe1 * P1[b] : pi[0] * P0[b] + pi[1] * P1[b])
+                           : (q0lik ? P1[b] * x0 : P1[b]);
                 ge[b] = 0.0;
             }
             double nll = 0.0;
@@ -1525,6 +1616,15 @@ void k_guide_survival(DevArgs c) {
                 g1 += ge[b] * P1[b];
             }
             double gmu = pe1 * dmu;
+            if (q0lik) {
+                gmu = negc ? 0.0 : dmu * x0;
+                // - log p(q_0) + log q(q_0): (ia - 1/G) log x per guide; normalisers in k_param
+                const double dconc = ia - (double)(1.0f / (float)c.G_tot);
+                const double lx = flog(x0);
+                nll += dconc * lx;
+                c.gq[(long)r * G + g] = g1 + dconc * frcp(x0);
+                acc[kPQ0] += lx;
+            }
             if (MIX) {
                 double gpi[2] = {g0, g1};
                 if (ACC) {

@@ -20,7 +20,7 @@ import torch
 from . import _lib
 
 PI_NOISE_SD = 0.655  # bean/model/utils.py:133
-POSITIVE = ("mu_scale", "sd_scale", "alpha_pi", "noise_scale", "q0")
+POSITIVE = ("mu_scale", "sd_scale", "alpha_pi", "noise_scale", "q0", "initial_abundance")
 
 
 def _quantile_edges(upper: torch.Tensor, lower: torch.Tensor):
@@ -63,9 +63,15 @@ class HipSVI:
         if family not in _lib.FAMILY:
             raise ValueError(f"unknown model family {family!r}")
         survival = getattr(data, "selection", "sorting") == "survival"
-        if survival and family not in ("ControlNormal", "MixtureNormal"):
+        if survival and family not in ("Normal", "ControlNormal", "MixtureNormal"):
             raise NotImplementedError(
-                f"survival {family} is not implemented in the HIP engine yet (ControlNormal, MixtureNormal are)")
+                f"survival {family} is not implemented in the HIP engine yet (Normal, ControlNormal, MixtureNormal are)")
+        surv_normal = survival and family == "Normal"
+        self.surv_normal = surv_normal
+        if surv_normal and prior_params is not None and "initial_abundance" in prior_params:
+            raise NotImplementedError("prior_params['initial_abundance'] is not supported by the HIP engine")
+        if surv_normal and n_guides_total and n_guides_total != data.n_guides:
+            raise NotImplementedError("the survival NormalModel couples all guides (Dirichlet over guides): single GPU")
         self.survival = survival
         if not torch.cuda.is_available():
             raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
@@ -159,6 +165,16 @@ class HipSVI:
         self._bind("A0", f64(data.a0))
         if survival:
             self._bind("TIMEPOINTS", f64(data.timepoints))
+            if surv_normal:
+                # `mu[data.negctrl_guide_idx, :] = 0.0` (survival_model.py:59-60); indexing with None
+                # (no index given) zeroes every row there, which is kept
+                negmask = torch.zeros(G, dtype=torch.uint8)
+                idx = getattr(data, "negctrl_guide_idx", None)
+                if idx is None:
+                    negmask[:] = 1
+                else:
+                    negmask[torch.as_tensor(np.asarray(idx), dtype=torch.int64)] = 1
+                self._bind("NEGCTRL_MASK", negmask.to(dev).contiguous())
             if mixture:
                 if int(data.control_timepoint.numel()) != n_ctrl:
                     raise ValueError("control_timepoint must list one time per control condition")
@@ -211,6 +227,8 @@ class HipSVI:
             init["sd_scale"] = torch.zeros(pshape)
         if survival and mixture:  # q0 = ones(G) / G (survival_model.py:660-664)
             init["q0"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(G))))
+        if surv_normal:  # initial_abundance = ones(G) / G (survival_model.py:630-634)
+            init["initial_abundance"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(G))))
         if mixture:
             init["alpha_pi"] = torch.zeros((G, A))
             if tiling:  # alpha_pi0[~allele_mask] = epsilon (model.py:643)
@@ -222,7 +240,10 @@ class HipSVI:
         self.grads: Dict[str, torch.Tensor] = {}
         self._m: Dict[str, torch.Tensor] = {}
         self._v: Dict[str, torch.Tensor] = {}
-        for i, name in enumerate(_lib.PARAM_ORDER):
+        order = list(_lib.PARAM_ORDER)
+        if surv_normal:
+            order[order.index("q0")] = "initial_abundance"  # same slot: a positive (G,) Dirichlet concentration
+        for i, name in enumerate(order):
             if name not in init:
                 continue
             p = init[name].to(dev, torch.float32).contiguous()
@@ -249,6 +270,9 @@ class HipSVI:
                 self._noise_out["eps_u"] = torch.zeros(G, dtype=torch.float64, device=dev)
                 self._bind("X0_OUT", self._noise_out["initial_abundance"])
                 self._bind("EPS_U_OUT", self._noise_out["eps_u"])
+            if surv_normal:
+                self._noise_out["q_0"] = torch.zeros((R, G), dtype=torch.float64, device=dev)
+                self._bind("X0_OUT", self._noise_out["q_0"])
             if mixture:
                 self._noise_out["pi"] = torch.zeros((R, G, A), dtype=torch.float64, device=dev)
                 self._bind("PI_OUT", self._noise_out["pi"])
@@ -311,7 +335,10 @@ class HipSVI:
         ``None`` returns to the in-kernel generator."""
         dev = self.device
         names = {"eps_mu": "EPS_MU_IN", "eps_sd": "EPS_SD_IN", "pi": "PI_IN", "eps_noise": "EPS_NOISE_IN",
-                 "initial_abundance": "X0_IN", "eps_u": "EPS_U_IN"}
+                 "eps_u": "EPS_U_IN"}
+        # the draw of the Dirichlet-over-guides site: `initial_abundance` in the survival MixtureNormal
+        # guide, `q_0` (site initial_guide_abundance) in the survival NormalModel
+        names["q_0" if self.surv_normal else "initial_abundance"] = "X0_IN"
         if noise is not None and "mu_negctrl" in noise and "eps_u" not in noise:
             m0, s0 = float(np.float32(self._shape.negctrl_loc)), float(np.float32(self._shape.negctrl_scale))
             noise = dict(noise)

@@ -1,10 +1,9 @@
 """Survival-screen model / guide descriptors (see ``model.py`` for the idea).
 
 Names, arguments and defaults follow ``bean/model/survival_model.py``.  The
-HIP engine implements ``ControlNormal`` and ``MixtureNormal`` (+Acc) for
-survival screens; ``NormalModel`` (``--uniform-edit``) and
-``MultiMixtureNormalModel`` (tiling) are restated in ``oracle/survival.py`` /
-described here but raise ``NotImplementedError`` when fitted.
+HIP engine implements ``Normal`` (``--uniform-edit``), ``ControlNormal`` and
+``MixtureNormal`` (+Acc) for survival screens; ``MultiMixtureNormalModel``
+(tiling) is described here but raises ``NotImplementedError`` when fitted.
 """
 from __future__ import annotations
 

@@ -127,6 +127,8 @@ enum bean_hip_buf {
     BEAN_BUF_TIMEPOINTS,      /* f64 (B)                                         opt  */
     BEAN_BUF_CONTROL_TIME,    /* f64 (C)   timepoint(s) of the control condition opt  */
     BEAN_BUF_LOG_OBS0,        /* f64 (R,G) log((X[:,0,:]+1)/sum): observed initial abundance opt */
+    BEAN_BUF_NEGCTRL_MASK,    /* u8  (G)   survival NormalModel: 1 where the guide is a negative control
+                                 (mu forced to 0, survival_model.py:59-60)                   opt  */
     /* ---- parameters: unconstrained values as Pyro's param store keeps them */
     BEAN_BUF_P_MU_LOC = 32,   /* f32 (T)                                              */
     BEAN_BUF_P_MU_SCALE,      /* f32 (T)   log mu_scale                               */

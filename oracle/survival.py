@@ -154,9 +154,10 @@ def normal_loss(data, params, noise=None, use_bcmatch=True, mask_thres=10, prior
         "initial_guide_abundance": tdist.Dirichlet(ia, validate_args=False).log_prob(q_0).sum(),
         "mu_targets": tdist.Normal(P["mu_loc"], P["mu_scale"]).log_prob(mu_t).sum(),
     }
-    prior_ia = torch.ones(G) / G
+    prior_ia = torch.ones(G) / G  # float32 values, as the reference builds them
     if prior_params is not None and "initial_abundance" in prior_params:
         prior_ia = prior_params["initial_abundance"]
+    prior_ia = prior_ia.to(ia.dtype)  # the float64 checking mode evaluates the same values in float64
     model_lp = {
         "mu_targets": _mu_prior(prior_params).log_prob(mu_t).sum(),
         "initial_guide_abundance": tdist.Dirichlet(prior_ia[None].expand(R, -1), validate_args=False)

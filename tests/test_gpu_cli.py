@@ -71,10 +71,11 @@ def test_sorting_variant_with_accessibility_column(tmp_path):
     assert ((sg["scaled_edit_eff"] >= 1e-3) & (sg["scaled_edit_eff"] <= 1 - 1e-3)).all()
 
 
-@pytest.mark.parametrize("extra", [[], ["--fit-negctrl"]])
+@pytest.mark.parametrize("extra", [[], ["--fit-negctrl"], ["--uniform-edit"], ["--uniform-edit", "--fit-negctrl"]])
 def test_survival_variant_runs(tmp_path, extra):
     d = _run(tmp_path, "survival", "variant", SURV, "--n-iter", "10", "--control-condition=D7", *extra)
-    el = pd.read_csv(f"{d}/bean_element_result.MixtureNormal.csv")
+    label = "Normal" if "--uniform-edit" in extra else "MixtureNormal"
+    el = pd.read_csv(f"{d}/bean_element_result.{label}.csv")
     # this data file lists target var_1 under two target groups, so the target table has one row more
     # than there are fitted targets (13): the reference's column-wise concat pads the last row with NaN
     fitted = el.dropna(subset=["mu"])
