@@ -1,6 +1,6 @@
 """``bean run``: screen -> tensors -> (negative-control fit) -> main fit -> tables.
 
-Follows ``bean/cli/run.py:66-311`` step for step for the variant library design;
+Follows ``bean/cli/run.py:66-311`` step for step (variant and tiling library designs);
 every step delegates to the module that mirrors the reference's.  The fit itself
 runs on the MI355X through ``run_inference`` (``libbean_hip``).
 """
@@ -18,6 +18,7 @@ from ..framework import read_h5ad
 from ..model.readwrite import write_result_table
 from ..model.run import (_check_prior_params, _get_guide_info, _get_guide_target_info, check_args,
                          identify_model_guide, identify_negctrl_model_guide, run_inference)
+from ..model.tiling_info import guide_to_variant_df, variant_table
 from ..preprocessing.screen_data import DATACLASS_DICT
 from ..preprocessing.utils import prepare_bdata
 
@@ -65,22 +66,42 @@ def main(args, return_data=False):
         popt=args.popt,
         use_bcmatch=(not args.ignore_bcmatch),
         negctrl_guide_idx=negctrl_idx,
+        allele_df_key=args.allele_df_key,
+        control_guide_tag=args.control_guide_tag,
     )
     if args.save_raw:
         pkl.dump(bdata, open(f"{prefix}/ndata.pkl", "wb"))
     if return_data:
         return ndata
-    if args.library_design != "variant":
-        raise NotImplementedError("`bean run ... tiling` from an .h5ad is not implemented yet")
     adj_negctrl_idx = None
     control = args.control_condition.split(",")[0]
-    if not args.uniform_edit and "edit_rate" not in ndata.screen.guides.columns:
-        ndata.screen.get_guide_edit_rate(unsorted_condition_label=control, condition_col=args.condition_col)
-    target_info_df = _get_guide_target_info(ndata.screen, args, cols_include=[args.negctrl_col])
-    if args.adjust_confidence_by_negative_control:
-        adj_negctrl_idx = np.where(target_info_df[args.negctrl_col].map(lambda v: str(v).lower())
-                                   == args.negctrl_col_value.lower())[0]
+    if args.library_design == "variant":
+        if not args.uniform_edit and "edit_rate" not in ndata.screen.guides.columns:
+            ndata.screen.get_guide_edit_rate(unsorted_condition_label=control, condition_col=args.condition_col)
+        target_info_df = _get_guide_target_info(ndata.screen, args, cols_include=[args.negctrl_col])
+        if args.adjust_confidence_by_negative_control:
+            adj_negctrl_idx = np.where(target_info_df[args.negctrl_col].map(lambda v: str(v).lower())
+                                       == args.negctrl_col_value.lower())[0]
+    else:
+        # tiling: one row per edit (bean/cli/run.py:155-206)
+        if "edit_rate_norm" not in ndata.screen.guides.columns and "edits" in ndata.screen.layers:
+            ndata.screen.get_guide_edit_rate(unsorted_condition_label=control, condition_col=args.condition_col)
+        splice = None
+        if getattr(args, "splice_site_path", None) is not None:
+            import pandas as pd
+            splice = pd.read_csv(args.splice_site_path).pos
+        target_info_df = variant_table(ndata, ndata.screen.guides.index.values,
+                                       bdata.guides["target_group"].values, control_tag=args.control_guide_tag,
+                                       splice_sites=splice)
+        if args.adjust_confidence_by_negative_control:
+            adj_negctrl_idx = np.where((target_info_df.ref == target_info_df.alt)
+                                       & (target_info_df.coding == "coding"))[0]
+            info(f"Using {len(adj_negctrl_idx)} synonymous variants to adjust confidence.")
     guide_info_df = _get_guide_info(ndata.screen, args, guide_lfc_pseudocount=args.guide_lfc_pseudocount)
+    if args.library_design == "tiling":
+        import pandas as pd
+        guide_info_df = pd.concat([guide_info_df, guide_to_variant_df(target_info_df).reindex(guide_info_df.index)],
+                                  axis=1)
     if args.prior_params is not None:
         model = partial(model, prior_params=_check_prior_params(args.prior_params, ndata))
 

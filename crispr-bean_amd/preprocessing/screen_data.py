@@ -4,7 +4,8 @@ library design (``VariantSorting[Reporter]ScreenData``,
 ``VariantSurvival[Reporter]ScreenData``): sample ordering (replicate, condition),
 bin edges / timepoints, masks, size factors, the trend-fitted Dirichlet-Multinomial
 precisions ``a0`` / ``a0_bcmatch`` / ``pi_a0`` and control allele counts.
-Tiling screens (allele tables -> CSR ``allele_to_edit``) are not built here yet.
+Tiling screens (``TilingSortingReporterScreenData``): the allele tables are turned into the CSR
+``allele_to_edit`` map, allele count tensors and the allele mask by ``alleles.py``.
 
 Reference quirks kept: the control condition always stays among the selected
 samples (``bean/cli/run.py:114``); size factors are normalised column
@@ -19,6 +20,7 @@ import numpy as np
 import pandas as pd
 import torch
 
+from .alleles import allele_count_tensor, build_allele_tensors
 from .alpha0 import fitted_alpha0, fitted_pi_alpha0, pred_alpha0, pred_pi_alpha0
 from .data_class import ScreenTensors
 from .utils import assign_rep_ids_and_sort
@@ -62,6 +64,10 @@ def build_variant_screen_data(
     target_col: str = "target",
     use_bcmatch: bool = True,
     negctrl_guide_idx: Optional[Sequence[int]] = None,
+    library_design: str = "variant",
+    allele_df_key: Optional[str] = None,
+    allele_col: Optional[str] = None,
+    control_guide_tag: Optional[str] = None,
     **_ignored,
 ) -> ScreenTensors:
     replicate_column = "replicate"
@@ -164,7 +170,8 @@ def build_variant_screen_data(
         sample_mask=sample_mask, control_sample_mask=control_sample_mask, repguide_mask=rg,
         size_factor=sf, size_factor_control=sf_control, a0=torch.as_tensor(a0), popt=popt_fit,
     )
-    data.selection, data.library_design = selection, "variant"
+    tiling = library_design == "tiling"
+    data.selection, data.library_design = selection, library_design
     data.screen = screen
     data.screen_control = ctrl
     data.condition_column, data.control_condition, data.target_col = condition_column, control, target_col
@@ -181,10 +188,13 @@ def build_variant_screen_data(
                              "ReporterScreen.samples[time_col]. Check your input ReporterScreen object.")
         data.control_timepoint = torch.as_tensor(ct)
         data.n_timepoints = B
-    lengths = _target_lengths(screen.guides, target_col)
-    data.target_lengths = torch.as_tensor(lengths)
-    data.n_targets = int(len(lengths))
-    data.target_names = list(pd.unique(screen.guides[target_col].astype(str)))
+    if not tiling:
+        lengths = _target_lengths(screen.guides, target_col)
+        data.target_lengths = torch.as_tensor(lengths)
+        data.n_targets = int(len(lengths))
+        data.target_names = list(pd.unique(screen.guides[target_col].astype(str)))
+    else:
+        data.target_lengths = None
     data.negctrl_guide_idx = negctrl_guide_idx
     data.guide_accessibility = None
     if accessibility_col is not None:
@@ -202,12 +212,29 @@ def build_variant_screen_data(
         data.size_factor_bcmatch_control = torch.as_tensor(
             ctrl.samples["size_factor_bcmatch"].to_numpy()).reshape(R, C)
         data.a0_bcmatch = torch.as_tensor(pred_alpha0(Xb, sf_b, popt_fit, sample_mask))
+    if tiling:
+        # TilingReporterScreenData._post_init (data_class.py:574-654)
+        if allele_df_key is None or allele_df_key not in screen.uns:
+            raise ValueError(f"--allele-df-key `{allele_df_key}` is not in the screen's uns: {list(screen.uns)}")
+        at = build_allele_tensors(screen.uns[allele_df_key], list(screen.guides.index), allele_col=allele_col,
+                                  control_guide_tag=control_guide_tag)
+        data.n_max_alleles = at.n_max_alleles
+        data.edit_index = at.edit_index
+        data.n_edits = len(at.edit_index)
+        data.n_targets = data.n_edits
+        data.a2e_ptr, data.a2e_idx, data.allele_mask = at.a2e_ptr, at.a2e_idx, at.allele_mask
+        data.allele_counts = allele_count_tensor(at, samples, list(screen.guides.index),
+                                                 np.asarray(screen.layers["X_bcmatch"]), R, id_col)
+        data.allele_counts_control = allele_count_tensor(at, ctrl.samples, list(screen.guides.index),
+                                                         np.asarray(ctrl.layers["X_bcmatch"]), R, id_col)
+        data.n_alleles_dropped = at.n_dropped
     if reporter:
-        if "edits" not in screen.layers:
-            raise ValueError("the screen has no `edits` layer (reporter editing outcomes)")
-        edited = rbg(ctrl.layers["edits"], C)
-        nonedited = (data.X_bcmatch_control - edited).clamp(min=0)
-        data.allele_counts_control = torch.stack([nonedited, edited], dim=-1)
+        if not tiling:
+            if "edits" not in screen.layers:
+                raise ValueError("the screen has no `edits` layer (reporter editing outcomes)")
+            edited = rbg(ctrl.layers["edits"], C)
+            nonedited = (data.X_bcmatch_control - edited).clamp(min=0)
+            data.allele_counts_control = torch.stack([nonedited, edited], dim=-1)
         if pi_popt is not None:
             pi_a0 = pred_pi_alpha0(data.allele_counts_control, sf_control, pi_popt)
         else:
@@ -217,14 +244,11 @@ def build_variant_screen_data(
     return data
 
 
-def _builder(selection, reporter):
+def _builder(selection, reporter, library_design="variant"):
     def make(screen, **kw):
-        return build_variant_screen_data(screen, selection=selection, reporter=reporter, **kw)
+        return build_variant_screen_data(screen, selection=selection, reporter=reporter,
+                                         library_design=library_design, **kw)
     return make
-
-
-def _not_yet(*_a, **_k):
-    raise NotImplementedError("tiling screens are not yet built from a ReporterScreen in this implementation")
 
 
 # model label -> tensor builder (``DATACLASS_DICT`` of bean/preprocessing/data_class.py:1540-1556)
@@ -236,8 +260,8 @@ DATACLASS_DICT = {
         "MixtureNormal+Acc": _builder("sorting", True),
         "_MixtureNormal+Acc": _builder("sorting", True),
         "MixtureNormalConstPi": _builder("sorting", False),
-        "MultiMixtureNormal": _not_yet,
-        "MultiMixtureNormal+Acc": _not_yet,
+        "MultiMixtureNormal": _builder("sorting", True, "tiling"),
+        "MultiMixtureNormal+Acc": _builder("sorting", True, "tiling"),
     },
     "survival": {
         "Normal": _builder("survival", False),
@@ -245,7 +269,7 @@ DATACLASS_DICT = {
         "_MixtureNormal": _builder("survival", True),
         "MixtureNormal+Acc": _builder("survival", True),
         "_MixtureNormal+Acc": _builder("survival", True),
-        "MultiMixtureNormal": _not_yet,
-        "MultiMixtureNormal+Acc": _not_yet,
+        "MultiMixtureNormal": _builder("survival", True, "tiling"),
+        "MultiMixtureNormal+Acc": _builder("survival", True, "tiling"),
     },
 }

@@ -83,6 +83,40 @@ def test_survival_variant_runs(tmp_path, extra):
     assert np.isfinite(fitted[["mu", "mu_sd", "mu_z"]].values).all() and (fitted["mu_sd"] > 0).all()
 
 
+TILING = os.path.join(os.path.dirname(__file__), "golden", "tiling_mini_screen.h5ad")
+
+
+@pytest.mark.parametrize("extra,label", [
+    ([], "MultiMixtureNormal"),
+    (["--uniform-edit"], "MultiMixtureNormal"),  # tiling ignores --uniform-edit (bean/model/run.py:404-419)
+    (["--fit-negctrl", "--negctrl-col", "strand", "--negctrl-col-value", "neg", "--control-guide-tag", "neg"],
+     "MultiMixtureNormal"),
+    (["--uniform-edit", "--fit-negctrl", "--negctrl-col", "strand", "--negctrl-col-value", "neg",
+      "--control-guide-tag", "neg"], "MultiMixtureNormal"),
+])
+def test_sorting_tiling_runs(tmp_path, extra, label):
+    """The reference's `bean run sorting tiling` invocations (tests/test_run.py:85-150, 218) on its
+    tiling mini-screen with the unfiltered allele table (`--allele-df-key allele_counts`): up to 230
+    alleles per guide there, reduced to the 7 most abundant per guide with a warning."""
+    argv = ["sorting", "tiling", TILING, "--n-iter", "10", "--repguide-mask", "None",
+            "--allele-df-key", "allele_counts"]
+    if "--control-guide-tag" not in extra:
+        argv += ["--control-guide-tag", "None"]
+    with pytest.warns(UserWarning, match="most abundant alleles"):
+        d = _run(tmp_path, *argv, *extra)
+    el = pd.read_csv(f"{d}/bean_element_result.{label}.csv")
+    sg = pd.read_csv(f"{d}/bean_sgRNA_result.{label}.csv")
+    assert len(sg) == 30
+    if label == "MultiMixtureNormal":
+        assert {"edit", "group", "coding", "effective_edit_rate", "editing_guides", "n_guides", "n_coocc",
+                "mu", "mu_sd", "mu_z", "sd"} <= set(el.columns)
+        assert len(el) > 20 and np.isfinite(el[["mu", "mu_sd", "mu_z", "sd"]].values).all()
+        assert (el["n_guides"] >= 1).all() and (el["effective_edit_rate"] >= 0).all()
+        assert "variants" in sg.columns
+    if "--fit-negctrl" in extra:
+        assert {"mu_scaled", "mu_z_scaled"} <= set(el.columns)
+
+
 def test_longer_fit_moves_parameters_and_saves_raw(tmp_path):
     import pickle
 

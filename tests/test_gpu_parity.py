@@ -412,6 +412,26 @@ def test_tiling_elbo_and_gradients_match_oracle(engine, gen_kw, kw):
     _compare_tiling(engine, data, kw)
 
 
+def test_tiling_screen_built_from_h5ad_matches_oracle(engine):
+    """The reference's tiling mini-screen file through the .h5ad reader and the allele-table
+    builder, then ELBO + gradients against the oracle on the same tensors."""
+    import warnings
+
+    from bean_amd.framework import h5ad_io, read_h5ad
+    from bean_amd.preprocessing.screen_data import DATACLASS_DICT
+
+    if not os.path.exists(h5ad_io.HELPER_PYTHON):
+        pytest.skip("no h5py interpreter")
+    s = read_h5ad(os.path.join(os.path.dirname(__file__), "golden", "tiling_mini_screen.h5ad"))
+    s.samples["replicate"] = s.samples["replicate"].astype(str)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        data = DATACLASS_DICT["sorting"]["MultiMixtureNormal"](
+            s, sample_mask_column=None, allele_df_key="allele_counts", control_condition="bulk")
+    assert data.n_max_alleles == 8 and data.n_guides == 30
+    _compare_tiling(engine, data, {})
+
+
 def test_tiling_trajectory_and_fused_loop(engine):
     data = make_sorting_tiling_screen(250, 2, seed=6, n_max_alleles=6)
     n = 20
