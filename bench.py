@@ -97,10 +97,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal on a one-GPU box only: BEAN_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # exchanges over gloo (RCCL refuses two ranks on one device); never set by the driver
+    rehearsal = os.environ.get("BEAN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     data_cpu = make_sorting_variant_screen(
         args.guides, N_REPS, seed=BASE_SEED + 1 + rank, with_accessibility=args.scale_by_acc
