@@ -58,6 +58,7 @@ class bean_hip_shape(ctypes.Structure):
 # enum bean_hip_family / flags / buffer slots (include/bean_hip.h)
 FAMILY = {"Normal": 0, "ControlNormal": 1, "MixtureNormal": 2, "MultiMixtureNormal": 3}
 FLAG_USE_BCMATCH, FLAG_SCALE_BY_ACC, FLAG_FIT_NOISE, FLAG_PRIOR_NORMAL_MU, FLAG_DUMP_PI = 1, 2, 4, 8, 16
+FLAG_NOT_LOSS_OWNER = 32
 BUF = {
     "X": 0, "X_BC": 1, "ALLELE_CTRL": 2, "REPGUIDE": 3, "SIZE_FACTOR": 4, "SIZE_FACTOR_BC": 5,
     "SAMPLE_MASK": 6, "A0": 7, "A0_BC": 8, "PI_A0": 9, "Z_HI": 10, "Z_LO": 11,
@@ -65,6 +66,7 @@ BUF = {
     "PRIOR_MU_LOC": 15, "PRIOR_MU_SCALE": 16, "PRIOR_SD_LOC": 17, "PRIOR_SD_SCALE": 18,
     "A2E_PTR": 19, "A2E_IDX": 20, "E2A_PTR": 21, "E2A_IDX": 22, "ALLELE_MASK": 23,
     "TIMEPOINTS": 24, "CONTROL_TIME": 25, "LOG_OBS0": 26, "NEGCTRL_MASK": 27,
+    "XCHG_GSUM": 28, "XCHG_TGRAD": 29,
     "P": 32, "G": 48, "M": 64, "V": 80,
     "EPS_MU_IN": 96, "EPS_SD_IN": 97, "PI_IN": 98, "EPS_NOISE_IN": 99,
     "EPS_MU_OUT": 100, "EPS_SD_OUT": 101, "PI_OUT": 102, "EPS_NOISE_OUT": 103,
@@ -84,6 +86,10 @@ SYMBOLS = [
     ("bean_hip_elbo_grad", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_void_p]),
     ("bean_hip_adam", c_int32, [c_void_p, c_uint64, c_void_p]),
     ("bean_hip_svi_run", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_int32, c_void_p]),
+    ("bean_hip_sharded_begin", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_void_p]),
+    ("bean_hip_sharded_sums", c_int32, [c_void_p, c_void_p]),
+    ("bean_hip_sharded_guide", c_int32, [c_void_p, c_void_p]),
+    ("bean_hip_sharded_update", c_int32, [c_void_p, c_int32, c_void_p]),
     ("bean_hip_step_bytes", c_uint64, [c_void_p]),
     ("bean_hip_dominant_kernel", c_char_p, [c_void_p]),
     ("bean_hip_set_profile", c_int32, [c_void_p, c_int32]),

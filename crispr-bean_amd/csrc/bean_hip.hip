@@ -36,6 +36,7 @@ struct bean_hip_ctx {
     bool fused_guide;  // false: BEAN_HIP_GUIDE=split selects the sample / lik / pi-terms launches
     bool wave_guide;   // sorting variant families, default: one wave per (guide tile, replicate)
     int* tile_targets_dev;
+    double* gsum_ws;  // library-owned normaliser buffer (replaced by BEAN_BUF_XCHG_GSUM when bound)
     // graph cache
     hipGraphExec_t graph_exec;
     int graph_chunk;
@@ -96,6 +97,8 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_X0_IN: case BEAN_BUF_X0_OUT:
             return ((is_survival(s) && is_mixture(s)) || is_surv_normal(s)) ? 8 * R * G : 0;
         case BEAN_BUF_NEGCTRL_MASK: return is_surv_normal(s) ? G : 0;
+        case BEAN_BUF_XCHG_GSUM: return (is_survival(s) && is_mixture(s)) ? 8 * (R + 1) : 0;
+        case BEAN_BUF_XCHG_TGRAD: return 8 * 2 * T;
         case BEAN_BUF_EPS_U_IN: case BEAN_BUF_EPS_U_OUT: return (is_survival(s) && is_mixture(s)) ? 8 * G : 0;
         case BEAN_BUF_TARGET_OFFSETS: return is_tiling(s) ? 0 : 4 * (T + 1);
         case BEAN_BUF_GUIDE_TO_TARGET: return is_tiling(s) ? 0 : 4 * G;
@@ -160,6 +163,8 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.loss_hist = (double*)P(BEAN_BUF_LOSS_HIST);
     d.time = (const double*)P(BEAN_BUF_TIMEPOINTS);
     d.negctrl = (const uint8_t*)P(BEAN_BUF_NEGCTRL_MASK);
+    if (P(BEAN_BUF_XCHG_GSUM)) d.gsum = (double*)P(BEAN_BUF_XCHG_GSUM);
+    else d.gsum = c->gsum_ws;
     d.ctrl_time = (const double*)P(BEAN_BUF_CONTROL_TIME);
     d.log_obs0 = (const double*)P(BEAN_BUF_LOG_OBS0);
     d.x0_in = (const double*)P(BEAN_BUF_X0_IN);
@@ -247,6 +252,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const bool surv_mix = is_survival(*s) && is_mixture(*s);
     const bool surv_norm = is_surv_normal(*s);
     d.surv_q0lik = surv_norm ? 1 : 0;
+    d.not_loss_owner = (s->flags & BEAN_FLAG_NOT_LOSS_OWNER) ? 1 : 0;
+    c->gsum_ws = nullptr;
     const uint64_t Rr = d.R;
     const uint64_t n_gblk = (G + 255) / 256;
     d.n_gamma_blocks = (int)n_gblk;
@@ -312,11 +319,13 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         d.gam = w; w += Rr * G;
         d.gpart = w; w += n_gblk * (Rr + 1);
         d.gsum = w; w += Rr + 1;
+        c->gsum_ws = d.gsum;
     }
     if (surv_norm) {
         d.gam = w; w += Rr * G;
         d.gpart = w; w += n_gblk * (Rr + 1);
         d.gsum = w; w += Rr + 1;
+        c->gsum_ws = d.gsum;
         d.gq = w; w += Rr * G;
         d.sq = w; w += Rr;
     }
@@ -354,7 +363,8 @@ extern "C" int bean_hip_bind(bean_hip_ctx* c, int slot, void* ptr, uint64_t nbyt
     c->slot_bytes[slot] = ptr ? nbytes : 0;
     sync_devargs(c);
     drop_graph(c);
-    if (slot < BEAN_BUF_P_MU_LOC) c->prepared = false;
+    if (slot < BEAN_BUF_P_MU_LOC && slot != BEAN_BUF_XCHG_GSUM && slot != BEAN_BUF_XCHG_TGRAD)
+        c->prepared = false;  // data changed: the data-only precomputation is stale
     return 0;
 }
 
@@ -428,10 +438,12 @@ static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_block
 }
 
 template <bool FINISH, bool ADAM, bool PREP>
-static void launch_param(bean_hip_ctx* c, hipStream_t stream) {
+static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgrad = nullptr) {
     int ntb, nb;
     grid_param(c, ntb, nb);
-    hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP>), dim3(nb), dim3(256), 0, stream, c->d, ntb);
+    DevArgs d = c->d;
+    d.tgrad = tgrad;
+    hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP>), dim3(nb), dim3(256), 0, stream, d, ntb);
 }
 
 template <int B>
@@ -526,7 +538,14 @@ static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
     }
 }
 
-static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
+// normalisers of the Dirichlet-over-guides draw (survival): gsum from this rank's block partials
+static void launch_sums(bean_hip_ctx* c, hipStream_t stream) {
+    const DevArgs& d = c->d;
+    if (d.survival && (d.family == kMixture || d.surv_q0lik))
+        hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, stream, d);
+}
+
+static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = true) {
     const DevArgs& d = c->d;
     if (!c->fused_guide && !d.survival && d.family != kMultiMixture) {
         launch_guide_split(c, stream);
@@ -537,8 +556,7 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         return;
     }
     const int nw = waves_per_block(c);
-    if (d.survival && (d.family == kMixture || d.surv_q0lik))  // normalisers of the Dirichlet(q0) draw
-        hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, stream, d);
+    if (with_sums) launch_sums(c, stream);
     if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
         const long n = (long)(d.A - 1) * d.G;
         hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
@@ -654,6 +672,61 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
     }
     enqueue_pairs(c, stream, pairs);
     launch_param<true, true, false>(c, stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ---- guide-sharded stepping with exchange points (see bean_hip.h)
+extern "C" int bean_hip_sharded_begin(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
+                                      void* stream_) {
+    if (!c) return fail("bean_hip_sharded_begin: null handle");
+    if (!c->prepared) return fail("bean_hip_sharded_begin: call bean_hip_prepare first");
+    if (check_bound(c, false, true)) return -1;
+    if (first_step + n_steps > c->loss_capacity)
+        return fail("bean_hip_sharded_begin: loss_hist too small for first_step + n_steps");
+    if (is_survival(c->shape) && is_mixture(c->shape) && !c->slot_ptr[BEAN_BUF_XCHG_GSUM])
+        return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_GSUM for a sharded survival MixtureNormal fit");
+    if ((c->shape.family == BEAN_FAMILY_CONTROL_NORMAL || is_tiling(c->shape)) && !c->slot_ptr[BEAN_BUF_XCHG_TGRAD])
+        return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_TGRAD for a sharded ControlNormal / tiling fit");
+    hipStream_t stream = (hipStream_t)stream_;
+    c->d.seed = seed;
+    if (n_steps) HIP_OK(hipMemsetAsync(c->d.loss_hist + first_step, 0, 8 * n_steps, stream));
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d.ctrA, c->d.ctrB,
+                       (unsigned long long)first_step, (unsigned long long)first_step);
+    launch_param<false, false, true>(c, stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bean_hip_sharded_sums(bean_hip_ctx* c, void* stream_) {
+    if (!c) return fail("bean_hip_sharded_sums: null handle");
+    launch_sums(c, (hipStream_t)stream_);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bean_hip_sharded_guide(bean_hip_ctx* c, void* stream_) {
+    if (!c) return fail("bean_hip_sharded_guide: null handle");
+    hipStream_t stream = (hipStream_t)stream_;
+    launch_guide(c, stream, false);
+    if (c->slot_ptr[BEAN_BUF_XCHG_TGRAD]) {
+        int ntb, nb;
+        grid_param(c, ntb, nb);
+        hipLaunchKernelGGL(k_target_reduce, dim3(ntb), dim3(256), 0, stream, c->d,
+                           (double*)c->slot_ptr[BEAN_BUF_XCHG_TGRAD]);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bean_hip_sharded_update(bean_hip_ctx* c, int32_t last, void* stream_) {
+    if (!c) return fail("bean_hip_sharded_update: null handle");
+    hipStream_t stream = (hipStream_t)stream_;
+    const double* tg = (const double*)c->slot_ptr[BEAN_BUF_XCHG_TGRAD];
+    if (last)
+        launch_param<true, true, false>(c, stream, tg);
+    else
+        launch_param<true, true, true>(c, stream, tg);
     HIP_OK(hipGetLastError());
     return 0;
 }

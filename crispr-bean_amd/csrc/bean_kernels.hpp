@@ -122,6 +122,9 @@ struct DevArgs {
     // survival NormalModel: q_0 ~ Dirichlet(initial_abundance) over all guides enters the likelihood
     int surv_q0lik;
     const uint8_t* negctrl;          // (G) guides whose mu is forced to 0
+    // sharded runs with replicated per-target parameters
+    const double* tgrad;             // (2, T) all-reduced likelihood gradients, or null: reduce locally
+    int not_loss_owner;              // 1: another rank adds the loss terms of the replicated parameters
     double *gq;                      // (R, G) d loss / d q_0[r, g]
     double *sq;                      // (R) sum_g q_0[r, g] * gq[r, g]
     int n_gamma_blocks;
@@ -357,6 +360,96 @@ __device__ __forceinline__ void write_phi_entry(const DevArgs& c, int t, int b, 
     c.tabPy[o] = -(ufh - ufl) * inv * dsig_dy;
 }
 
+// Target handled by this thread of a k_param / k_target_reduce target block, and whether the
+// thread is the one that owns the target's parameters.
+__device__ __forceinline__ void target_of_thread(const DevArgs& c, int& t, bool& active) {
+    if (c.wide_targets) {
+        t = blockIdx.x;
+        active = threadIdx.x == 0;
+    } else {
+        t = (blockIdx.x * blockDim.x + threadIdx.x) / kLanesPerTarget;
+        active = t < c.T && (threadIdx.x & (kLanesPerTarget - 1)) == 0;
+    }
+}
+
+// Likelihood gradient of one target w.r.t. its drawn mu_t / y_t: the guide -> target segmented
+// sum (a8), in a fixed order.  Valid in the `active` thread.
+__device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool active, double* scratch,
+                                                 double& gmu, double& gy) {
+    gmu = 0.0;
+    gy = 0.0;
+    if (c.wide_targets) {
+        const int g0 = c.toff[t], g1 = c.toff[t + 1];
+        double a = 0.0, b = 0.0;
+        for (int g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+            a += lik_row(c, kPGmu, g);
+            b += lik_row(c, kPGy, g);
+        }
+        gmu = block_sum(a, scratch);
+        gy = block_sum(b, scratch);
+        return;
+    }
+    if (active) {
+        if (c.family == kMultiMixture) {
+            // edit <- alleles containing it (transposed CSR): the backward of
+            // allele_to_edit @ mu_edits and ||allele_to_edit * sd_edits|| (model.py:618-622)
+            const int A1 = c.A - 1;
+            const double sd = exp(c.y_t[t]);
+            for (int k = c.e2a_ptr[t]; k < c.e2a_ptr[t + 1]; ++k) {
+                const int slot = c.e2a_idx[k];
+                const long o = (long)(slot % A1) * c.G + slot / A1;
+                gmu += c.part[(long)kTGmu * c.G + o];
+                // d sigma_a / d y_e = sd_e^2 / sigma_a
+                gy += c.part[(long)kTGsig * c.G + o] * sd * sd / c.sig_a[o];
+            }
+        } else if (!c.wrow) {
+            const int g0 = c.toff[t], g1 = c.toff[t + 1];
+            for (int g = g0; g < g1; ++g) {
+                gmu += lik_row(c, kPGmu, g);
+                gy += lik_row(c, kPGy, g);
+            }
+        }
+    }
+    if (c.wrow) {
+        // wave form: the (guide, replicate) rows of the target are spread over its lane
+        // group and summed by a fixed shuffle tree (deterministic, shard independent)
+        const int lg = threadIdx.x & (kLanesPerTarget - 1);
+        double a = 0.0, b = 0.0;
+        if (t < c.T) {
+            const int g0 = c.toff[t], ng = c.toff[t + 1] - g0;
+            const int n = ng * c.R;
+            for (int i = lg; i < n; i += kLanesPerTarget) {
+                const int r = i / ng, g = g0 + (i - r * ng);
+                a += c.wrow[((long)kPGmu * c.R + r) * c.G + g];
+                b += c.wrow[((long)kPGy * c.R + r) * c.G + g];
+            }
+        }
+#pragma unroll
+        for (int off = kLanesPerTarget / 2; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, kLanesPerTarget);
+            b += __shfl_xor(b, off, kLanesPerTarget);
+        }
+        gmu = a;
+        gy = b;
+    }
+}
+
+// Sharded runs of families whose per-target parameters are replicated on every rank
+// (ControlNormal, tiling per-edit parameters): this rank's part of every target's likelihood
+// gradient, (2, T) doubles, for the host to all-reduce before k_param.
+__global__ __launch_bounds__(256) void k_target_reduce(DevArgs c, double* out) {
+    __shared__ double scratch[16];
+    int t;
+    bool active;
+    target_of_thread(c, t, active);
+    double gmu, gy;
+    target_grad_sums(c, t, active, scratch, gmu, gy);
+    if (active) {
+        out[t] = gmu;
+        out[c.T + t] = gy;
+    }
+}
+
 // -------------------------------------------------------------------- k_param
 // grid = n_target_blocks + n_guide_blocks, 256 threads.
 template <bool FINISH, bool ADAM, bool PREP>
@@ -378,64 +471,17 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
         int t;
         bool active;
         double gmu = 0.0, gy = 0.0, tab_mu = 0.0, tab_y = 0.0;
-        if (c.wide_targets) {
-            t = blockIdx.x;
-            active = threadIdx.x == 0;
-            if (FINISH) {
-                const int g0 = c.toff[t], g1 = c.toff[t + 1];
-                double a = 0.0, b = 0.0;
-                for (int g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
-                    a += lik_row(c, kPGmu, g);
-                    b += lik_row(c, kPGy, g);
+        target_of_thread(c, t, active);
+        if (FINISH) {
+            if (c.tgrad) {
+                // sharded run of a family whose per-target parameters are shared across shards: the
+                // sums were formed by k_target_reduce and all-reduced by the host
+                if (active) {
+                    gmu = c.tgrad[t];
+                    gy = c.tgrad[c.T + t];
                 }
-                gmu = block_sum(a, scratch);
-                gy = block_sum(b, scratch);
-            }
-        } else {
-            t = (blockIdx.x * blockDim.x + threadIdx.x) / kLanesPerTarget;
-            active = t < c.T && (threadIdx.x & (kLanesPerTarget - 1)) == 0;
-            if (FINISH && active) {
-                if (c.family == kMultiMixture) {
-                    // edit <- alleles containing it (transposed CSR): the backward of
-                    // allele_to_edit @ mu_edits and ||allele_to_edit * sd_edits|| (model.py:618-622)
-                    const int A1 = c.A - 1;
-                    const double sd = exp(c.y_t[t]);
-                    for (int k = c.e2a_ptr[t]; k < c.e2a_ptr[t + 1]; ++k) {
-                        const int slot = c.e2a_idx[k];
-                        const long o = (long)(slot % A1) * c.G + slot / A1;
-                        gmu += c.part[(long)kTGmu * c.G + o];
-                        // d sigma_a / d y_e = sd_e^2 / sigma_a
-                        gy += c.part[(long)kTGsig * c.G + o] * sd * sd / c.sig_a[o];
-                    }
-                } else if (!c.wrow) {
-                    const int g0 = c.toff[t], g1 = c.toff[t + 1];
-                    for (int g = g0; g < g1; ++g) {
-                        gmu += lik_row(c, kPGmu, g);
-                        gy += lik_row(c, kPGy, g);
-                    }
-                }
-            }
-            if (FINISH && c.wrow) {
-                // wave form: the (guide, replicate) rows of the target are spread over its lane
-                // group and summed by a fixed shuffle tree (deterministic, shard independent)
-                const int lg = threadIdx.x & (kLanesPerTarget - 1);
-                double a = 0.0, b = 0.0;
-                if (t < c.T) {
-                    const int g0 = c.toff[t], ng = c.toff[t + 1] - g0;
-                    const int n = ng * c.R;
-                    for (int i = lg; i < n; i += kLanesPerTarget) {
-                        const int r = i / ng, g = g0 + (i - r * ng);
-                        a += c.wrow[((long)kPGmu * c.R + r) * c.G + g];
-                        b += c.wrow[((long)kPGy * c.R + r) * c.G + g];
-                    }
-                }
-#pragma unroll
-                for (int off = kLanesPerTarget / 2; off > 0; off >>= 1) {
-                    a += __shfl_xor(a, off, kLanesPerTarget);
-                    b += __shfl_xor(b, off, kLanesPerTarget);
-                }
-                gmu = a;
-                gy = b;
+            } else {
+                target_grad_sums(c, t, active, scratch, gmu, gy);
             }
         }
         if (active && c.survival) {
@@ -797,6 +843,9 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
         }
     }
     if (FINISH) {
+        // replicated per-target parameters (sharded ControlNormal / tiling): their prior and entropy
+        // terms are counted by one rank only
+        if ((int)blockIdx.x < n_target_blocks && c.not_loss_owner) loss_fin = 0.0;
         const double tot = block_sum(loss_fin, scratch);
         if (threadIdx.x == 0) {
             double add = tot;

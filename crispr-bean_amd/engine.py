@@ -59,6 +59,8 @@ class HipSVI:
         target_offset: int = 0,
         n_guides_total: int = 0,
         mu_negctrl=(0.0, 0.1),
+        t0_totals: Optional[torch.Tensor] = None,
+        loss_owner: bool = True,
     ):
         if family not in _lib.FAMILY:
             raise ValueError(f"unknown model family {family!r}")
@@ -129,6 +131,8 @@ class HipSVI:
             flags |= _lib.FLAG_FIT_NOISE
         if dump_noise:
             flags |= _lib.FLAG_DUMP_PI
+        if not loss_owner:
+            flags |= _lib.FLAG_NOT_LOSS_OWNER
         self.prior_params = prior_params
         if prior_params is not None and ("mu_loc" in prior_params or "mu_scale" in prior_params):
             flags |= _lib.FLAG_PRIOR_NORMAL_MU
@@ -181,9 +185,14 @@ class HipSVI:
                 self._bind("CONTROL_TIME", f64(data.control_timepoint))
                 # observed initial abundance (survival_model.py:310), formed in float32 as the reference does
                 x_t0 = data.X[:, 0, :].to(torch.float32) + 1
-                obs0 = x_t0 / x_t0.sum(-1, keepdim=True)
                 if n_guides_total and n_guides_total != G:
-                    raise NotImplementedError("guide-sharded survival fits need the all-reduced t0 totals")
+                    # guide shard: the normaliser is the whole screen's (R,) total of X[:, 0, :] + 1
+                    if t0_totals is None:
+                        raise ValueError("a guide-sharded survival fit needs t0_totals (all-reduced sums of X[:, 0, :] + 1)")
+                    tot0 = torch.as_tensor(t0_totals).to(torch.float32).reshape(-1, 1).to(x_t0.device)
+                else:
+                    tot0 = x_t0.sum(-1, keepdim=True)
+                obs0 = x_t0 / tot0
                 self._bind("LOG_OBS0", f64(torch.log(obs0.double())))
         else:
             z_hi, z_lo = _quantile_edges(data.upper_bounds, data.lower_bounds)
@@ -225,8 +234,9 @@ class HipSVI:
         if not survival:  # survival models have no sd latent (bean/cli/run.py:305)
             init["sd_loc"] = torch.zeros(pshape)
             init["sd_scale"] = torch.zeros(pshape)
-        if survival and mixture:  # q0 = ones(G) / G (survival_model.py:660-664)
-            init["q0"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(G))))
+        if survival and mixture:  # q0 = ones(G) / G over the WHOLE screen (survival_model.py:660-664)
+            g_all = int(n_guides_total) if n_guides_total else G
+            init["q0"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(g_all))))
         if surv_normal:  # initial_abundance = ones(G) / G (survival_model.py:630-634)
             init["initial_abundance"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(G))))
         if mixture:
@@ -316,6 +326,49 @@ class HipSVI:
 
     def _on_stream(self):
         return HipSVI._StreamScope(self)
+
+    # ------------------------------------------------- guide-sharded stepping
+    def exchange_buffers(self) -> Dict[str, torch.Tensor]:
+        """Allocate and bind the exchange buffers this family needs when its guides are sharded
+        over ranks (``bean_hip_sharded_*``): ``gsum`` (survival MixtureNormal) and/or ``tgrad``
+        (ControlNormal, tiling).  Empty for the families that need no exchange."""
+        if getattr(self, "_xchg", None) is None:
+            self._xchg = {}
+            R = self.data.n_reps
+            if self.survival and self.family == "MixtureNormal":
+                self._xchg["gsum"] = torch.zeros(R + 1, dtype=torch.float64, device=self.device)
+                self._bind("XCHG_GSUM", self._xchg["gsum"])
+            if self.family in ("ControlNormal", "MultiMixtureNormal"):
+                self._xchg["tgrad"] = torch.zeros(2 * self.T, dtype=torch.float64, device=self.device)
+                self._bind("XCHG_TGRAD", self._xchg["tgrad"])
+        return self._xchg
+
+    def run_exchanged(self, n_steps: int, all_reduce, seed: int = 101, first_step: Optional[int] = None):
+        """``n_steps`` SVI steps of one guide shard; ``all_reduce(tensor)`` must sum the tensor over
+        the ranks in place on the current stream (``torch.distributed.all_reduce``)."""
+        first = self.steps_done if first_step is None else int(first_step)
+        if first + n_steps > self.loss_hist.numel():
+            raise ValueError("loss history too small: raise num_steps / loss_capacity")
+        x = self.exchange_buffers()
+        sp = self._sptr()
+        with self._on_stream(), torch.cuda.stream(self.stream):
+            _lib.check(self.lib.bean_hip_sharded_begin(self._h, int(seed), first, int(n_steps), sp), "sharded_begin")
+            for i in range(n_steps):
+                _lib.check(self.lib.bean_hip_sharded_sums(self._h, sp), "sharded_sums")
+                if "gsum" in x:
+                    all_reduce(x["gsum"])
+                _lib.check(self.lib.bean_hip_sharded_guide(self._h, sp), "sharded_guide")
+                if "tgrad" in x:
+                    all_reduce(x["tgrad"])
+                _lib.check(self.lib.bean_hip_sharded_update(self._h, 1 if i == n_steps - 1 else 0, sp),
+                           "sharded_update")
+        self.steps_done = first + n_steps
+
+    # the four phases, for drivers that interleave several engines in one process (tests)
+    def phase(self, name: str, *args):
+        fn = getattr(self.lib, "bean_hip_sharded_" + name)
+        with self._on_stream():
+            _lib.check(fn(self._h, *args, self._sptr()), "sharded_" + name)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -110,14 +110,17 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
     device = torch.device("cuda", torch.cuda.current_device())
     spec = _resolve(model)
     # ControlNormal has screen-wide scalar parameters and only sees the (small)
-    # negative-control subset: every rank fits it redundantly instead of sharding
-    sharded = world > 1 and spec.family != "ControlNormal"
+    # negative-control subset: every rank fits it redundantly instead of sharding (the engine can
+    # shard it - bean_hip_sharded_* - but a per-step collective costs more than the fit).  The
+    # survival NormalModel couples all guides through its Dirichlet-over-guides draw: same.
+    redundant = spec.family == "ControlNormal" or (spec.selection == "survival" and spec.family == "Normal")
+    sharded = world > 1 and not redundant
     engines = []
 
-    def factory(shard_data, shard, n_total):
+    def factory(shard_data, shard, n_total, **extra):
         eng = build_engine(
             model, guide, shard_data.to(device), initial_lr=initial_lr, gamma=gamma, num_steps=num_steps,
-            device=device, guide_offset=shard[0], target_offset=shard[2], n_guides_total=n_total,
+            device=device, guide_offset=shard[0], target_offset=shard[2], n_guides_total=n_total, **extra,
         )
         engines.append(eng)
         return eng

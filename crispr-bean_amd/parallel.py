@@ -16,6 +16,18 @@ state are shard-local and no gradient crosses GPUs.  What is exchanged:
 Random streams are keyed by global guide/target indices
 (``bean_hip_shape.guide_offset`` ...), so an N-GPU fit reproduces the 1-GPU fit
 bit for bit.
+
+Families in which something IS shared across shards step through
+``HipSVI.run_exchanged`` instead, with one small all-reduce at each exchange point of the step:
+
+* tiling (``MultiMixtureNormal``): the per-edit parameters are replicated on every rank and the
+  guides are cut anywhere; per step one all-reduce of the per-edit likelihood gradients
+  ``(2, E)`` float64 between the guide kernel and the parameter update (every rank then applies the
+  same ClippedAdam update); rank 0 counts the replicated parameters' prior/entropy terms;
+* survival ``MixtureNormal``: target-aligned shards as above, plus per step one all-reduce of the
+  ``R + 1`` normalisers of the Dirichlet-over-all-guides draw; the observed-abundance totals are
+  formed once from the whole screen.
+These fits agree with the single-GPU fit up to the regrouping of float64 sums.
 """
 from __future__ import annotations
 
@@ -58,6 +70,13 @@ def plan_shards(target_lengths: Sequence[int], world_size: int) -> List[Shard]:
     return shards
 
 
+def plan_guide_shards(n_guides: int, world_size: int, n_targets: int = 0) -> List[Shard]:
+    """Near-equal contiguous guide ranges for families whose per-target parameters are replicated
+    (tiling): no target alignment is needed; every shard sees all ``n_targets`` targets."""
+    cuts = [round(k * n_guides / world_size) for k in range(world_size + 1)]
+    return [(cuts[k], cuts[k + 1], 0, n_targets) for k in range(world_size)]
+
+
 def shard_screen(data, shard: Shard):
     """Per-rank view of the screen.  Per-sample tensors (size factors, masks,
     bin edges) are global and shared; per-guide tensors are sliced."""
@@ -98,7 +117,7 @@ class _Group:
 
 
 PER_TARGET = ("mu_loc", "mu_scale", "sd_loc", "sd_scale")
-PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale")
+PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale", "q0")
 
 
 def run_sharded(
@@ -120,17 +139,31 @@ def run_sharded(
     the WHOLE screen on every rank.
     """
     grp = _Group(group)
-    shards = plan_shards(data.target_lengths.cpu().numpy(), grp.world)
+    replicated_targets = getattr(data, "target_lengths", None) is None  # tiling: per-edit parameters
+    if replicated_targets:
+        shards = plan_guide_shards(data.n_guides, grp.world, getattr(data, "n_targets", 0))
+    else:
+        shards = plan_shards(data.target_lengths.cpu().numpy(), grp.world)
     mine = shards[grp.rank]
     if mine[1] - mine[0] == 0:
         raise ValueError(
             f"rank {grp.rank} received no guides: {data.n_targets} targets cannot feed {grp.world} ranks"
         )
-    eng = engine_factory(shard_screen(data, mine), mine, data.n_guides)
+    extra = {}
+    if replicated_targets:
+        extra["loss_owner"] = grp.rank == 0
+    if getattr(data, "selection", "sorting") == "survival":
+        # observed initial abundance is normalised over the whole screen (survival_model.py:306-311)
+        extra["t0_totals"] = (data.X[:, 0, :].to(torch.float32) + 1).sum(-1)
+    eng = engine_factory(shard_screen(data, mine), mine, data.n_guides, **extra)
+    exchanged = bool(eng.exchange_buffers()) if hasattr(eng, "exchange_buffers") else False
     done = 0
     while done < num_steps:
         k = min(report_every, num_steps - done)
-        eng.run(k, seed=seed)
+        if exchanged:
+            eng.run_exchanged(k, grp.all_reduce_sum, seed=seed)
+        else:
+            eng.run(k, seed=seed)
         window = eng.loss_hist[done : done + k]
         stream = getattr(eng, "stream", None)
         if stream is not None:
@@ -147,6 +180,9 @@ def run_sharded(
     t_sizes = [s[3] - s[2] for s in shards]
     whole: Dict[str, torch.Tensor] = {}
     for name, t in local.items():
+        if replicated_targets and name not in PER_GUIDE:
+            whole[name] = t  # identical on every rank
+            continue
         sizes = g_sizes if name in PER_GUIDE else t_sizes
         whole[name] = grp.all_gather_rows(t.contiguous(), sizes)
     eng.close()

@@ -62,7 +62,9 @@ enum bean_hip_flags {
     BEAN_FLAG_SCALE_BY_ACC = 2,    /* scale_pi_by_accessibility (utils.py:106-178)         */
     BEAN_FLAG_FIT_NOISE = 4,       /* guide learns noise_loc/noise_scale (utils.py:144-155) */
     BEAN_FLAG_PRIOR_NORMAL_MU = 8, /* --prior-params: Normal instead of Laplace (model.py:408-420) */
-    BEAN_FLAG_DUMP_PI = 16         /* write the Dirichlet draws to BEAN_BUF_PI_OUT (tests)  */
+    BEAN_FLAG_DUMP_PI = 16,        /* write the Dirichlet draws to BEAN_BUF_PI_OUT (tests)  */
+    BEAN_FLAG_NOT_LOSS_OWNER = 32  /* guide-sharded fit of a family with replicated per-target
+                                      parameters: another rank counts their prior/entropy terms */
 };
 
 typedef struct bean_hip_shape {
@@ -129,6 +131,11 @@ enum bean_hip_buf {
     BEAN_BUF_LOG_OBS0,        /* f64 (R,G) log((X[:,0,:]+1)/sum): observed initial abundance opt */
     BEAN_BUF_NEGCTRL_MASK,    /* u8  (G)   survival NormalModel: 1 where the guide is a negative control
                                  (mu forced to 0, survival_model.py:59-60)                   opt  */
+    /* exchange buffers of guide-sharded fits (bean_hip_sharded_*): the library writes this rank's
+       sums, the caller all-reduces them over the ranks, the library reads the totals */
+    BEAN_BUF_XCHG_GSUM,       /* f64 (R+1) survival MixtureNormal: sum_g of the Dirichlet(q0) site's gamma
+                                 draws per replicate, sum_g q0                               opt  */
+    BEAN_BUF_XCHG_TGRAD,      /* f64 (2,T) ControlNormal / tiling: per-target likelihood gradient opt  */
     /* ---- parameters: unconstrained values as Pyro's param store keeps them */
     BEAN_BUF_P_MU_LOC = 32,   /* f32 (T)                                              */
     BEAN_BUF_P_MU_SCALE,      /* f32 (T)   log mu_scale                               */
@@ -215,6 +222,26 @@ int bean_hip_adam(bean_hip_ctx* ctx, uint64_t t, void* stream);
  * graph_chunk steps when graph_chunk > 0 (eager launches when 0). */
 int bean_hip_svi_run(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step,
                      uint64_t n_steps, int32_t graph_chunk, void* stream);
+
+/* The same loop for guide-sharded fits of families in which something is shared across the
+ * shards (the reference is single-process, so there is no interface to
+ * mirror).  The step is cut at its exchange points; after each call that names a buffer the
+ * caller all-reduces (sum) that caller-owned buffer over the ranks, on the same stream:
+ *
+ *   bean_hip_sharded_begin(first_step, n_steps)     once per run: zero the loss window, draw step 0
+ *   per step:
+ *     bean_hip_sharded_sums      -> BEAN_BUF_XCHG_GSUM   (survival MixtureNormal: normalisers of the
+ *                                                         Dirichlet-over-guides draw; no-op otherwise)
+ *     bean_hip_sharded_guide     -> BEAN_BUF_XCHG_TGRAD  (ControlNormal, tiling: per-target likelihood
+ *                                                         gradients; not written when the slot is unbound)
+ *     bean_hip_sharded_update(last)                       gradients, ClippedAdam, draws of the next step
+ *
+ * Families whose parameters are all per-target or per-guide with target-aligned shards (sorting
+ * Normal / MixtureNormal) need none of this: bean_hip_svi_run on every rank is the sharded fit. */
+int bean_hip_sharded_begin(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step, uint64_t n_steps, void* stream);
+int bean_hip_sharded_sums(bean_hip_ctx* ctx, void* stream);
+int bean_hip_sharded_guide(bean_hip_ctx* ctx, void* stream);
+int bean_hip_sharded_update(bean_hip_ctx* ctx, int32_t last, void* stream);
 
 /* Introspection for bench.py / DESIGN.md: algorithmic bytes one step moves
  * (each input read once, each parameter and moment read and written once) and

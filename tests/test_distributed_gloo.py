@@ -149,3 +149,114 @@ def test_empty_rank_is_an_error():
     data = make_sorting_variant_screen(6, 2, seed=9, guides_per_target=3)  # 2 targets
     shards = parallel.plan_shards(data.target_lengths.numpy(), 4)
     assert [s[1] - s[0] for s in shards].count(0) == 2
+
+
+# ------------------------------------------------- exchange families (tiling, survival)
+class ExchangeEngine:
+    """Minimal stand-in with the interface of a HipSVI whose family needs per-step exchanges: the
+    "fit" is arithmetic whose result depends on every rank's data only through the all-reduced
+    buffer, so the plumbing of run_sharded (shard plan, extras, per-step all-reduce, gathering) is
+    what is checked."""
+
+    stream = None
+
+    def __init__(self, data, shard, n_total, replicated, **extra):
+        self.data, self.shard, self.extra = data, shard, extra
+        self.replicated = replicated
+        self.xchg = {"tgrad" if replicated else "gsum": torch.zeros(3, dtype=torch.float64)}
+        self.loss_hist = torch.zeros(64, dtype=torch.float64)
+        self.steps_done = 0
+        self.shared = torch.zeros(3, dtype=torch.float64)
+        self.per_guide = torch.zeros(data.n_guides, 2)
+
+    def exchange_buffers(self):
+        return self.xchg
+
+    def run_exchanged(self, k, all_reduce, seed=101):
+        buf = next(iter(self.xchg.values()))
+        for _ in range(k):
+            s = self.steps_done
+            buf[:] = torch.tensor([self.data.X.sum(), self.data.n_guides, s + 1.0], dtype=torch.float64)
+            all_reduce(buf)
+            self.shared += buf
+            self.per_guide += self.data.a0[:, None].float() * (s + 1)
+            self.loss_hist[s] = float(self.data.n_guides)
+            self.steps_done += 1
+
+    def run(self, *a, **k):
+        raise AssertionError("exchange families must step through run_exchanged")
+
+    def constrained(self):
+        name = "mu_loc" if self.replicated else "q0"
+        out = {"alpha_pi": self.per_guide.clone()}
+        if self.replicated:
+            out["mu_loc"] = self.shared.clone()
+        else:
+            out["q0"] = self.per_guide[:, 0].clone()
+            out["mu_loc"] = torch.full((self.data.n_targets, 1), float(self.shared[0]))
+        return out
+
+    def close(self):
+        pass
+
+
+def _exchange_worker(rank, world, port, out_dir, kind):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if kind == "tiling":
+            from bean_amd.preprocessing.synthetic import make_sorting_tiling_screen
+            data = make_sorting_tiling_screen(61, 2, seed=5, n_max_alleles=4)
+        else:
+            from bean_amd.preprocessing.synthetic import make_survival_variant_screen
+            data = make_survival_variant_screen(64, 2, seed=5)
+        seen = {}
+
+        def factory(d, shard, gtot, **extra):
+            seen.update(extra=extra, shard=shard, n=d.n_guides)
+            return ExchangeEngine(d, shard, gtot, kind == "tiling", **extra)
+
+        whole, losses = parallel.run_sharded(factory, data, 5, seed=3, report_every=2)
+        extra = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in seen["extra"].items()}
+        torch.save({"params": whole, "losses": losses, "extra": extra, "shard": seen["shard"], "n": seen["n"]},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("kind", ["tiling", "survival"])
+def test_two_rank_exchange_families_plumbing(tmp_path, kind):
+    world = 2
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path), kind), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    if kind == "tiling":
+        from bean_amd.preprocessing.synthetic import make_sorting_tiling_screen
+        data = make_sorting_tiling_screen(61, 2, seed=5, n_max_alleles=4)
+        # guides cut anywhere, every shard sees all edits, rank 0 owns the replicated loss terms
+        assert [o["shard"] for o in outs] == [(0, 30, 0, data.n_targets), (30, 61, 0, data.n_targets)]
+        assert [o["extra"]["loss_owner"] for o in outs] == [True, False]
+    else:
+        from bean_amd.preprocessing.synthetic import make_survival_variant_screen
+        data = make_survival_variant_screen(64, 2, seed=5)
+        want = (data.X[:, 0, :].float() + 1).sum(-1).tolist()
+        for o in outs:  # whole-screen t0 totals on every rank, target-aligned cuts
+            assert o["extra"]["t0_totals"] == want and "loss_owner" not in o["extra"]
+        assert outs[0]["shard"][1] == outs[1]["shard"][0] and outs[1]["shard"][1] == 64
+    assert sum(o["n"] for o in outs) == data.n_guides
+    # the per-step all-reduce summed both ranks' buffers: X total, guide total, step counter x 2
+    steps = 5
+    shared = torch.tensor([float(data.X.sum()) * steps, data.n_guides * steps, 2.0 * sum(range(1, steps + 1))],
+                          dtype=torch.float64)
+    for o in outs:
+        assert o["losses"] == [float(data.n_guides)] * steps  # loss windows all-reduced
+        assert o["params"]["alpha_pi"].shape == (data.n_guides, 2)  # per-guide: gathered
+        np.testing.assert_allclose(o["params"]["alpha_pi"][:, 0].numpy(),
+                                   data.a0.float().numpy() * sum(range(1, steps + 1)), rtol=1e-6)
+        if kind == "tiling":
+            np.testing.assert_allclose(o["params"]["mu_loc"].numpy(), shared.numpy(), rtol=1e-12)  # replicated
+        else:
+            assert o["params"]["q0"].shape == (data.n_guides,)  # per-guide q0 gathered
+            assert o["params"]["mu_loc"].shape == (data.n_targets, 1)  # per-target: gathered by target counts
+            np.testing.assert_allclose(o["params"]["mu_loc"].numpy(), float(shared[0]), rtol=1e-12)
