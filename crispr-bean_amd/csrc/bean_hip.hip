@@ -93,11 +93,11 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_Z_HI: case BEAN_BUF_Z_LO: return is_survival(s) ? 0 : 8 * B;
         case BEAN_BUF_TIMEPOINTS: return is_survival(s) ? 8 * B : 0;
         case BEAN_BUF_CONTROL_TIME: return (is_survival(s) && is_mixture(s)) ? 8 * C : 0;
-        case BEAN_BUF_LOG_OBS0: return (is_survival(s) && is_mixture(s)) ? 8 * R * G : 0;
+        case BEAN_BUF_LOG_OBS0: return (is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) ? 8 * R * G : 0;
         case BEAN_BUF_X0_IN: case BEAN_BUF_X0_OUT:
-            return ((is_survival(s) && is_mixture(s)) || is_surv_normal(s)) ? 8 * R * G : 0;
+            return ((is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) || is_surv_normal(s)) ? 8 * R * G : 0;
         case BEAN_BUF_NEGCTRL_MASK: return is_surv_normal(s) ? G : 0;
-        case BEAN_BUF_XCHG_GSUM: return (is_survival(s) && is_mixture(s)) ? 8 * (R + 1) : 0;
+        case BEAN_BUF_XCHG_GSUM: return (is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) ? 8 * (R + 1) : 0;
         case BEAN_BUF_XCHG_TGRAD: return 8 * 2 * T;
         case BEAN_BUF_EPS_U_IN: case BEAN_BUF_EPS_U_OUT: return (is_survival(s) && is_mixture(s)) ? 8 * G : 0;
         case BEAN_BUF_TARGET_OFFSETS: return is_tiling(s) ? 0 : 4 * (T + 1);
@@ -187,8 +187,6 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (!s || !out) return fail("bean_hip_create: null argument");
     if (s->selection != BEAN_SELECTION_SORTING && s->selection != BEAN_SELECTION_SURVIVAL)
         return fail("bean_hip_create: unknown selection");
-    if (is_survival(*s) && s->family == BEAN_FAMILY_MULTI_MIXTURE)
-        return fail("bean_hip_create: survival screens support Normal, ControlNormal and MixtureNormal in this build");
     if (is_surv_normal(*s) && s->n_guides_total > 0 && s->n_guides_total != s->n_guides)
         return fail("bean_hip_create: the survival NormalModel couples all guides and cannot be guide-sharded");
     if (is_survival(*s) && !(s->negctrl_scale > 0.0)) return fail("bean_hip_create: negctrl_scale must be > 0");
@@ -249,7 +247,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const uint64_t A1 = is_tiling(*s) ? (uint64_t)(d.A - 1) : 0;
     const uint64_t n_tab = is_tiling(*s) ? A1 * G : T;  // table columns: allele slots or targets
     const uint64_t n_part = is_tiling(*s) ? (uint64_t)kTNumPart : (uint64_t)kNumPart;
-    const bool surv_mix = is_survival(*s) && is_mixture(*s);
+    const bool surv_mix = is_survival(*s) && s->family == BEAN_FAMILY_MIXTURE_NORMAL;
+    const bool surv_tiling = is_survival(*s) && is_tiling(*s);
     const bool surv_norm = is_surv_normal(*s);
     d.surv_q0lik = surv_norm ? 1 : 0;
     d.not_loss_owner = (s->flags & BEAN_FLAG_NOT_LOSS_OWNER) ? 1 : 0;
@@ -258,7 +257,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const uint64_t n_gblk = (G + 255) / 256;
     d.n_gamma_blocks = (int)n_gblk;
     const uint64_t n_surv = (surv_mix ? 2 * G + Rr * G + n_gblk * (Rr + 1) + (Rr + 1) : 0) +
-                            (surv_norm ? 2 * Rr * G + n_gblk * (Rr + 1) + (Rr + 1) + Rr : 0);
+                            (surv_norm ? 2 * Rr * G + n_gblk * (Rr + 1) + (Rr + 1) + Rr : 0) +
+                            (surv_tiling ? 2 * G : 0);
     const bool split_ok = !is_survival(*s) && !is_tiling(*s);
     const bool use_split = split_ok && !c->fused_guide;
     c->wave_guide = c->wave_guide && split_ok;
@@ -321,6 +321,10 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         d.gsum = w; w += Rr + 1;
         c->gsum_ws = d.gsum;
     }
+    if (surv_tiling) {
+        d.u_g = w; w += G;
+        d.eps_u = w; w += G;
+    }
     if (surv_norm) {
         d.gam = w; w += Rr * G;
         d.gpart = w; w += n_gblk * (Rr + 1);
@@ -380,7 +384,8 @@ static int check_bound(bean_hip_ctx* c, bool need_grads, bool need_moments) {
     REQ(BEAN_BUF_A0); REQ(BEAN_BUF_LOSS_HIST);
     if (is_survival(s)) {
         REQ(BEAN_BUF_TIMEPOINTS);
-        if (is_mixture(s)) { REQ(BEAN_BUF_CONTROL_TIME); REQ(BEAN_BUF_LOG_OBS0); }
+        if (is_mixture(s)) REQ(BEAN_BUF_CONTROL_TIME);
+        if (s.family == BEAN_FAMILY_MIXTURE_NORMAL) REQ(BEAN_BUF_LOG_OBS0);
     } else {
         REQ(BEAN_BUF_Z_HI); REQ(BEAN_BUF_Z_LO);
     }
@@ -449,7 +454,7 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
 template <int B>
 static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 block, size_t lds) {
     const DevArgs& d = c->d;
-    if (d.survival) {
+    if (d.survival && d.family != kMultiMixture) {
         if (d.family == kMixture) {
             if (d.flags & kAcc)
                 hipLaunchKernelGGL((k_guide_survival<B, kMixture, true>), grid, block, lds, stream, d);
@@ -684,7 +689,7 @@ extern "C" int bean_hip_sharded_begin(bean_hip_ctx* c, uint64_t seed, uint64_t f
     if (check_bound(c, false, true)) return -1;
     if (first_step + n_steps > c->loss_capacity)
         return fail("bean_hip_sharded_begin: loss_hist too small for first_step + n_steps");
-    if (is_survival(c->shape) && is_mixture(c->shape) && !c->slot_ptr[BEAN_BUF_XCHG_GSUM])
+    if (is_survival(c->shape) && c->shape.family == BEAN_FAMILY_MIXTURE_NORMAL && !c->slot_ptr[BEAN_BUF_XCHG_GSUM])
         return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_GSUM for a sharded survival MixtureNormal fit");
     if ((c->shape.family == BEAN_FAMILY_CONTROL_NORMAL || is_tiling(c->shape)) && !c->slot_ptr[BEAN_BUF_XCHG_TGRAD])
         return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_TGRAD for a sharded ControlNormal / tiling fit");
@@ -742,13 +747,13 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
     if (is_tiling(s)) bytes += G * A /*allele_mask*/ + 4 * (G * (A - 1) + 1) + 2 * 4 * (uint64_t)s.n_a2e_nnz + 4 * (T + 1);
     if (s.flags & BEAN_FLAG_SCALE_BY_ACC) bytes += G * (8 + ((s.flags & BEAN_FLAG_FIT_NOISE) ? 2 * 3 * 4 * 2 : 0));
     bytes += T * ((is_survival(s) ? 2 : 4) * 3 * 4 * 2);  // per-target params with moments, read + written
-    if (is_survival(s) && is_mixture(s)) bytes += G * (3 * 4 * 2 /*q0*/ + 8 * R /*log_obs0*/);
+    if (is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) bytes += G * (3 * 4 * 2 /*q0*/ + 8 * R /*log_obs0*/);
     return bytes;
 }
 
 extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
-    if (c && c->d.survival) return "k_guide_survival";
     if (c && c->d.family == kMultiMixture) return "k_guide_tiling";
+    if (c && c->d.survival) return "k_guide_survival";
     if (c && c->wave_guide) return "k_guide_wave";
     return "k_lik";
 }

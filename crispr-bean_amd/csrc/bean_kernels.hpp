@@ -252,12 +252,16 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_targe
         }
         const double pa0 = c.pi_a0[g];
         const double rS = frcp(S), rSe = frcp(S + kEps);
+        // the survival tiling guide clamps its concentration at 1e-5 (survival_model.py:813-821);
+        // the sorting one does not (model.py:942-950)
+        const bool clampq = c.survival != 0;
         const double nrg = c.part[(long)kTNrg * c.G + g];
         double sq = 0.0, sp = 0.0;
 #pragma unroll
         for (int a = 0; a < kAMax; ++a)
             if (a < A) {
-                sq += alpha[a] * rS * pa0;
+                const double q = alpha[a] * rS * pa0;
+                sq += (clampq && q < 1e-5) ? 1e-5 : q;
                 const double v = (alpha[a] + kEps / A) * rSe * pa0;
                 sp += v < kEps ? kEps : v;
             }
@@ -271,7 +275,9 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_targe
             gq[a] = 0.0;
             gp[a] = 0.0;
             if (a < A) {
-                const double cq = alpha[a] * rS * pa0;
+                const double cqr = alpha[a] * rS * pa0;
+                const bool cqc = clampq && cqr < 1e-5;
+                const double cq = cqc ? 1e-5 : cqr;
                 const double cpr = (alpha[a] + kEps / A) * rSe * pa0;
                 const bool cpc = cpr < kEps;
                 const double cp = cpc ? kEps : cpr;
@@ -279,7 +285,7 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_targe
                 lgamma_digamma(cq, lg, dg);
                 const double L = c.part[(long)(kTL + a) * c.G + g];
                 lq += -nrg * lg + (cq - 1.0) * L;
-                gq[a] = L + nrg * (dgS_q - dg) + c.part[(long)(kTPath + a) * c.G + g];
+                gq[a] = cqc ? 0.0 : L + nrg * (dgS_q - dg) + c.part[(long)(kTPath + a) * c.G + g];
                 lgamma_digamma(cp, lg, dg);
                 lp += -nrg * lg + (cp - 1.0) * L;
                 gp[a] = cpc ? 0.0 : -(L + nrg * (dgS_p - dg));
@@ -394,13 +400,13 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
             // edit <- alleles containing it (transposed CSR): the backward of
             // allele_to_edit @ mu_edits and ||allele_to_edit * sd_edits|| (model.py:618-622)
             const int A1 = c.A - 1;
-            const double sd = exp(c.y_t[t]);
+            const double sd = c.survival ? 0.0 : exp(c.y_t[t]);  // survival: no sd latent
             for (int k = c.e2a_ptr[t]; k < c.e2a_ptr[t + 1]; ++k) {
                 const int slot = c.e2a_idx[k];
                 const long o = (long)(slot % A1) * c.G + slot / A1;
                 gmu += c.part[(long)kTGmu * c.G + o];
                 // d sigma_a / d y_e = sd_e^2 / sigma_a
-                gy += c.part[(long)kTGsig * c.G + o] * sd * sd / c.sig_a[o];
+                if (!c.survival) gy += c.part[(long)kTGsig * c.G + o] * sd * sd / c.sig_a[o];
             }
         } else if (!c.wrow) {
             const int g0 = c.toff[t], g1 = c.toff[t + 1];
@@ -622,6 +628,32 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
         }
     } else if (c.family == kMultiMixture) {
         param_guide_tiling<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
+        if (c.survival) {
+            // per-guide baseline growth mu_negctrl ~ N(m0, s0): sampled in the model only
+            // (survival_model.py:479-483), i.e. a fresh prior draw each step
+            const int g = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
+            if (g < c.G) {
+                if (FINISH) {
+                    const float s0f = (float)c.neg_scale;
+                    const double du = c.u_g[g] - (double)(float)c.neg_loc;
+                    loss_fin += du * du / (2.0 * (double)(s0f * s0f)) + (double)logf(s0f) + kHalfLog2PiC;
+                }
+                if (PREP) {
+                    double eps;
+                    if (c.eps_u_in) {
+                        eps = c.eps_u_in[g];
+                    } else {
+                        rocrand_state_philox4x32_10 st;
+                        rocrand_init(c.seed, ((unsigned long long)kSiteAux << 48) + (unsigned long long)(c.g_off + g),
+                                     s_prep * 4ull, &st);
+                        eps = (double)rocrand_normal(&st);
+                    }
+                    c.eps_u[g] = eps;
+                    c.u_g[g] = (double)(float)c.neg_loc + eps * (double)(float)c.neg_scale;
+                    if (c.eps_u_out) c.eps_u_out[g] = eps;
+                }
+            }
+        }
     } else if (mixture) {
         // ------------------------------------------------- guide part
         const int g = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
@@ -1789,6 +1821,23 @@ __global__ __launch_bounds__(256) void k_allele(DevArgs c) {
     const int a1 = (int)(idx / c.G), g = (int)(idx % c.G);
     const long slot = (long)g * A1 + a1;
     const bool valid = c.amask[(long)g * c.A + a1 + 1] != 0;
+    if (c.survival) {
+        // growth of the allele over the timepoints, exp((u_g + sum_e mu_e) t_b); masked alleles get
+        // probability 0 (survival_model.py:484-488, 561-567)
+        double mu = 0.0;
+        for (int k = c.a2e_ptr[slot]; k < c.a2e_ptr[slot + 1]; ++k) mu += c.mu_t[c.a2e_idx[k]];
+        c.mu_a[idx] = mu;
+        const double full = c.u_g[g] + mu;
+        for (int b = 0; b < c.B; ++b) {
+            const double tb = c.time[b];
+            const double P = valid ? exp(full * tb) : 0.0;
+            const long o = ((long)b * A1 + a1) * c.G + g;
+            c.tabP[o] = P;
+            c.tabPmu[o] = tb * P;
+            c.tabPy[o] = 0.0;
+        }
+        return;
+    }
     double mu = 0.0, var = 0.0;
     for (int k = c.a2e_ptr[slot]; k < c.a2e_ptr[slot + 1]; ++k) {
         const int e = c.a2e_idx[k];
@@ -1873,6 +1922,8 @@ void k_guide_tiling(DevArgs c) {
 #pragma unroll
             for (int a = 0; a < kAMax; ++a) {
                 cq[a] = alpha[a] * rs;
+                // the survival tiling guide clamps its concentration (survival_model.py:813-821)
+                if (c.survival && a < A && cq[a] < 1e-5) cq[a] = 1e-5;
                 total += cq[a];
             }
         }
@@ -1881,6 +1932,11 @@ void k_guide_tiling(DevArgs c) {
             kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
             lpn = c.lpn[g];
         }
+        // unedited allele: the sorting bins' P0[b], or the guide's baseline growth exp(u_g t_b)
+        const double u = c.survival ? c.u_g[g] : 0.0;
+        double P0g[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) P0g[b] = c.survival ? exp(u * c.time[b]) : c.P0[b];
         for (int r = w; r < c.R; r += nw) {
             const bool rgm = c.rg[(long)r * G + g] != 0;
             // both pi sites, the Multinomial and the count likelihoods are masked by
@@ -1952,7 +2008,7 @@ void k_guide_tiling(DevArgs c) {
             double e[B], ge[B];
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                double v = pe0 * c.P0[b];
+                double v = pe0 * P0g[b];
 #pragma unroll
                 for (int a = 1; a < kAMax; ++a)
                     if (a < A) v += pe[a] * c.tabP[((long)b * A1 + (a - 1)) * G + g];
@@ -1975,7 +2031,7 @@ void k_guide_tiling(DevArgs c) {
             // back through the mixture
             double s0 = 0.0, gpi[kAMax];
 #pragma unroll
-            for (int b = 0; b < B; ++b) s0 += ge[b] * c.P0[b];
+            for (int b = 0; b < B; ++b) s0 += ge[b] * P0g[b];
             gpi[0] = ACC ? 0.0 : s0;
 #pragma unroll
             for (int a = 1; a < kAMax; ++a) {
@@ -2011,16 +2067,58 @@ void k_guide_tiling(DevArgs c) {
             for (int a = 0; a < kAMax; ++a) {
                 if (a < A) {
                     const double lpi = flog(pi[a]), rpi = frcp(pi[a]);
-                    const double pr = pi[a] * rsum;
-                    const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
-                    const double lg = inside ? lpi - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
-                    double cnt = 0.0;
-                    for (int cc = 0; cc < c.C; ++cc)
-                        cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
-                    nll -= cnt * lg;
-                    if (inside) gpi[a] -= cnt * rpi;
+                    if (!c.survival) {
+                        const double pr = pi[a] * rsum;
+                        const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+                        const double lg = inside ? lpi - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                        double cnt = 0.0;
+                        for (int cc = 0; cc < c.C; ++cc)
+                            cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                        nll -= cnt * lg;
+                        if (inside) gpi[a] -= cnt * rpi;
+                    }
                     L[a] += lpi;
                     gpi[a] += (cq[a] - 1.0) * rpi;  // + d log q / d pi
+                }
+            }
+            if (c.survival) {
+                // control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)), mu = [u, u + mu_a]
+                // (survival_model.py:535-548): gradients to pi and, through the growth, to mu_a
+                for (int cc = 0; cc < c.C; ++cc) {
+                    const double tc = c.ctrl_time[cc];
+                    double wv[kAMax], gr[kAMax], W = 0.0;
+#pragma unroll
+                    for (int a = 0; a < kAMax; ++a) {
+                        gr[a] = 0.0;
+                        wv[a] = 0.0;
+                        if (a < A) {
+                            const double m = a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g];
+                            gr[a] = exp(m * tc);
+                            wv[a] = pi[a] * gr[a];
+                            W += wv[a];
+                        }
+                    }
+                    const double rW = frcp(W);
+                    double n_in = 0.0, cnt[kAMax];
+                    bool inside[kAMax];
+#pragma unroll
+                    for (int a = 0; a < kAMax; ++a) {
+                        cnt[a] = 0.0;
+                        inside[a] = false;
+                        if (a < A) {
+                            const double pr = wv[a] * rW;
+                            inside[a] = pr > kProbEps && pr < 1.0 - kProbEps;
+                            cnt[a] = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                            nll -= cnt[a] * flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                            if (inside[a]) n_in += cnt[a];
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < kAMax; ++a)
+                        if (a < A) {
+                            gpi[a] += ((inside[a] ? -cnt[a] * frcp(wv[a]) : 0.0) + n_in * rW) * gr[a];
+                            if (a >= 1) gmu_s[a - 1] += ((inside[a] ? -cnt[a] : 0.0) + n_in * wv[a] * rW) * tc;
+                        }
                 }
             }
             nrg += 1.0;

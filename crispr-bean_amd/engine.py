@@ -65,9 +65,6 @@ class HipSVI:
         if family not in _lib.FAMILY:
             raise ValueError(f"unknown model family {family!r}")
         survival = getattr(data, "selection", "sorting") == "survival"
-        if survival and family not in ("Normal", "ControlNormal", "MixtureNormal"):
-            raise NotImplementedError(
-                f"survival {family} is not implemented in the HIP engine yet (Normal, ControlNormal, MixtureNormal are)")
         surv_normal = survival and family == "Normal"
         self.surv_normal = surv_normal
         if surv_normal and prior_params is not None and "initial_abundance" in prior_params:
@@ -183,6 +180,7 @@ class HipSVI:
                 if int(data.control_timepoint.numel()) != n_ctrl:
                     raise ValueError("control_timepoint must list one time per control condition")
                 self._bind("CONTROL_TIME", f64(data.control_timepoint))
+            if family == "MixtureNormal":
                 # observed initial abundance (survival_model.py:310), formed in float32 as the reference does
                 x_t0 = data.X[:, 0, :].to(torch.float32) + 1
                 if n_guides_total and n_guides_total != G:
@@ -234,7 +232,7 @@ class HipSVI:
         if not survival:  # survival models have no sd latent (bean/cli/run.py:305)
             init["sd_loc"] = torch.zeros(pshape)
             init["sd_scale"] = torch.zeros(pshape)
-        if survival and mixture:  # q0 = ones(G) / G over the WHOLE screen (survival_model.py:660-664)
+        if survival and family == "MixtureNormal":  # q0 = ones(G) / G over the WHOLE screen (survival_model.py:660-664)
             g_all = int(n_guides_total) if n_guides_total else G
             init["q0"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(g_all))))
         if surv_normal:  # initial_abundance = ones(G) / G (survival_model.py:630-634)
@@ -276,10 +274,11 @@ class HipSVI:
                 self._noise_out["eps_sd"] = torch.zeros(T, dtype=torch.float64, device=dev)
                 self._bind("EPS_SD_OUT", self._noise_out["eps_sd"])
             if survival and mixture:
-                self._noise_out["initial_abundance"] = torch.zeros((R, G), dtype=torch.float64, device=dev)
                 self._noise_out["eps_u"] = torch.zeros(G, dtype=torch.float64, device=dev)
-                self._bind("X0_OUT", self._noise_out["initial_abundance"])
                 self._bind("EPS_U_OUT", self._noise_out["eps_u"])
+            if survival and family == "MixtureNormal":
+                self._noise_out["initial_abundance"] = torch.zeros((R, G), dtype=torch.float64, device=dev)
+                self._bind("X0_OUT", self._noise_out["initial_abundance"])
             if surv_normal:
                 self._noise_out["q_0"] = torch.zeros((R, G), dtype=torch.float64, device=dev)
                 self._bind("X0_OUT", self._noise_out["q_0"])
@@ -479,7 +478,14 @@ class HipSVI:
     def constrained(self) -> Dict[str, torch.Tensor]:
         """Constrained parameter values, as ``pyro.get_param_store()[name]``."""
         torch.cuda.synchronize(self.device)
-        return {k: (v.exp() if k in POSITIVE else v.clone()) for k, v in self.unconstrained.items()}
+        out = {k: (v.exp() if k in POSITIVE else v.clone()) for k, v in self.unconstrained.items()}
+        if self.survival and self.family == "MultiMixtureNormal":
+            # the reference's tiling survival guide registers this parameter and never uses it
+            # (survival_model.py:770-774): it keeps its initial value
+            g_all = int(self._shape.n_guides_total) or self.data.n_guides
+            out["initial_abundance"] = torch.full((self.data.n_guides,), 1.0 / g_all, dtype=torch.float32,
+                                                  device=self.device)
+        return out
 
 
 def test_special(op: int, a, x=None, b=None, device="cuda:0"):

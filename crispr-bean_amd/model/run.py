@@ -70,7 +70,7 @@ def build_engine(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000,
         raise ValueError(f"{m.selection} model used with a {getattr(data, 'selection', 'sorting')} screen")
     if m.selection == "survival":
         neg = m.get("mu_negctrl", (0.0, 0.1))
-        if m.family == "MixtureNormal":
+        if m.family in ("MixtureNormal", "MultiMixtureNormal"):
             engine_kw = dict(engine_kw, mu_negctrl=(float(neg[0]), float(neg[1])))
     return HipSVI(
         m.family,

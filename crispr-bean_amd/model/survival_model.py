@@ -1,9 +1,8 @@
 """Survival-screen model / guide descriptors (see ``model.py`` for the idea).
 
 Names, arguments and defaults follow ``bean/model/survival_model.py``.  The
-HIP engine implements ``Normal`` (``--uniform-edit``), ``ControlNormal`` and
-``MixtureNormal`` (+Acc) for survival screens; ``MultiMixtureNormalModel``
-(tiling) is described here but raises ``NotImplementedError`` when fitted.
+HIP engine implements all of them: ``Normal`` (``--uniform-edit``), ``ControlNormal``,
+``MixtureNormal`` (+Acc) and the tiling ``MultiMixtureNormal`` (+Acc).
 """
 from __future__ import annotations
 
@@ -40,13 +39,13 @@ def MixtureNormalModel(data=None, alpha_prior: float = 1, use_bcmatch: bool = Tr
                  mask_thres=mask_thres, prior_params=prior_params, mu_negctrl=mu_negctrl)
 
 
-def MultiMixtureNormalModel(data=None, alpha_prior=1, use_bcmatch=True, sd_scale=0.01, norm_pi=False,
-                            scale_by_accessibility=False, epsilon=1e-5, fit_noise: bool = False,
-                            prior_params: Optional[dict] = None):
+def MultiMixtureNormalModel(data=None, alpha_prior=1, use_bcmatch=True, use_all_timepoints_for_pi: bool = True,
+                            sd_scale=0.01, norm_pi=False, scale_by_accessibility=False, fit_noise: bool = False,
+                            prior_params: Optional[dict] = None, epsilon=1e-5, mu_negctrl=(0.0, 0.1)):
     """bean/model/survival_model.py:427-626."""
     return _spec("MultiMixtureNormal", "model", alpha_prior=alpha_prior, use_bcmatch=use_bcmatch,
                  scale_by_accessibility=scale_by_accessibility, fit_noise=fit_noise,
-                 prior_params=prior_params, epsilon=epsilon)
+                 prior_params=prior_params, epsilon=epsilon, mu_negctrl=mu_negctrl)
 
 
 def NormalGuide(data=None):

@@ -393,3 +393,22 @@ def make_survival_variant_screen(
     data.negctrl_guide_idx = np.nonzero(is_negctrl[g2t])[0]
     data.validate()
     return data
+
+
+def make_survival_tiling_screen(n_guides: int = 2000, n_reps: int = 3, times=(0.0, 7.0, 14.0),
+                                control_index: int = 1, seed: int = BASE_SEED + 6, **tiling_kw) -> ScreenTensors:
+    """Tiling survival screen for parity tests: the allele / edit structure, allele counts and guide
+    counts of :func:`make_sorting_tiling_screen` with its conditions relabelled as timepoints
+    (normalised by the last one, ``data_class.py:1034-1053``) and the control condition moved to
+    timepoint ``control_index``.  The counts are not drawn from a growth model - the tiling survival
+    tests compare arithmetic, not recovery."""
+    B = len(times)
+    bins = tuple((i / B, (i + 1) / B) for i in range(B - 1))  # B - 1 sort bins + the control pseudo-bin
+    data = make_sorting_tiling_screen(n_guides, n_reps, seed=seed, bins=bins, **tiling_kw)
+    assert data.n_condits == B, (data.n_condits, B)
+    t = np.asarray(times, dtype=np.float64)
+    data.selection = "survival"
+    data.timepoints = torch.as_tensor(t / t.max())
+    data.control_timepoint = data.timepoints[control_index:control_index + 1].clone()
+    data.upper_bounds = data.lower_bounds = None
+    return data

@@ -42,6 +42,16 @@ def init_params(family: str, data, fit_noise: bool = True, scale_by_acc: bool = 
     G = data.n_guides
     if family == "ControlNormal":
         p = {k: torch.tensor(0.0, dtype=f) for k in ("mu_loc", "mu_scale")}
+    elif family == "MultiMixtureNormal":
+        E, A = data.n_edits, data.n_max_alleles
+        p = {k: torch.zeros((E,), dtype=f) for k in ("mu_loc", "mu_scale")}
+        ap = torch.zeros((G, A), dtype=f)
+        ap[~data.allele_mask] = float(torch.log(torch.tensor(1e-5)))
+        p["alpha_pi"] = ap
+        if scale_by_acc:
+            p["noise_loc"] = torch.zeros(G, dtype=f)
+            p["noise_scale"] = torch.full((G,), PI_NOISE_SD, dtype=f).log()
+        return {k: v.clone().requires_grad_(True) for k, v in p.items()}
     else:
         T = data.n_targets
         p = {k: torch.zeros((T, 1), dtype=f) for k in ("mu_loc", "mu_scale")}
@@ -178,7 +188,63 @@ def normal_loss(data, params, noise=None, use_bcmatch=True, mask_thres=10, prior
     return _finish(model_lp, guide_lp, record)
 
 
+def multi_mixture_normal_loss(data, params, noise=None, use_bcmatch=True, scale_by_accessibility=False,
+                              fit_noise=True, mask_thres=10, prior_params=None, mu_negctrl=(0.0, 0.1),
+                              record=None, eps=1e-5):
+    """Tiling survival screens: ``MultiMixtureNormalModel`` / ``MultiMixtureNormalGuide``
+    (427-626, 759-833).  Per-edit growth effects, allele = sum of its edits on top of the per-guide
+    baseline ``mu_negctrl`` (model-only draw, as in ``MixtureNormalModel``); masked alleles get zero
+    growth probability (561-567) but stay in the control Multinomial (535-548).  The guide declares
+    an ``initial_abundance`` parameter it never uses (770-774): it has no gradient and is not part of
+    the loss."""
+    P = _constrained({k: v for k, v in params.items() if k != "initial_abundance"})
+    R, B, G, A, E = data.n_reps, data.n_condits, data.n_guides, data.n_max_alleles, data.n_edits
+    a2e = data.allele_to_edit_dense().to(P["mu_loc"].dtype)
+    mu_e = normal_rsample(P["mu_loc"], P["mu_scale"], _noise(noise, "eps_mu"))
+    guide_lp = {"mu_targets": tdist.Normal(P["mu_loc"], P["mu_scale"]).log_prob(mu_e).sum()}
+    alpha_pi = torch.where(data.allele_mask, P["alpha_pi"], torch.full_like(P["alpha_pi"], eps))
+    rg = data.repguide_mask.unsqueeze(1)
+    conc_q = (alpha_pi / alpha_pi.sum(-1)[:, None] * data.pi_a0[:, None])[None, None].expand(R, 1, -1, -1)
+    conc_q = conc_q.clamp(1e-5)
+    pi = dirichlet_rsample(conc_q, _noise(noise, "pi"))
+    guide_lp["pi"] = masked_sum(tdist.Dirichlet(conc_q, validate_args=False).log_prob(pi), rg)
+    model_lp = {}
+    pi_eff = pi
+    if scale_by_accessibility:
+        q_noise = tdist.Normal(P["noise_loc"], P["noise_scale"])
+        lpn = normal_rsample(P["noise_loc"], P["noise_scale"], _noise(noise, "eps_noise"))
+        guide_lp["logit_pi_noise"] = q_noise.log_prob(lpn).sum()
+        model_lp["logit_pi_noise"] = tdist.Normal(0.0, PI_NOISE_SD).log_prob(lpn).sum()
+        pi_eff = scale_pi_by_accessibility(pi, data.guide_accessibility, lpn)
+    model_lp["mu_targets"] = _mu_prior(prior_params).log_prob(mu_e).sum()
+    neg = tdist.Normal(mu_negctrl[0], mu_negctrl[1])
+    u = _noise(noise, "mu_negctrl")
+    if u is None:
+        u = neg.sample((G,))
+    u = u.to(neg.loc.dtype)
+    model_lp["mu_negctrl"] = neg.log_prob(u).sum()
+    mu_a = torch.matmul(a2e, mu_e)  # (G, A - 1)
+    mu = torch.cat([u.unsqueeze(-1), u.unsqueeze(-1) + mu_a], -1)  # (G, A)
+    conc_p = (alpha_pi + eps / A) / (alpha_pi.sum(-1)[:, None] + eps) * data.pi_a0[:, None]
+    conc_p = torch.where(conc_p < eps, torch.full_like(conc_p, eps), conc_p)[None, None].expand(R, 1, -1, -1)
+    model_lp["pi"] = masked_sum(tdist.Dirichlet(conc_p, validate_args=False).log_prob(pi), rg)
+    tc = data.control_timepoint
+    n_c = len(tc)
+    growth_c = torch.exp(mu[None, None].expand(R, n_c, -1, -1) * tc[None, :, None, None].expand(R, -1, G, A))
+    model_lp["control_allele_count"] = masked_sum(
+        tdist.Multinomial(probs=pi.expand(-1, n_c, -1, -1) * growth_c, validate_args=False).log_prob(
+            data.allele_counts_control),
+        rg,
+    )
+    p_time = torch.exp(data.timepoints[:, None, None].expand(-1, G, 1) * mu[None].expand(B, -1, -1))
+    p_time = p_time * data.allele_mask[None].expand(B, -1, -1)
+    expected_guide_p = (pi_eff.expand(R, B, -1, -1) * p_time[None]).sum(-1)
+    model_lp.update(_count_likelihoods(data, expected_guide_p, use_bcmatch, mask_thres))
+    return _finish(model_lp, guide_lp, record)
+
+
 LOSSES = {
+    "MultiMixtureNormal": multi_mixture_normal_loss,
     "Normal": normal_loss,
     "ControlNormal": control_normal_loss,
     "MixtureNormal": mixture_normal_loss,

@@ -117,6 +117,23 @@ def test_sorting_tiling_runs(tmp_path, extra, label):
         assert {"mu_scaled", "mu_z_scaled"} <= set(el.columns)
 
 
+SURV_TILING = os.path.join(os.path.dirname(__file__), "golden", "survival_tiling_mini_screen.h5ad")
+
+
+@pytest.mark.parametrize("extra", [[], ["--fit-negctrl", "--negctrl-col", "strand", "--negctrl-col-value", "neg"]])
+def test_survival_tiling_runs(tmp_path, extra):
+    """`bean run survival tiling` on the reference's survival tiling mini-screen (the reference ships
+    the data file but no test invocation for it)."""
+    argv = ["survival", "tiling", SURV_TILING, "--n-iter", "10", "--repguide-mask", "None",
+            "--allele-df-key", "allele_counts", "--control-guide-tag", "None", "--control-condition=D7"]
+    with pytest.warns(UserWarning, match="most abundant alleles"):
+        d = _run(tmp_path, *argv, *extra)
+    el = pd.read_csv(f"{d}/bean_element_result.MultiMixtureNormal.csv")
+    sg = pd.read_csv(f"{d}/bean_sgRNA_result.MultiMixtureNormal.csv")
+    assert len(sg) == 30 and len(el) > 20 and "sd" not in el.columns
+    assert np.isfinite(el[["mu", "mu_sd", "mu_z"]].values).all() and (el["mu_sd"] > 0).all()
+
+
 def test_longer_fit_moves_parameters_and_saves_raw(tmp_path):
     import pickle
 

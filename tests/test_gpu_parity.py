@@ -619,3 +619,82 @@ def test_survival_trajectory_fused_loop_and_interface(engine):
     mu, truth = out["params"]["mu_loc"].numpy().ravel(), data.truth["mu"]
     big = np.abs(truth) > 1.0
     assert big.sum() > 5 and np.mean(np.sign(mu[big]) == np.sign(truth[big])) > 0.8
+
+
+# ---------------------------------------------------------- tiling survival
+from bean_amd.preprocessing.synthetic import make_survival_tiling_screen  # noqa: E402
+
+
+def _compare_survival_tiling(engine, data, kw, seed=7, step=2):
+    torch.manual_seed(seed)
+    eng = engine.HipSVI("MultiMixtureNormal", data.to(DEV), dump_noise=True, num_steps=50, **kw)
+    for k, v in eng.unconstrained.items():
+        noise = 0.3 * torch.randn_like(v)
+        if k == "alpha_pi":
+            noise = noise * data.allele_mask.to(DEV)
+        v.add_(noise)
+    loss, grads = eng.elbo_grad(step=step, seed=seed)
+    draws = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+    assert set(draws) >= {"eps_mu", "pi", "mu_negctrl"}
+    for mode, tl, tg in (("f64", 1e-9, 5e-7), ("ref", 2e-6, 2e-5)):
+        params = {k: v.detach().cpu().clone() for k, v in eng.unconstrained.items()}
+        d = data
+        if mode == "f64":
+            params = {k: v.double() for k, v in params.items()}
+            d = elbo.as_float64(data)
+        params = {k: v.requires_grad_(True) for k, v in params.items()}
+        ref_loss, ref_grads, _ = svi.loss_and_grads(osurv.multi_mixture_normal_loss, d, params, noise=draws, **kw)
+        assert abs(loss - ref_loss) <= tl * abs(ref_loss), (mode, loss, ref_loss)
+        for k, g in grads.items():
+            ref = ref_grads[k].double().reshape(-1)
+            err = (g.cpu().double().reshape(-1) - ref).abs().max().item()
+            assert err <= tg * (ref.abs().max().item() + 1e-30), (mode, k, err)
+    assert torch.all(grads["alpha_pi"][~data.allele_mask.to(DEV)] == 0)
+    eng.close()
+
+
+@pytest.mark.parametrize("gen_kw,kw", [
+    (dict(n_guides=400, n_reps=3, mask_fraction=0.05), {}),
+    (dict(n_guides=300, n_reps=2, with_accessibility=True, n_max_alleles=5), dict(scale_by_accessibility=True)),
+    (dict(n_guides=130, n_reps=4, n_max_alleles=3, times=(0.0, 3.0, 6.0, 9.0, 12.0)), {}),
+    (dict(n_guides=200, n_reps=2, n_max_alleles=8), dict(mu_negctrl=(0.05, 0.2))),
+])
+def test_survival_tiling_matches_oracle(engine, gen_kw, kw):
+    data = make_survival_tiling_screen(seed=11, **gen_kw)
+    _compare_survival_tiling(engine, data, kw)
+
+
+def test_survival_tiling_trajectory_fused_loop_and_store(engine):
+    from functools import partial
+
+    from bean_amd.model import survival_model as vm
+    from bean_amd.model.run import run_inference
+
+    data = make_survival_tiling_screen(250, 2, seed=12, n_max_alleles=6)
+    n = 12
+    eng = engine.HipSVI("MultiMixtureNormal", data.to(DEV), dump_noise=True, num_steps=2000)
+    params = osurv.init_params("MultiMixtureNormal", data)
+    optim = svi.ClippedAdam(params, lr=0.01, lrd=0.1 ** (1 / 2000))
+    for t in range(n):
+        loss, _ = eng.elbo_grad(step=t, seed=5, loss_index=t)
+        draws = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+        eng.adam(t + 1)
+        ref = svi.svi_step(osurv.multi_mixture_normal_loss, data, params, optim, noise=draws)
+        assert abs(loss - ref) <= 5e-6 * abs(ref), (t, loss, ref)
+    torch.cuda.synchronize()
+    for k, v in eng.unconstrained.items():
+        ref = params[k].detach()
+        err = (v.cpu() - ref).abs().max().item()
+        assert err <= 2e-4 * max(1.0, ref.abs().max().item()), (k, err)
+    fused = engine.HipSVI("MultiMixtureNormal", data.to(DEV), num_steps=2000)
+    fused.run(n, seed=5, graph_chunk=4)
+    for k in eng.unconstrained:
+        assert torch.equal(eng.unconstrained[k], fused.unconstrained[k]), k
+    eng.close()
+    fused.close()
+    store, out = run_inference(partial(vm.MultiMixtureNormalModel), partial(vm.MultiMixtureNormalGuide), data,
+                               num_steps=150, verbose=False)
+    # the reference's guide registers an unused `initial_abundance` parameter: it stays 1 / G
+    assert set(store.keys()) == {"mu_loc", "mu_scale", "alpha_pi", "initial_abundance"}
+    assert torch.allclose(store["initial_abundance"].cpu(), torch.full((250,), 1 / 250))
+    assert np.isfinite(out["loss"]).all() and out["loss"][-1] < out["loss"][0]
