@@ -77,7 +77,6 @@ def _shape(**kw):
 @pytest.mark.parametrize("kw,msg", [
     (dict(family=7), "family"),
     (dict(selection=2), "selection"),
-    (dict(selection=1, family=3, n_max_alleles=4, n_edits=2, n_targets=2), "survival screens support"),
     (dict(selection=1, family=0, n_guides_total=400), "cannot be guide-sharded"),
     (dict(family=3, n_max_alleles=9, n_edits=2, n_targets=2), "n_max_alleles"),
     (dict(family=3, n_max_alleles=4, n_edits=3, n_targets=2), "n_targets == n_edits"),
