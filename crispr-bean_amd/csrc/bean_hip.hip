@@ -36,6 +36,7 @@ struct bean_hip_ctx {
     bool fused_guide;  // false: BEAN_HIP_GUIDE=split selects the sample / lik / pi-terms launches
     bool wave_guide;   // sorting variant families, default: one wave per (guide tile, replicate)
     int* tile_targets_dev;
+    bool tiling_wave;  // tiling families, default: k_guide_tiling_wave (BEAN_HIP_TILING=block: k_guide_tiling)
     double* gsum_ws;  // library-owned normaliser buffer (replaced by BEAN_BUF_XCHG_GSUM when bound)
     // graph cache
     hipGraphExec_t graph_exec;
@@ -225,6 +226,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         const char* mode = getenv("BEAN_HIP_GUIDE");
         c->fused_guide = !((env && env[0] == '1') || (mode && !strcmp(mode, "split")));
         c->wave_guide = c->fused_guide;
+        const char* tmode = getenv("BEAN_HIP_TILING");
+        c->tiling_wave = !(tmode && !strcmp(tmode, "block"));
     }
     c->graph_exec = nullptr;
     c->graph_chunk = 0;
@@ -262,6 +265,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const bool split_ok = !is_survival(*s) && !is_tiling(*s);
     const bool use_split = split_ok && !c->fused_guide;
     c->wave_guide = c->wave_guide && split_ok;
+    c->tiling_wave = c->tiling_wave && is_tiling(*s);
+    const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G : 0;
     const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G
                                        : (c->wave_guide ? (uint64_t)(kNumPart + 2) * Rr * G : 0);
 #ifdef BEAN_STAMP
@@ -269,7 +274,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
 #else
     const uint64_t n_dbg = 0;
 #endif
-    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + n_surv + n_split + n_dbg;
+    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + n_surv + n_split + n_dbg + n_trow;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
     if (e != hipSuccess) {
@@ -301,6 +306,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.tile_targets = 64;
     if (n_dbg) {
         d.dbg = (unsigned long long*)w; w += n_dbg;
+    }
+    if (c->tiling_wave) {
+        d.trow = w; w += n_trow;
     }
     if (c->wave_guide) {
         d.wrow = w; w += (uint64_t)kNumPart * Rr * G;
@@ -465,10 +473,16 @@ static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 
         }
     } else if (d.family == kMultiMixture) {
         const size_t tl = ((size_t)kTNumPart * 64 + 16) * sizeof(double);
-        if (d.flags & kAcc)
-            hipLaunchKernelGGL((k_guide_tiling<B, true>), grid, block, tl, stream, d);
-        else
-            hipLaunchKernelGGL((k_guide_tiling<B, false>), grid, block, tl, stream, d);
+        if (d.survival) {
+            if (d.flags & kAcc)
+                hipLaunchKernelGGL((k_guide_tiling<B, true, true>), grid, block, tl, stream, d);
+            else
+                hipLaunchKernelGGL((k_guide_tiling<B, false, true>), grid, block, tl, stream, d);
+        } else if (d.flags & kAcc) {
+            hipLaunchKernelGGL((k_guide_tiling<B, true, false>), grid, block, tl, stream, d);
+        } else {
+            hipLaunchKernelGGL((k_guide_tiling<B, false, false>), grid, block, tl, stream, d);
+        }
     }
 }
 
@@ -550,6 +564,35 @@ static void launch_sums(bean_hip_ctx* c, hipStream_t stream) {
         hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, stream, d);
 }
 
+// tiling families, one wave per (guide tile, replicate), then the sum over replicates
+static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
+    const DevArgs& d = c->d;
+    const bool acc = (d.flags & kAcc) != 0;
+    const dim3 grid((d.G + 63) / 64, d.R), block(64);
+    const size_t lds = (size_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * 64 * sizeof(double) +
+                       (size_t)2 * d.B * 64 * sizeof(float);
+    const bool prof = c->profile && c->ev.size() < 8192;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, stream);
+    }
+    if (d.survival) {
+        if (acc) hipLaunchKernelGGL((k_guide_tiling_wave<true, true>), grid, block, lds, stream, d);
+        else hipLaunchKernelGGL((k_guide_tiling_wave<false, true>), grid, block, lds, stream, d);
+    } else {
+        if (acc) hipLaunchKernelGGL((k_guide_tiling_wave<true, false>), grid, block, lds, stream, d);
+        else hipLaunchKernelGGL((k_guide_tiling_wave<false, false>), grid, block, lds, stream, d);
+    }
+    if (prof) {
+        (void)hipEventRecord(e1, stream);
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+    }
+    hipLaunchKernelGGL(k_sum_trow, dim3((d.G + 255) / 256, kTNumPart), dim3(256), 0, stream, d);
+}
+
 static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = true) {
     const DevArgs& d = c->d;
     if (!c->fused_guide && !d.survival && d.family != kMultiMixture) {
@@ -565,6 +608,10 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
     if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
         const long n = (long)(d.A - 1) * d.G;
         hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
+    }
+    if (c->tiling_wave) {
+        launch_guide_tiling_wave(c, stream);
+        return;
     }
     const dim3 grid((d.G + 63) / 64), block(64 * nw);
     const size_t lds = ((size_t)nw * kNumPart * 64 + 16) * sizeof(double);
@@ -752,7 +799,7 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
 }
 
 extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
-    if (c && c->d.family == kMultiMixture) return "k_guide_tiling";
+    if (c && c->d.family == kMultiMixture) return c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling";
     if (c && c->d.survival) return "k_guide_survival";
     if (c && c->wave_guide) return "k_guide_wave";
     return "k_lik";

@@ -100,6 +100,7 @@ struct DevArgs {
     double* rrow;                      // (3, R, G) split form: d/dmu_t, d/dy_t, d/dnoise per (rep, guide)
     double* wrow;                      // (kNumPart, R, G) wave form: every per-guide row, per replicate
     int tile_targets;                  // wave form: most targets spanned by any 64-guide tile (<= 64)
+    double* trow;                      // (kTNumPart, R, G) tiling wave form: per-replicate rows
     double* nobs;                      // (2, R, G) wave form: count totals of X / X_bcmatch, -1 where masked
     StepCtr *ctrA, *ctrB;
     // tiling (MultiMixtureNormal): CSR allele slot -> edits and its transpose
@@ -1883,7 +1884,9 @@ __global__ __launch_bounds__(256) void k_allele(DevArgs c) {
 // the guide's alleles, both DirMult terms, Multinomial on control allele counts,
 // implicit gradient.  Static loops over kAMax components, predicated by a < A.
 // dynamic LDS = kTNumPart * 64 doubles + 16.
-template <int B, bool ACC>
+// SURV: tiling survival screens (growth instead of sorting bins), a compile-time switch so that the
+// sorting instantiation carries none of its state.
+template <int B, bool ACC, bool SURV>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BEAN_GUIDE_WAVES_PER_EU)))
 void k_guide_tiling(DevArgs c) {
     extern __shared__ double lds[];
@@ -1923,7 +1926,7 @@ void k_guide_tiling(DevArgs c) {
             for (int a = 0; a < kAMax; ++a) {
                 cq[a] = alpha[a] * rs;
                 // the survival tiling guide clamps its concentration (survival_model.py:813-821)
-                if (c.survival && a < A && cq[a] < 1e-5) cq[a] = 1e-5;
+                if (SURV && a < A && cq[a] < 1e-5) cq[a] = 1e-5;
                 total += cq[a];
             }
         }
@@ -1933,10 +1936,10 @@ void k_guide_tiling(DevArgs c) {
             lpn = c.lpn[g];
         }
         // unedited allele: the sorting bins' P0[b], or the guide's baseline growth exp(u_g t_b)
-        const double u = c.survival ? c.u_g[g] : 0.0;
+        const double u = SURV ? c.u_g[g] : 0.0;
         double P0g[B];
 #pragma unroll
-        for (int b = 0; b < B; ++b) P0g[b] = c.survival ? exp(u * c.time[b]) : c.P0[b];
+        for (int b = 0; b < B; ++b) P0g[b] = SURV ? exp(u * c.time[b]) : c.P0[b];
         for (int r = w; r < c.R; r += nw) {
             const bool rgm = c.rg[(long)r * G + g] != 0;
             // both pi sites, the Multinomial and the count likelihoods are masked by
@@ -2067,7 +2070,7 @@ void k_guide_tiling(DevArgs c) {
             for (int a = 0; a < kAMax; ++a) {
                 if (a < A) {
                     const double lpi = flog(pi[a]), rpi = frcp(pi[a]);
-                    if (!c.survival) {
+                    if (!SURV) {
                         const double pr = pi[a] * rsum;
                         const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
                         const double lg = inside ? lpi - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
@@ -2081,7 +2084,7 @@ void k_guide_tiling(DevArgs c) {
                     gpi[a] += (cq[a] - 1.0) * rpi;  // + d log q / d pi
                 }
             }
-            if (c.survival) {
+            if (SURV) {
                 // control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)), mu = [u, u + mu_a]
                 // (survival_model.py:535-548): gradients to pi and, through the growth, to mu_a
                 for (int cc = 0; cc < c.C; ++cc) {
@@ -2192,6 +2195,321 @@ void k_guide_tiling(DevArgs c) {
         atomicAdd(&c.loss_hist[ctr.slot], tot);
         if (blockIdx.x == 0) *c.ctrA = ctr;
     }
+}
+
+// ------------------------------------------------------- k_guide_tiling_wave
+// Wave form of k_guide_tiling (same arithmetic): one single-wave workgroup per (64-guide tile,
+// replicate), no per-thread arrays indexed at run time and no accumulators across replicates, so
+// nothing lives in scratch.  Per-allele state is two register arrays (pi, d loss / d pi) walked by
+// fully unrolled loops; everything indexed by the bin b is a thread-private LDS column walked by
+// rolled loops: e[b], d nll / d e[b], the digamma differences of the current likelihood, the counts.
+// The per-replicate rows go to trow[(q, r, g)]; k_sum_trow adds the replicates into `part`.
+// dynamic LDS: (3 B [+ 3 kAMax if ACC]) * 64 doubles + 2 B * 64 floats.
+template <bool ACC, bool SURV>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void k_guide_tiling_wave(DevArgs c) {
+    extern __shared__ double tls[];
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x * 64 + lane;
+    const int r = blockIdx.y;
+    const bool valid = g < c.G;
+    const StepCtr ctr = *c.ctrB;
+    const int G = c.G, A = c.A, A1 = c.A - 1, B = c.B;
+    double* es = tls + lane;                 // e[b]              at es[b * 64]
+    double* gs = tls + B * 64 + lane;        // d nll / d e[b]    at gs[b * 64]
+    double* ds = tls + 2 * B * 64 + lane;    // digamma diffs     at ds[b * 64]
+    double* ps = tls + 3 * B * 64 + lane;    // ACC: pe, d pe / d pi, d pe / d l at ps[(k * kAMax + a) * 64]
+    float* xs = (float*)(tls + (3 * B + (ACC ? 3 * kAMax : 0)) * 64) + lane;  // xs[(lik * B + b) * 64]
+    double loss = 0.0;
+
+    if (valid) {
+        const long RG = (long)c.R * G;
+        double* row = c.trow + (long)r * G + g;  // row q of this replicate at row[q * RG]
+        const bool rgm = c.rg[(long)r * G + g] != 0;
+        const bool use_bc = (c.flags & kUseBc) != 0;
+        if (!rgm) {
+            // both pi sites, the Multinomial and the count likelihoods are masked by repguide_mask in
+            // tiling (model.py:659,682,731; guide 941): the replicate contributes nothing
+            for (int q = 0; q < kTNumPart; ++q) row[q * RG] = 0.0;
+            if (c.flags & kDumpPi)
+                for (int a = 0; a < A; ++a) c.pi_out[((long)r * G + g) * A + a] = 1.0 / A;
+        } else {
+            // counts of both likelihoods: one batch of loads, then LDS
+            {
+                float xv[2][kBMax];
+#pragma unroll
+                for (int b = 0; b < kBMax; ++b) {
+                    const long xo = ((long)r * B + (b < B ? b : B - 1)) * G + g;
+                    xv[0][b] = c.X[xo];
+                    xv[1][b] = use_bc ? c.Xbc[xo] : 0.f;
+                }
+#pragma unroll
+                for (int b = 0; b < kBMax; ++b) {
+                    const int bb = b < B ? b : B - 1;
+                    xs[(0 * B + bb) * 64] = xv[0][b];
+                    xs[(1 * B + bb) * 64] = xv[1][b];
+                }
+            }
+            // ---- concentrations of the guide's Dirichlet
+            double alpha[kAMax], Ssum = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a) {
+                const bool am = a < A && c.amask[(long)g * A + a] != 0;
+                alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
+                Ssum += alpha[a];
+            }
+            const double pa0 = c.pi_a0[g];
+            const double rsq = frcp(Ssum) * pa0;
+            double cq[kAMax], total = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a) {
+                cq[a] = alpha[a] * rsq;
+                if (SURV && a < A && cq[a] < 1e-5) cq[a] = 1e-5;  // guide-side clamp (survival_model.py:813-821)
+                total += cq[a];
+            }
+            // ---- draw
+            double pi[kAMax];
+            if (c.pi_in) {
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a) pi[a] = a < A ? c.pi_in[((long)r * G + g) * A + a] : 0.0;
+            } else {
+                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+                double sum = 0.0;
+#pragma unroll
+                for (int a = 0; a < kAMax; a += 2) {
+                    pi[a] = 0.0;
+                    pi[a + 1] = 0.0;
+                    if (a < A) {  // components are drawn two at a time (one rejection loop per pair)
+                        const GammaPair gp = sample_gamma_pair(cq[a], a + 1 < A ? cq[a + 1] : 1.0, rng);
+                        rng.k = gp.k;
+                        pi[a] = fmax(gp.g0, kDblMin);
+                        sum += pi[a];
+                        if (a + 1 < A) {
+                            pi[a + 1] = fmax(gp.g1, kDblMin);
+                            sum += pi[a + 1];
+                        }
+                    }
+                }
+                const double rs = frcp(sum);
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a)
+                    if (a < A) pi[a] = fmin(fmax(pi[a] * rs, kDblMin), kOneMinus);
+            }
+            if (c.flags & kDumpPi) {
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a)
+                    if (a < A) c.pi_out[((long)r * G + g) * A + a] = pi[a];
+            }
+            // ---- accessibility transform (utils.py:106-178); its per-allele pieces live in LDS
+            double pe0 = pi[0];
+            if (ACC) {
+                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double lpn = c.lpn[g];
+                double sum = 0.0;
+#pragma unroll
+                for (int a = 1; a < kAMax; ++a) {
+                    if (a < A) {
+                        const double s1 = pi[a] * kacc;
+                        const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+                        const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+                        const double l = flog(p1c * frcp(1.0 - p1c)) + lpn;
+                        const double el = exp(l);
+                        const double pn = el * frcp(1.0 + el);
+                        const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+                        const double pea = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+                        const double dl = in2 ? pn * (1.0 - pn) : 0.0;
+                        ps[(0 * kAMax + a) * 64] = pea;
+                        ps[(1 * kAMax + a) * 64] = in1 ? dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+                        ps[(2 * kAMax + a) * 64] = dl;
+                        sum += pea;
+                    }
+                }
+                pe0 = 1.0 - sum;
+            }
+            const double u = SURV ? c.u_g[g] : 0.0;
+            // ---- e[b] = sum_a pe_a P_a[b]
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                double v = pe0 * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
+#pragma unroll
+                for (int a = 1; a < kAMax; ++a)
+                    if (a < A)
+                        v += (ACC ? ps[(0 * kAMax + a) * 64] : pi[a]) * c.tabP[((long)b * A1 + (a - 1)) * G + g];
+                es[b * 64] = v;
+                gs[b * 64] = 0.0;
+            }
+            // ---- both Dirichlet-Multinomial terms, d nll / d e[b] accumulated in gs
+            double nll = 0.0;
+            const double* sm = c.smask + r * B;
+            const double epsB = kEps / (double)B;
+#pragma unroll 1
+            for (int lik = 0; lik < 2; ++lik) {
+                if (lik == 1 && !use_bc) break;
+                const float* xp = xs + lik * B * 64;
+                const double* sf = (lik ? c.sf_bc : c.sf) + r * B;
+                double nn = 0.0, S = 0.0;
+#pragma unroll 1
+                for (int b = 0; b < B; ++b) {
+                    nn += (double)xp[b * 64];
+                    S += es[b * 64] * uniform_ld(sf, b);
+                }
+                if (!(nn > (double)c.mask_thres)) continue;
+                const double a0 = lik ? c.a0_bc[g] : c.a0[g];
+                const double inv = frcp(S + kEps);
+                double A0 = 0.0, lsum = 0.0, Ua = 0.0, Va = 0.0;
+#pragma unroll 1
+                for (int b = 0; b < B; ++b) {
+                    const double araw = (es[b * 64] * uniform_ld(sf, b) + epsB) * inv * a0 * uniform_ld(sm, b);
+                    const bool floored = araw < kEps;
+                    const double al = floored ? kEps : araw;
+                    A0 += al;
+                    const DD db = lgamma_digamma_diff_inl(al, (double)xp[b * 64]);
+                    lsum += db.d;
+                    ds[b * 64] = db.dp;
+                    Ua += floored ? 0.0 : araw;
+                    Va += floored ? 0.0 : db.dp * araw;
+                }
+                const DD d0 = lgamma_digamma_diff_inl(A0, nn);
+                nll += d0.d - lsum;
+                const double W = (d0.dp * Ua - Va) * inv;
+#pragma unroll 1
+                for (int b = 0; b < B; ++b) {
+                    const double sfb = uniform_ld(sf, b), smb = uniform_ld(sm, b);
+                    const double araw = (es[b * 64] * sfb + epsB) * inv * a0 * smb;
+                    const double ga = araw < kEps ? 0.0 : d0.dp - ds[b * 64];
+                    gs[b * 64] += (ga * a0 * smb * inv - W) * sfb;
+                }
+            }
+            // ---- back through the mixture: d loss / d pi_a and the per-allele-slot rows
+            double s0 = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b)
+                s0 += gs[b * 64] * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
+            double gpi[kAMax], gm[kAMax - 1], gnoise = 0.0;
+            gpi[0] = ACC ? 0.0 : s0;
+#pragma unroll
+            for (int a = 1; a < kAMax; ++a) {
+                gpi[a] = 0.0;
+                gm[a - 1] = 0.0;
+                if (a < A) {
+                    double sa = 0.0, dm = 0.0, dsg = 0.0;
+#pragma unroll 1
+                    for (int b = 0; b < B; ++b) {
+                        const long o = ((long)b * A1 + (a - 1)) * G + g;
+                        const double ge = gs[b * 64];
+                        sa += ge * c.tabP[o];
+                        dm += ge * c.tabPmu[o];
+                        if (!SURV) dsg += ge * c.tabPy[o];
+                    }
+                    const double pea = ACC ? ps[(0 * kAMax + a) * 64] : pi[a];
+                    gm[a - 1] = pea * dm;
+                    row[(long)(kTGsig + a - 1) * RG] = pea * dsg;
+                    if (ACC) {
+                        gpi[a] = (sa - s0) * ps[(1 * kAMax + a) * 64];
+                        gnoise += (sa - s0) * ps[(2 * kAMax + a) * 64];
+                    } else {
+                        gpi[a] = sa;
+                    }
+                }
+            }
+            // ---- Multinomial on control allele counts + Dirichlet log-prob pieces
+            if (!SURV) {
+                double s = 0.0;
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a)
+                    if (a < A) s += pi[a];
+                const double ls = s == 1.0 ? 0.0 : flog(s);
+                const double rsum = s == 1.0 ? 1.0 : frcp(s);
+#pragma unroll
+                for (int a = 0; a < kAMax; ++a) {
+                    if (a < A) {
+                        const double pr = pi[a] * rsum;
+                        const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+                        const double lg = inside ? flog(pi[a]) - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                        double cnt = 0.0;
+                        for (int cc = 0; cc < c.C; ++cc)
+                            cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                        nll -= cnt * lg;
+                        if (inside) gpi[a] -= cnt * frcp(pi[a]);
+                    }
+                }
+            } else {
+                // control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)), mu = [u, u + mu_a]
+                // (survival_model.py:535-548): gradients to pi and, through the growth, to mu_a
+                for (int cc = 0; cc < c.C; ++cc) {
+                    const double tc = c.ctrl_time[cc];
+                    double W = 0.0;
+#pragma unroll
+                    for (int a = 0; a < kAMax; ++a)
+                        if (a < A) W += pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+                    const double rW = frcp(W);
+                    double n_in = 0.0;
+#pragma unroll
+                    for (int a = 0; a < kAMax; ++a)
+                        if (a < A) {
+                            const double wv = pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+                            const double pr = wv * rW;
+                            const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                            nll -= cnt * flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                            if (pr > kProbEps && pr < 1.0 - kProbEps) n_in += cnt;
+                        }
+#pragma unroll
+                    for (int a = 0; a < kAMax; ++a)
+                        if (a < A) {
+                            const double gr = exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+                            const double wv = pi[a] * gr, pr = wv * rW;
+                            const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+                            const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                            gpi[a] += ((inside ? -cnt * frcp(wv) : 0.0) + n_in * rW) * gr;
+                            if (a >= 1) gm[a - 1] += ((inside ? -cnt : 0.0) + n_in * wv * rW) * tc;
+                        }
+                }
+            }
+            // model-side floored concentration c_p (model.py:640-651) for - d log p / d pi
+            const double rSe = frcp(Ssum + kEps) * pa0;
+            double proj = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a) {
+                if (a < A) {
+                    const double rpi = frcp(pi[a]);
+                    row[(long)(kTL + a) * RG] = flog(pi[a]);
+                    gpi[a] += (cq[a] - 1.0) * rpi;  // + d log q / d pi
+                    const double v = (alpha[a] + kEps / A) * rSe;
+                    gpi[a] -= ((v < kEps ? kEps : v) - 1.0) * rpi;
+                    proj += pi[a] * gpi[a];
+                    if (a >= 1) row[(long)(kTGmu + a - 1) * RG] = gm[a - 1];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a)
+                if (a < A) row[(long)(kTPath + a) * RG] = dirichlet_grad_one(pi[a], cq[a], total) * (gpi[a] - proj);
+            row[(long)kTGnoise * RG] = gnoise;
+            row[(long)kTNrg * RG] = 1.0;
+            loss = nll;
+        }
+    }
+    const double tot = wave_sum(loss);
+    if (lane == 0) {
+        atomicAdd(&c.loss_hist[ctr.slot], tot);
+        if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = ctr;
+    }
+}
+
+// part[q, g] = sum_r trow[q, r, g] for the rows of the alleles that exist (fixed order)
+__global__ __launch_bounds__(256) void k_sum_trow(DevArgs c) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;
+    if (g >= c.G) return;
+    const int A = c.A;
+    bool used = q == kTGnoise || q == kTNrg;
+    if (q >= kTPath && q < kTPath + kAMax) used = q - kTPath < A;
+    if (q >= kTL && q < kTL + kAMax) used = q - kTL < A;
+    if (q >= kTGmu && q < kTGmu + kAMax - 1) used = q - kTGmu < A - 1;
+    if (q >= kTGsig) used = q - kTGsig < A - 1;
+    if (!used) return;
+    double s = 0.0;
+    for (int r = 0; r < c.R; ++r) s += c.trow[((long)q * c.R + r) * c.G + g];
+    c.part[(long)q * c.G + g] = s;
 }
 
 // ------------------------------------------------------------------ one-offs
