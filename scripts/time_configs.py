@@ -2,7 +2,7 @@
 (config 3), one rank's shard of the 500k-guide variant screen (config 4), survival (config 5).
 Writes gpurun_out/configs.json."""
 import json, os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bean_amd
 from bean_amd import engine
