@@ -23,7 +23,7 @@ import torch
 from .alleles import allele_count_tensor, build_allele_tensors
 from .alpha0 import fitted_alpha0, fitted_pi_alpha0, pred_alpha0, pred_pi_alpha0
 from .data_class import ScreenTensors
-from .utils import assign_rep_ids_and_sort
+from .utils import assign_rep_ids_and_sort, get_accessibility_guides
 
 
 def _size_factor(X: np.ndarray) -> np.ndarray:
@@ -73,8 +73,6 @@ def build_variant_screen_data(
     replicate_column = "replicate"
     screen = screen.copy()
     samples = screen.samples
-    if accessibility_bw_path is not None and accessibility_col is None:
-        raise NotImplementedError("--acc-bw-path needs pyBigWig, which is not available: provide --acc-col instead")
     samples["size_factor"] = _size_factor(screen.X)
     if reporter or use_bcmatch:
         if "X_bcmatch" not in screen.layers:
@@ -200,6 +198,8 @@ def build_variant_screen_data(
     if accessibility_col is not None:
         acc = screen.guides[accessibility_col].values.astype(np.float64)
         data.guide_accessibility = torch.as_tensor(acc)
+    elif accessibility_bw_path is not None:  # ScreenData._post_init (data_class.py:126-133)
+        data.guide_accessibility = get_accessibility_guides(accessibility_bw_path, screen.guides)
 
     if reporter or use_bcmatch:
         Xb = rbg(screen.layers["X_bcmatch"], B)

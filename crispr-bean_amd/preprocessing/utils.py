@@ -63,3 +63,44 @@ def assign_rep_ids_and_sort(screen, rep_col: str, condition_id_col: str = None):
     keys = [f"{rep_col}_id"] + ([condition_id_col] if condition_id_col else [])
     order = screen.samples.sort_values(keys, kind="stable").index
     return screen[:, order]
+
+
+def _accessibility_single(pos, track, chrom: str = "chr19", guide_start_pos: int = 0, half_window_size: int = 100):
+    """Mean log accessibility signal around a genomic position (``bean/preprocessing/utils.py:70-108``):
+    exp(nanmean(log(values + 1))) over the window; NaN when the position is missing or the read fails."""
+    if half_window_size < 0:
+        raise ValueError("Window size must be non-negative.")
+    if pos == "control" or (isinstance(pos, float) and np.isnan(pos)):
+        return np.nan
+    try:
+        v = track.values(chrom, int(guide_start_pos + pos - half_window_size),
+                         int(guide_start_pos + pos + half_window_size))
+        with np.errstate(all="ignore"):
+            return float(np.exp(np.nanmean(np.log(np.asarray(v) + 1.0))))
+    except Exception as exc:  # the reference prints and carries on (utils.py:106-108)
+        print(exc)
+        return np.nan
+
+
+def get_accessibility_guides(accessibility_bw_path: str, guide_info, half_window_size: int = 100):
+    """Guide accessibility from a bigWig track (``bean/preprocessing/utils.py:111-147``): needs
+    ``genomic_pos`` and ``chrom`` (or ``chr``) columns; guides without a value get the median."""
+    import torch
+
+    from ..framework.bigwig import open_bigwig
+
+    acc = open_bigwig(accessibility_bw_path)
+    if "chr" in guide_info.columns and "chrom" not in guide_info.columns:
+        guide_info = guide_info.rename(columns={"chr": "chrom"})
+    has_chrom = "chrom" in guide_info.columns
+    vals = [
+        _accessibility_single(row.genomic_pos, acc, chrom=(row.chrom if has_chrom else "chr19"),
+                              guide_start_pos=0, half_window_size=half_window_size)
+        for row in guide_info.itertuples()
+    ]
+    acc.close()
+    out = torch.as_tensor(np.asarray(vals, dtype=np.float64))
+    if torch.isnan(out).all():
+        raise ValueError("Cannot retrieve guide accessibility from the bigWig file. Check your inputs.")
+    out[torch.isnan(out)] = torch.nanmedian(out)
+    return out

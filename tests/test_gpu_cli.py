@@ -17,6 +17,7 @@ pytestmark = [pytest.mark.gpu,
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 VAR = os.path.join(GOLD, "var_mini_screen.h5ad")
 SURV = os.path.join(GOLD, "survival_var_mini_screen.h5ad")
+TILING = os.path.join(GOLD, "tiling_mini_screen.h5ad")
 
 
 def _run(tmp_path, *argv):
@@ -46,6 +47,26 @@ def test_sorting_variant_runs(tmp_path, extra, label):
     if "--uniform-edit" not in extra:
         assert "edit_rate" in sg.columns and "edit_rate_mean" in el.columns
     assert os.path.exists(f"{d}/bean_run.log")
+
+
+@pytest.mark.parametrize("extra,label", [([], "MixtureNormal+Acc"), (["--fit-negctrl"], "MixtureNormal+Acc")])
+def test_sorting_variant_with_accessibility_track(tmp_path, extra, label):
+    """tests/test_run.py:7,46 of the reference: `--scale-by-acc --acc-bw-path <bigWig>`."""
+    d = _run(tmp_path, "sorting", "variant", VAR, "--n-iter", "10", "--scale-by-acc", "--acc-bw-path",
+             os.path.join(GOLD, "accessibility_signal_chr6.bw"), "--repguide-mask", "None", *extra)
+    sg = pd.read_csv(f"{d}/bean_sgRNA_result.{label}.csv")
+    assert {"accessibility", "scaled_edit_eff"} <= set(sg.columns)
+    assert np.isfinite(sg["accessibility"]).all() and sg["accessibility"].nunique() > 1
+
+
+def test_sorting_tiling_with_accessibility_track(tmp_path):
+    """tests/test_run.py:85,124: tiling with `--scale-by-acc --acc-bw-path`."""
+    with pytest.warns(UserWarning, match="most abundant alleles"):
+        d = _run(tmp_path, "sorting", "tiling", TILING, "--n-iter", "10", "--repguide-mask", "None",
+                 "--allele-df-key", "allele_counts", "--control-guide-tag", "None", "--scale-by-acc",
+                 "--acc-bw-path", os.path.join(GOLD, "accessibility_signal.bw"))
+    el = pd.read_csv(f"{d}/bean_element_result.MultiMixtureNormal+Acc.csv")
+    assert len(el) > 20 and np.isfinite(el[["mu", "mu_sd", "mu_z", "sd"]].values).all()
 
 
 def test_sorting_variant_with_accessibility_column(tmp_path):
@@ -81,9 +102,6 @@ def test_survival_variant_runs(tmp_path, extra):
     fitted = el.dropna(subset=["mu"])
     assert len(el) == 14 and len(fitted) == 13 and "sd" not in el.columns
     assert np.isfinite(fitted[["mu", "mu_sd", "mu_z"]].values).all() and (fitted["mu_sd"] > 0).all()
-
-
-TILING = os.path.join(os.path.dirname(__file__), "golden", "tiling_mini_screen.h5ad")
 
 
 @pytest.mark.parametrize("extra,label", [
