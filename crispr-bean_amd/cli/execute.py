@@ -1,5 +1,5 @@
-"""``bean`` command dispatcher (``bean/cli/execute.py:30-84``): only the ``run``
-sub-command is in scope of this implementation."""
+"""``bean`` command dispatcher (``bean/cli/execute.py:30-84``): the ``run`` sub-command and its
+companion ``build-prior`` are in scope of this implementation."""
 from __future__ import annotations
 
 import argparse
@@ -13,12 +13,20 @@ def get_parser():
     sub = parser.add_subparsers(dest="subcommand", help="bean subcommands")
     run = sub.add_parser("run", help="Quantify variant effect sizes from screen data (MI355X)")
     attach_run_args(run)
+    from .build_prior import attach_args as attach_prior_args
+
+    attach_prior_args(sub.add_parser("build-prior", help="obtain prior_params.pkl for batched runs"))
     return parser
 
 
 def main(argv=None):
     parser = get_parser()
     args = parser.parse_args(argv)
+    if args.subcommand == "build-prior":
+        from .build_prior import main as build_prior_main
+
+        build_prior_main(args)
+        return 0
     if args.subcommand != "run":
         parser.print_help()
         return 2

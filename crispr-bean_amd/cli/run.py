@@ -118,6 +118,7 @@ def main(args, return_data=False):
         if args.selection == "survival":
             model = partial(model, mu_negctrl=(param_history_dict_negctrl["mu_loc"].detach().mean(),
                                                param_history_dict_negctrl["mu_scale"].detach().mean()))
+    save_dict["data"] = ndata
     param_history_dict, save_dict_model = deepcopy(run_inference(model, guide, ndata, num_steps=args.n_iter))
     save_dict.update(save_dict_model)
     outfile = f"{prefix}/bean_element[sgRNA]_result.{model_label}{args.result_suffix}.csv"

@@ -162,3 +162,27 @@ def test_longer_fit_moves_parameters_and_saves_raw(tmp_path):
     assert len(loss) == 300 and loss[-1] < loss[0]
     assert set(raw["params"]) == {"mu_loc", "mu_scale", "sd_loc", "sd_scale", "alpha_pi"}
     assert raw["params"]["mu_loc"].shape == (6, 1) and raw["params"]["alpha_pi"].shape == (30, 2)
+
+
+def test_build_prior_then_run_with_prior_params(tmp_path):
+    """`bean build-prior` (bean/cli/build_prior.py): the first batch's posterior of the shared variants
+    becomes the prior of the second batch, which then runs with `--prior-params`."""
+    import pickle
+
+    out1 = str(tmp_path / "b1")
+    d1 = _run(tmp_path / "b1", "sorting", "variant", VAR, "--n-iter", "40", "--save-raw")
+    raw = f"{d1}/MixtureNormal.result.pkl"
+    saved = pickle.load(open(raw, "rb"))
+    assert "data" in saved and saved["data"].n_targets == 6
+    prior_path = str(tmp_path / "prior.pkl")
+    # the data file has no `mask` column: an empty --sample-mask-col (as `_run` passes) switches it off
+    cmd = f"bean run sorting variant {VAR} -o {out1} --n-iter 10 --sample-mask-col "
+    assert bean_main(["build-prior", cmd, cmd, raw, prior_path]) == 0
+    prior = pickle.load(open(prior_path, "rb"))
+    assert set(prior) == {"mu_loc", "mu_scale", "sd_loc", "sd_scale"}
+    for k in prior:  # every variant is shared here: the prior is the first run's posterior
+        assert tuple(prior[k].shape) == (6, 1)
+        np.testing.assert_allclose(prior[k].numpy().ravel(), np.asarray(saved["params"][k]).ravel(), rtol=1e-6)
+    d2 = _run(tmp_path / "b2", "sorting", "variant", VAR, "--n-iter", "10", "--prior-params", prior_path)
+    el = pd.read_csv(f"{d2}/bean_element_result.MixtureNormal.csv")
+    assert len(el) == 6 and np.isfinite(el[["mu", "mu_sd", "mu_z", "sd"]].values).all()
