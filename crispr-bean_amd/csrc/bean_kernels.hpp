@@ -802,22 +802,9 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
             }
         }
         if (PREP) {
+            // the gamma draws of the site follow in k_q0_draws (one thread per (replicate, guide))
             double ia = 0.0;
             if (in) ia = (double)expf(iau);
-            for (int r = 0; r < c.R; ++r) {
-                double gm = 0.0;
-                if (in) {
-                    if (c.x0_in) {
-                        gm = c.x0_in[(long)r * c.G + g];  // injected draw: already normalised
-                    } else {
-                        Rng rng(c.seed, kSiteQ0, (unsigned long long)r * c.G_tot + (c.g_off + g), s_prep * 256ull);
-                        gm = (double)fmaxf((float)sample_gamma(ia, rng), 1.17549435e-38f);
-                    }
-                    c.gam[(long)r * c.G + g] = gm;
-                }
-                const double tot = block_sum(gm, scratch);
-                if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + r] = tot;
-            }
             const double tq = block_sum(ia, scratch);
             if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + c.R] = tq;
         }
@@ -855,22 +842,7 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                 c.u_g[g] = (double)(float)c.neg_loc + eps * (double)(float)c.neg_scale;
                 if (c.eps_u_out) c.eps_u_out[g] = eps;
             }
-            for (int r = 0; r < c.R; ++r) {
-                double gm = 0.0;
-                if (in) {
-                    if (c.x0_in) {
-                        gm = c.x0_in[(long)r * c.G + g];  // injected draw: already normalised
-                    } else {
-                        Rng rng(c.seed, kSiteQ0, (unsigned long long)r * c.G_tot + (c.g_off + g), s_prep * 256ull);
-                        // torch draws this site in float32 (q0 is a float32 parameter): the gamma
-                        // underflows to 0 and is floored at FLT_MIN (ATen _s_dirichlet_cpu)
-                        gm = (double)fmaxf((float)sample_gamma(q0, rng), 1.17549435e-38f);
-                    }
-                    c.gam[(long)r * c.G + g] = gm;
-                }
-                const double tot = block_sum(gm, scratch);
-                if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + r] = tot;
-            }
+            // the gamma draws of the Dirichlet(q0) site follow in k_q0_draws
             const double tq = block_sum(q0, scratch);
             if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + c.R] = tq;
         }
@@ -1552,6 +1524,41 @@ void k_pi_terms(DevArgs c) {
 
 // ------------------------------------------------------------ survival kernels
 // Totals of the per-block sums written by k_param's survival guide part:
+// Gamma draws of the Dirichlet-over-all-guides site (survival MixtureNormal q0, survival NormalModel
+// initial_abundance), one thread per (replicate pair, guide), after k_param has updated the
+// parameter: gam[r, g] and the block partial sums gpart[block, r].  grid = (n_gamma_blocks, ceil(R/2)).
+// torch draws this site in float32 (the concentration is a float32 parameter): the gamma underflows
+// to 0 and is floored at FLT_MIN (ATen _s_dirichlet_cpu).
+__global__ __launch_bounds__(256) void k_q0_draws(DevArgs c) {
+    __shared__ double scratch[16];
+    // replicates are drawn two at a time (one rejection loop per pair): grid.y = ceil(R / 2)
+    const int gb = blockIdx.x, r0 = 2 * blockIdx.y, r1 = r0 + 1;
+    const bool two = r1 < c.R;
+    const int g = gb * blockDim.x + threadIdx.x;
+    const unsigned long long step = c.ctrB->step;  // the step k_param has just prepared
+    double gm0 = 0.0, gm1 = 0.0;
+    if (g < c.G) {
+        if (c.x0_in) {
+            gm0 = c.x0_in[(long)r0 * c.G + g];  // injected draws: already normalised
+            if (two) gm1 = c.x0_in[(long)r1 * c.G + g];
+        } else {
+            const double conc = (double)expf(c.p[7][g]);
+            Rng rng(c.seed, kSiteQ0, (unsigned long long)r0 * c.G_tot + (c.g_off + g), step * 256ull);
+            const GammaPair gp = sample_gamma_pair(conc, two ? conc : 1.0, rng);
+            gm0 = (double)fmaxf((float)gp.g0, 1.17549435e-38f);
+            gm1 = two ? (double)fmaxf((float)gp.g1, 1.17549435e-38f) : 0.0;
+        }
+        c.gam[(long)r0 * c.G + g] = gm0;
+        if (two) c.gam[(long)r1 * c.G + g] = gm1;
+    }
+    const double t0 = block_sum(gm0, scratch);
+    if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + r0] = t0;
+    if (two) {
+        const double t1 = block_sum(gm1, scratch);
+        if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + r1] = t1;
+    }
+}
+
 // gsum[r] = sum_g gamma[r, g] (normaliser of the Dirichlet(q0) draw), gsum[R] = sum_g q0.
 __global__ __launch_bounds__(256) void k_sum_parts(DevArgs c) {
     __shared__ double scratch[16];
