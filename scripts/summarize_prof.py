@@ -47,7 +47,7 @@ open(f"profiles/{tag}_counters.txt", "w").write("\n".join(lines) + "\n")
 if traffic:
     fetch = traffic.get("FETCH_SIZE", 0.0) * 1024 * 2  # KiB; gfx950 reports half of a coalesced stream
     write = traffic.get("WRITE_SIZE", 0.0) * 1024
-    json.dump({"kernel": "k_guide", "fetch_bytes_corrected": fetch, "write_bytes": write,
+    json.dump({"kernel": "k_guide_wave", "fetch_bytes_corrected": fetch, "write_bytes": write,
                "hbm_bytes_per_launch": fetch + write,
                "note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as read; separate --pmc passes"},
               open(f"profiles/{tag}_traffic.json", "w"), indent=1)
