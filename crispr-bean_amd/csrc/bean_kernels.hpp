@@ -688,10 +688,10 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
                 if (c.wrow) {
                     const long RG = (long)c.R * c.G;
                     const double* w = c.wrow + g;
+                    nrg = c.part[(long)kPNrg * c.G + g];  // data only (k_prepare)
 #pragma unroll 4
                     for (int r = 0; r < c.R; ++r) {
                         const double* wr = w + (long)r * c.G;
-                        nrg += wr[kPNrg * RG];
                         Lp_[0] += wr[kPLp * RG];
                         Lp_[1] += wr[(kPLp + 1) * RG];
                         Lq_[0] += wr[kPLq * RG];
@@ -1130,7 +1130,7 @@ void k_guide_wave(DevArgs c) {
                 gpi0 = 0.0;
                 gpi1 = (g1 - g0) * dpe1_dpi1;
             }
-            row[kPGnoise * RG] = ACC ? (g1 - g0) * dpe1_dl : 0.0;
+            if (ACC) row[kPGnoise * RG] = (g1 - g0) * dpe1_dl;
             const double lpi0 = flog(pi0), lpi1 = flog(pi1);
             const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
             if (rgm) {
@@ -1157,7 +1157,7 @@ void k_guide_wave(DevArgs c) {
                 gpi0 -= (cp0 - 1.0) * rpi0;
                 gpi1 -= (cp1 - 1.0) * rpi1;
             }
-            row[kPNrg * RG] = rgm ? 1.0 : 0.0;
+            // (the number of unmasked replicates of the guide is data: k_prepare keeps it in part[kPNrg])
             row[kPLp * RG] = rgm ? lpi0 : 0.0;
             row[(kPLp + 1) * RG] = rgm ? lpi1 : 0.0;
             row[kPLq * RG] = lpi0;
@@ -2544,6 +2544,12 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
         if (rgm && n > (double)c.mask_thres) v -= lgamma(1.0 + n) - lf;
         if ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) v -= lgamma(1.0 + nb) - lfb;
         if (c.nobs) {
+            // wave form: per-guide count of unmasked replicates (the kPNrg row is data)
+            if (r == 0) {
+                double cnt = 0.0;
+                for (int rr = 0; rr < c.R; ++rr) cnt += c.rg[(long)rr * c.G + g] != 0 ? 1.0 : 0.0;
+                c.part[(long)kPNrg * c.G + g] = cnt;
+            }
             c.nobs[idx] = (rgm && n > (double)c.mask_thres) ? n : -1.0;
             c.nobs[n_rg + idx] = ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) ? nb : -1.0;
         }
