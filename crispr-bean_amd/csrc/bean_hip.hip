@@ -446,8 +446,10 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
 static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_blocks) {
     const DevArgs& d = c->d;
     n_target_blocks = d.wide_targets ? d.T : (int)(((long)d.T * kLanesPerTarget + 255) / 256);
-    n_blocks = n_target_blocks +
-               ((d.family == kMixture || d.family == kMultiMixture || d.surv_q0lik) ? (d.G + 255) / 256 : 0);
+    int guide_blocks = 0;
+    if (d.family == kMultiMixture) guide_blocks = (int)(((long)d.G * kAMax + 255) / 256);  // kAMax lanes per guide
+    else if (d.family == kMixture || d.surv_q0lik) guide_blocks = (d.G + 255) / 256;
+    n_blocks = n_target_blocks + guide_blocks;
 }
 
 template <bool FINISH, bool ADAM, bool PREP>

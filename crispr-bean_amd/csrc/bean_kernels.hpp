@@ -228,82 +228,73 @@ __device__ __forceinline__ void emit_grad(const DevArgs& c, int which, long idx,
 // A-component pi site, chain to alpha_pi through the two concentration maps the
 // reference uses (guide: alpha/sum * pi_a0, model.py:938; model:
 // (alpha + eps/A)/(sum + eps) * pi_a0 floored at eps, model.py:646-651).
+// sum over the kAMax lanes that share one guide (fixed shuffle tree)
+__device__ __forceinline__ double allele_group_sum(double v) {
+#pragma unroll
+    for (int off = kAMax / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kAMax);
+    return v;
+}
+
+// Guide part of k_param for the tiling families: kAMax lanes per guide, lane a owns allele a (its
+// two lgamma/digamma pairs and its alpha_pi update); lane 0 also owns the guide's noise parameters.
 template <bool FINISH, bool ADAM, bool PREP>
 __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_target_blocks,
                                                    unsigned long long s_prep, AdamCoef ak,
                                                    double& loss_fin) {
-    const int g = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
+    const int tid = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
+    const int g = tid / kAMax, a = tid % kAMax;
     const bool acc_on = (c.flags & kAcc) != 0;
     const bool fit_noise = acc_on && (c.flags & kFitNoise);
-    if (g >= c.G) return;
+    const bool in = g < c.G;
     const int A = c.A;
+    const bool lead = in && a == 0;
     float nl = 0.f, ns_u = 0.f;
-    if (fit_noise) {
+    if (lead && fit_noise) {
         nl = c.p[5][g];
         ns_u = c.p[6][g];
     }
     if (FINISH) {
-        double alpha[kAMax], S = 0.0;
-        bool am[kAMax];
-#pragma unroll
-        for (int a = 0; a < kAMax; ++a) {
-            am[a] = a < A && c.amask[(long)g * A + a] != 0;
-            alpha[a] = a < A ? (am[a] ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
-            S += alpha[a];
-        }
-        const double pa0 = c.pi_a0[g];
-        const double rS = frcp(S), rSe = frcp(S + kEps);
+        const bool live = in && a < A;
+        const bool am = live && c.amask[(long)g * A + a] != 0;
+        const double alpha = live ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
+        const double S = allele_group_sum(alpha);
+        const double pa0 = in ? c.pi_a0[g] : 1.0;
+        const double rS = frcp(in ? S : 1.0), rSe = frcp((in ? S : 1.0) + kEps);
         // the survival tiling guide clamps its concentration at 1e-5 (survival_model.py:813-821);
         // the sorting one does not (model.py:942-950)
         const bool clampq = c.survival != 0;
-        const double nrg = c.part[(long)kTNrg * c.G + g];
-        double sq = 0.0, sp = 0.0;
-#pragma unroll
-        for (int a = 0; a < kAMax; ++a)
-            if (a < A) {
-                const double q = alpha[a] * rS * pa0;
-                sq += (clampq && q < 1e-5) ? 1e-5 : q;
-                const double v = (alpha[a] + kEps / A) * rSe * pa0;
-                sp += v < kEps ? kEps : v;
-            }
-        double lgS_q, dgS_q, lgS_p, dgS_p;
-        lgamma_digamma(sq, lgS_q, dgS_q);
-        lgamma_digamma(sp, lgS_p, dgS_p);
-        double lp = nrg * lgS_p, lq = nrg * lgS_q;
-        double gq[kAMax], gp[kAMax], dq = 0.0, dp = 0.0;
-#pragma unroll
-        for (int a = 0; a < kAMax; ++a) {
-            gq[a] = 0.0;
-            gp[a] = 0.0;
-            if (a < A) {
-                const double cqr = alpha[a] * rS * pa0;
-                const bool cqc = clampq && cqr < 1e-5;
-                const double cq = cqc ? 1e-5 : cqr;
-                const double cpr = (alpha[a] + kEps / A) * rSe * pa0;
-                const bool cpc = cpr < kEps;
-                const double cp = cpc ? kEps : cpr;
-                double lg, dg;
-                lgamma_digamma(cq, lg, dg);
-                const double L = c.part[(long)(kTL + a) * c.G + g];
-                lq += -nrg * lg + (cq - 1.0) * L;
-                gq[a] = cqc ? 0.0 : L + nrg * (dgS_q - dg) + c.part[(long)(kTPath + a) * c.G + g];
-                lgamma_digamma(cp, lg, dg);
-                lp += -nrg * lg + (cp - 1.0) * L;
-                gp[a] = cpc ? 0.0 : -(L + nrg * (dgS_p - dg));
-                dq += gq[a] * alpha[a];
-                dp += gp[a] * (alpha[a] + kEps / A);
-            }
+        const double nrg = in ? c.part[(long)kTNrg * c.G + g] : 0.0;
+        const double cqr = alpha * rS * pa0;
+        const bool cqc = clampq && cqr < 1e-5;
+        const double cq = cqc ? 1e-5 : cqr;
+        const double cpr = (alpha + kEps / A) * rSe * pa0;
+        const bool cpc = cpr < kEps;
+        const double cp = cpc ? kEps : cpr;
+        const double sq = allele_group_sum(live ? cq : 0.0), sp = allele_group_sum(live ? cp : 0.0);
+        double lgS_q = 0.0, dgS_q = 0.0, lgS_p = 0.0, dgS_p = 0.0, gq = 0.0, gp = 0.0;
+        if (in) {
+            lgamma_digamma(sq, lgS_q, dgS_q);
+            lgamma_digamma(sp, lgS_p, dgS_p);
         }
-        loss_fin = -lp + lq;
-        dq *= rS * rS;
-        dp *= rSe * rSe;
-#pragma unroll
-        for (int a = 0; a < kAMax; ++a)
-            if (a < A) {
-                const double ga = pa0 * (gq[a] * rS - dq + gp[a] * rSe - dp);
-                emit_grad<ADAM>(c, 4, (long)g * A + a, am[a] ? ga * alpha[a] : 0.0, ak);
-            }
-        if (acc_on) {
+        if (live) {
+            double lg, dg;
+            lgamma_digamma(cq, lg, dg);
+            const double L = c.part[(long)(kTL + a) * c.G + g];
+            const double lq = -nrg * lg + (cq - 1.0) * L;
+            gq = cqc ? 0.0 : L + nrg * (dgS_q - dg) + c.part[(long)(kTPath + a) * c.G + g];
+            lgamma_digamma(cp, lg, dg);
+            const double lp = -nrg * lg + (cp - 1.0) * L;
+            gp = cpc ? 0.0 : -(L + nrg * (dgS_p - dg));
+            loss_fin = lq - lp;
+        }
+        if (lead) loss_fin += nrg * (lgS_q - lgS_p);
+        const double dq = allele_group_sum(gq * alpha) * rS * rS;
+        const double dp = allele_group_sum(live ? gp * (alpha + kEps / A) : 0.0) * rSe * rSe;
+        if (live) {
+            const double ga = pa0 * (gq * rS - dq + gp * rSe - dp);
+            emit_grad<ADAM>(c, 4, (long)g * A + a, am ? ga * alpha : 0.0, ak);
+        }
+        if (lead && acc_on) {
             const double lpn = c.lpn[g], eps = c.eps_noise[g];
             const double gl = c.part[(long)kTGnoise * c.G + g];
             const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
@@ -323,7 +314,7 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_targe
             }
         }
     }
-    if (PREP && acc_on) {
+    if (PREP && acc_on && lead) {
         double eps;
         if (c.eps_noise_in) {
             eps = c.eps_noise_in[g];
@@ -396,20 +387,34 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
         gy = block_sum(b, scratch);
         return;
     }
-    if (active) {
-        if (c.family == kMultiMixture) {
-            // edit <- alleles containing it (transposed CSR): the backward of
-            // allele_to_edit @ mu_edits and ||allele_to_edit * sd_edits|| (model.py:618-622)
-            const int A1 = c.A - 1;
+    if (c.family == kMultiMixture) {
+        // edit <- alleles containing it (transposed CSR): the backward of
+        // allele_to_edit @ mu_edits and ||allele_to_edit * sd_edits|| (model.py:618-622).  The
+        // slots of the edit are spread over its lane group, summed by a fixed shuffle tree.
+        const int A1 = c.A - 1;
+        const int lg = threadIdx.x & (kLanesPerTarget - 1);
+        double a = 0.0, b = 0.0;
+        if (t < c.T) {
             const double sd = c.survival ? 0.0 : exp(c.y_t[t]);  // survival: no sd latent
-            for (int k = c.e2a_ptr[t]; k < c.e2a_ptr[t + 1]; ++k) {
+            for (int k = c.e2a_ptr[t] + lg; k < c.e2a_ptr[t + 1]; k += kLanesPerTarget) {
                 const int slot = c.e2a_idx[k];
                 const long o = (long)(slot % A1) * c.G + slot / A1;
-                gmu += c.part[(long)kTGmu * c.G + o];
+                a += c.part[(long)kTGmu * c.G + o];
                 // d sigma_a / d y_e = sd_e^2 / sigma_a
-                if (!c.survival) gy += c.part[(long)kTGsig * c.G + o] * sd * sd / c.sig_a[o];
+                if (!c.survival) b += c.part[(long)kTGsig * c.G + o] * sd * sd / c.sig_a[o];
             }
-        } else if (!c.wrow) {
+        }
+#pragma unroll
+        for (int off = kLanesPerTarget / 2; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, kLanesPerTarget);
+            b += __shfl_xor(b, off, kLanesPerTarget);
+        }
+        gmu = a;
+        gy = b;
+        return;
+    }
+    if (active) {
+        if (!c.wrow) {
             const int g0 = c.toff[t], g1 = c.toff[t + 1];
             for (int g = g0; g < g1; ++g) {
                 gmu += lik_row(c, kPGmu, g);
@@ -632,8 +637,9 @@ __global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
         if (c.survival) {
             // per-guide baseline growth mu_negctrl ~ N(m0, s0): sampled in the model only
             // (survival_model.py:479-483), i.e. a fresh prior draw each step
-            const int g = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
-            if (g < c.G) {
+            const int tid = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
+            const int g = tid / kAMax;  // kAMax lanes per guide (param_guide_tiling): lane 0 acts
+            if (g < c.G && tid % kAMax == 0) {
                 if (FINISH) {
                     const float s0f = (float)c.neg_scale;
                     const double du = c.u_g[g] - (double)(float)c.neg_loc;
