@@ -40,11 +40,22 @@ def cpu_baseline(data, seconds_budget=20.0):
     from oracle import elbo, svi
 
     torch.manual_seed(101)
-    n_threads = torch.get_num_threads()
     params = elbo.init_params("MixtureNormal", data)
     optim = svi.ClippedAdam(params, lr=0.01, lrd=0.1 ** (1 / 2000))
-    for _ in range(2):  # warm-up
-        svi.svi_step(elbo.mixture_normal_loss, data, params, optim)
+    # the eager path is partly overhead bound: give the CPU its best thread count (2 timed steps
+    # each at a few counts), then spend the budget there
+    avail = torch.get_num_threads()
+    best, n_threads = None, avail
+    for cand in sorted({min(avail, c) for c in (8, 16, 32, 64, avail)}):
+        torch.set_num_threads(cand)
+        svi.svi_step(elbo.mixture_normal_loss, data, params, optim)  # warm-up at this count
+        t = time.perf_counter()
+        for _ in range(2):
+            svi.svi_step(elbo.mixture_normal_loss, data, params, optim)
+        t = (time.perf_counter() - t) / 2
+        if best is None or t < best:
+            best, n_threads = t, cand
+    torch.set_num_threads(n_threads)
     t0 = time.perf_counter()
     n = 0
     while n < 4 or (time.perf_counter() - t0 < seconds_budget and n < 200):
@@ -57,7 +68,7 @@ def cpu_baseline(data, seconds_budget=20.0):
         "cores": n_threads,
         "kind": "port",
         "sample": f"{n} SVI steps of the same 50k-guide screen (float64 eager-torch oracle, "
-                  f"anomaly detection off, {dt:.1f} s)",
+                  f"anomaly detection off, {dt:.1f} s; fastest of 8/16/32/64/{avail} threads)",
     }
 
 
