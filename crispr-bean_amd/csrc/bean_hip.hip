@@ -536,7 +536,8 @@ static void launch_guide_split(bean_hip_ctx* c, hipStream_t stream) {
 static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     const dim3 grid((d.G + 63) / 64, d.R), block(64);
-    const size_t lds = (size_t)3 * d.B * d.tile_targets * sizeof(double) + (size_t)2 * d.B * 64 * sizeof(float);
+    const size_t lds = ((size_t)3 * d.B * d.tile_targets + (size_t)kWaveMisc * 64) * sizeof(double) +
+                       (size_t)2 * d.B * 64 * sizeof(float);
     const bool prof = c->profile && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {

@@ -134,6 +134,7 @@ struct DevArgs {
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
 constexpr int kLanesPerTarget = 8;  // k_param: lanes sharing one target's Phi table entries
 constexpr int kAMax = 8;
+constexpr int kWaveMisc = 6;  // k_guide_wave: per-guide values staged in LDS (count totals, a0, allele counts)
 constexpr int kBMax = 8;  // n_condits <= 8 (bean_hip_create)
 enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2 * kAMax,
              kTGsig = 2 + 2 * kAMax + (kAMax - 1), kTNumPart = 2 + 2 * kAMax + 2 * (kAMax - 1) };
@@ -930,7 +931,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void k_guide_wave(DevArgs c) {
     constexpr bool MIX = FAM == kMixture;
     // dynamic LDS: [3][B][ntm] doubles (P, dP/dmu, dP/dy columns of the tile's targets; ntm =
-    // c.tile_targets, the largest number of targets any tile spans) + [2][B][64] floats (counts)
+    // c.tile_targets, the largest number of targets any tile spans) + [kWaveMisc][64] doubles
+    // (per-guide values needed after the draw) + [2][B][64] floats (counts)
     extern __shared__ double tabs[];
     const int lane = threadIdx.x;
     const int g = blockIdx.x * 64 + lane;
@@ -960,36 +962,74 @@ void k_guide_wave(DevArgs c) {
     const int t0 = __builtin_amdgcn_readfirstlane(c.g2t[g_first]);
     const int nt = __builtin_amdgcn_readfirstlane(c.g2t[g_last]) - t0 + 1;
     const int ntm = c.tile_targets;
-    float* xs = (float*)(tabs + 3 * B * ntm);  // this thread's counts: xs[(lik * B + b) * 64 + lane]
+    double* ms = tabs + 3 * B * ntm + lane;               // ms[q * 64], q < kWaveMisc
+    float* xs = (float*)(tabs + 3 * B * ntm + kWaveMisc * 64);  // counts: xs[(lik * B + b) * 64 + lane]
     const bool use_bc = (c.flags & kUseBc) != 0;
     {
-        // counts of both likelihoods and table columns: one batch of loads, then LDS
+        // Everything the wave reads from global memory, issued as one batch before the first wait:
+        // the counts of both likelihoods, the table columns, and the per-guide values that are only
+        // needed after the draw (staged in LDS so that no load sits behind the sampler call).
         const int gc = valid ? g : G - 1;
-        const int tl = lane < nt ? lane : nt - 1;
+        const long rgc = (long)r * G + gc;
         float xv[2][kBMax];
-        double tv[3][kBMax];
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
-            const int bb = b < B ? b : B - 1;
-            const long xo = ((long)r * B + bb) * G + gc;
+            const long xo = ((long)r * B + (b < B ? b : B - 1)) * G + gc;
             xv[0][b] = c.X[xo];
             xv[1][b] = use_bc ? c.Xbc[xo] : 0.f;
-            const long o = (long)bb * T + t0 + tl;
-            tv[0][b] = c.tabP[o];
-            tv[1][b] = c.tabPmu[o];
-            tv[2][b] = c.tabPy[o];
         }
+        // table rows (which, b) are packed `per` rows to a load: P = pow2 >= nt lanes per row
+        int lg2 = 0;
+        while ((1 << lg2) < nt) ++lg2;
+        const int per = 64 >> lg2;                       // rows per load instruction
+        const int j = lane & ((1 << lg2) - 1), sub = lane >> lg2;
+        const int n_rows = 3 * B;
+        constexpr int kTabLoads = 6;                     // covers 3 B rows when per >= 4 (nt <= 16)
+        double tv[kTabLoads];
+        int wbv[kTabLoads];
+#pragma unroll
+        for (int q = 0; q < kTabLoads; ++q) {
+            const int wb = q * per + sub;
+            const bool ok = wb < n_rows && j < nt;
+            const int wbc = ok ? wb : 0;
+            const int which = (wbc >= B) + (wbc >= 2 * B), bb = wbc - which * B;
+            const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
+            tv[q] = tab[(long)bb * T + t0 + (ok ? j : 0)];
+            wbv[q] = ok ? wb : -1;
+        }
+        const double nn0 = c.nobs[rgc], nn1 = use_bc ? c.nobs[(long)c.R * G + rgc] : -1.0;
+        const double a00 = c.a0[gc], a01 = use_bc ? c.a0_bc[gc] : 0.0;
+        double cnt0 = 0.0, cnt1 = 0.0;
+        if (MIX)
+            for (int cc = 0; cc < c.C; ++cc) {
+                const float* al = c.allele + (((long)r * c.C + cc) * G + gc) * 2;
+                cnt0 += (double)al[0];
+                cnt1 += (double)al[1];
+            }
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
             const int bb = b < B ? b : B - 1;
             xs[(0 * B + bb) * 64 + lane] = xv[0][b];
             xs[(1 * B + bb) * 64 + lane] = xv[1][b];
-            if (lane < nt) {
-                tabs[(0 * B + bb) * ntm + lane] = tv[0][b];
-                tabs[(1 * B + bb) * ntm + lane] = tv[1][b];
-                tabs[(2 * B + bb) * ntm + lane] = tv[2][b];
+        }
+#pragma unroll
+        for (int q = 0; q < kTabLoads; ++q)
+            if (wbv[q] >= 0) tabs[wbv[q] * ntm + j] = tv[q];
+        // wide tiles (more than 16 targets in 64 guides): the remaining rows, one load per pass
+        for (int wb0 = kTabLoads * per; wb0 < n_rows; wb0 += per) {
+            const int wb = wb0 + sub;
+            if (wb < n_rows && j < nt) {
+                const int which = (wb >= B) + (wb >= 2 * B), bb = wb - which * B;
+                const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
+                tabs[wb * ntm + j] = tab[(long)bb * T + t0 + j];
             }
         }
+        ms[0 * 64] = nn0;
+        ms[1 * 64] = nn1;
+        ms[2 * 64] = a00;
+        ms[3 * 64] = a01;
+        ms[4 * 64] = cnt0;
+        ms[5 * 64] = cnt1;
     }
     __syncthreads();
 
@@ -1056,7 +1096,7 @@ void k_guide_wave(DevArgs c) {
             const float* xp = xs + lik * B * 64 + lane;  // xp[b * 64]
             const double* sf = (lik ? c.sf_bc : c.sf) + r * B;
             // n = sum x_b is data: k_prepare leaves it in nobs (-1 where the (rep, guide) is masked)
-            const double nn = c.nobs[((long)lik * c.R + r) * G + g];
+            const double nn = ms[lik * 64];
             if (nn < 0.0) continue;
             // pass 1: S = sum e_b sf_b
             double S = 0.0;
@@ -1073,7 +1113,7 @@ void k_guide_wave(DevArgs c) {
                 for (int b = 0; b < kBMax; ++b) S += b < B ? (w0 * qv[b] + w1 * pv[b]) * sv[b] : 0.0;
             }
             if (lik == 0) BEAN_STAMP_AT(3);
-            const double a0 = lik ? c.a0_bc[g] : c.a0[g];
+            const double a0 = ms[(2 + lik) * 64];
             const double inv = frcp(S + kEps);
             // pass 2 (see k_lik): U_Q = sum k_b Q_b, V_Q = sum dpsi_b k_b Q_b, t_Q = sum sf_b Q_b
             double A0 = 0.0, lsum = 0.0, Ua = 0.0, Va = 0.0;
@@ -1145,12 +1185,7 @@ void k_guide_wave(DevArgs c) {
                 const double s = pi0 + pi1;
                 const double ls = s == 1.0 ? 0.0 : flog(s);
                 const double rs = s == 1.0 ? 1.0 : frcp(s);
-                double cnt0 = 0.0, cnt1 = 0.0;
-                for (int cc = 0; cc < c.C; ++cc) {
-                    const float* al = c.allele + (((long)r * c.C + cc) * G + g) * 2;
-                    cnt0 += (double)al[0];
-                    cnt1 += (double)al[1];
-                }
+                const double cnt0 = ms[4 * 64], cnt1 = ms[5 * 64];
                 const double pr0 = pi0 * rs, pr1 = pi1 * rs;
                 const bool in0 = pr0 > kProbEps && pr0 < 1.0 - kProbEps;
                 const bool in1 = pr1 > kProbEps && pr1 < 1.0 - kProbEps;

@@ -75,15 +75,38 @@ __device__ __forceinline__ double stirling_digamma_tail(double w) {
                                w * (7.5757575757575758e-3 + w * -2.1092796092796093e-2)))));
 }
 
+// Longer Stirling tails, valid to ~1e-14 / 3e-14 absolute for z >= 6 (terms through B16): used for
+// the small argument of a difference so that its shift loop (divergent, and followed by a log and a
+// division) is only needed below 6 instead of below 10.
+__device__ __forceinline__ double stirling_lgamma_tail_long(double r, double w) {
+    return r * (8.3333333333333333e-2 +
+                w * (-2.7777777777777778e-3 +
+                     w * (7.9365079365079365e-4 +
+                          w * (-5.9523809523809524e-4 +
+                               w * (8.4175084175084175e-4 +
+                                    w * (-1.9175269175269175e-3 +
+                                         w * (6.4102564102564103e-3 + w * -2.9550653594771242e-2)))))));
+}
+__device__ __forceinline__ double stirling_digamma_tail_long(double w) {
+    return w * (8.3333333333333333e-2 +
+                w * (-8.3333333333333333e-3 +
+                     w * (3.9682539682539683e-3 +
+                          w * (-4.1666666666666667e-3 +
+                               w * (7.5757575757575758e-3 +
+                                    w * (-2.1092796092796093e-2 +
+                                         w * (8.3333333333333333e-2 + w * -4.4325980392156863e-1)))))));
+}
+
 constexpr double kShift = 10.0;
+constexpr double kShiftLo = 6.0;
 constexpr double kHalfLog2Pi = 0.91893853320467274178;
 
 // Raise z to >= kShift, accumulating P = prod(z+i) and Q = dP/dz, so that
 // lgamma(z) = lgamma(z') - log P and digamma(z) = digamma(z') - Q / P.
-__device__ __forceinline__ void shift_up(double& z, double& P, double& Q) {
+__device__ __forceinline__ void shift_up(double& z, double& P, double& Q, double zmin = kShift) {
     P = 1.0;
     Q = 0.0;
-    while (z < kShift) {
+    while (z < zmin) {
         Q = fma(Q, z, P);
         P *= z;
         z += 1.0;
@@ -133,15 +156,15 @@ __device__ __forceinline__ DD lgamma_digamma_diff_inl(double a, double x) {
         return out;
     }
     double z1 = a, z2 = a + x, P1, Q1, P2, Q2;
-    shift_up(z1, P1, Q1);
+    shift_up(z1, P1, Q1, kShiftLo);  // the concentration: longer tails instead of a longer shift
     shift_up(z2, P2, Q2);
     const double l1 = flog(z1), l2 = flog(z2);
     const double r1 = frcp(z1), r2 = frcp(z2);
     const double w1 = r1 * r1, w2 = r2 * r2;
     double d = (z2 - 0.5) * l2 - (z1 - 0.5) * l1 - (z2 - z1) +
-               (stirling_lgamma_tail(r2, w2) - stirling_lgamma_tail(r1, w1));
+               (stirling_lgamma_tail(r2, w2) - stirling_lgamma_tail_long(r1, w1));
     double dp = (l2 - l1) - 0.5 * (r2 - r1) -
-                (stirling_digamma_tail(w2) - stirling_digamma_tail(w1));
+                (stirling_digamma_tail(w2) - stirling_digamma_tail_long(w1));
     if (P1 != 1.0) {
         d += flog(P1);
         dp += Q1 * frcp(P1);
