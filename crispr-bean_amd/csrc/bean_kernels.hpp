@@ -944,14 +944,7 @@ void k_guide_wave(DevArgs c) {
 #ifdef BEAN_STAMP
     const long wave_gid = (long)blockIdx.y * gridDim.x + blockIdx.x;
 #endif
-#ifdef BEAN_STAMP
-    {   // slot 0: start on the device-wide 100 MHz clock (s_memtime counters are not comparable
-        // across the chip)
-        unsigned long long t_;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-        if (lane == 0) c.dbg[wave_gid * 8] = t_;
-    }
-#endif
+    BEAN_STAMP_AT(0);
 
     // Guides are target-sorted, so the tile's targets are one contiguous range of at most 64:
     // lane i stages the 3 B table entries of target t0 + i (coalesced); every lane then reads its
@@ -1057,7 +1050,7 @@ void k_guide_wave(DevArgs c) {
             } else {
                 BEAN_STAMP_AT(1);
                 Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
-                const GammaPair gp = sample_gamma_pair(cq0, cq1, rng);
+                const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng);
                 const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
                 const double rs2 = frcp(gm0 + gm1);
                 pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
@@ -1226,13 +1219,7 @@ void k_guide_wave(DevArgs c) {
         atomicAdd(&c.loss_hist[ctr.slot], tot);
         if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = ctr;
     }
-#ifdef BEAN_STAMP
-    {
-        unsigned long long t_;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-        if (lane == 0) c.dbg[wave_gid * 8 + 7] = t_;
-    }
-#endif
+    BEAN_STAMP_AT(7);
 }
 
 // ------------------------------------------------- split form (variant, diagnostic A/B)

@@ -415,7 +415,7 @@ struct GammaPair {
 // alpha < 1 boost (the method behind torch's sample_gamma), sharing one
 // rejection loop: each round costs one Philox counter for both components (gamma_round_at),
 // and a wave only iterates until its slowest lane has accepted both.
-__device__ BEAN_NOINLINE GammaPair sample_gamma_pair(double a0, double a1, Rng rng) {
+__device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1, Rng rng) {
     double scale0 = 1.0, scale1 = 1.0;
     if (a0 < 1.0 || a1 < 1.0) {
         const Pair u = uniform_pair(rng);
@@ -462,6 +462,11 @@ __device__ BEAN_NOINLINE GammaPair sample_gamma_pair(double a0, double a1, Rng r
     out.g1 = scale1 * g1;
     out.k = rng.k;
     return out;
+}
+
+// out-of-line copy for the kernels whose call sites have many live registers
+__device__ BEAN_NOINLINE GammaPair sample_gamma_pair(double a0, double a1, Rng rng) {
+    return sample_gamma_pair_inl(a0, a1, rng);
 }
 
 // single draw (second component unused)

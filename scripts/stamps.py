@@ -27,17 +27,3 @@ t0 = s[:, 0].min()
 for nm, col in (("start", 0), ("end", 7)):
     v = s[:, col] - t0
     print(nm, "percentiles 0/10/50/90/100:", [int(np.percentile(v, q)) for q in (0, 10, 50, 90, 100)])
-# wave form: slots 0 and 7 are s_memrealtime (100 MHz, device-wide)
-if WAVE:
-    st = (s[:, 0] - s[:, 0].min()) / 100.0
-    en = (s[:, 7] - s[:, 0].min()) / 100.0
-    print("start us percentiles 0/25/50/75/95/100:", [round(float(np.percentile(st, q)), 1) for q in (0, 25, 50, 75, 95, 100)])
-    print("end   us percentiles 0/25/50/75/95/100:", [round(float(np.percentile(en, q)), 1) for q in (0, 25, 50, 75, 95, 100)])
-    du = en - st
-    print("wave duration us percentiles 0/25/50/75/95/100:", [round(float(np.percentile(du, q)), 1) for q in (0, 25, 50, 75, 95, 100)])
-    late = st > np.percentile(st, 90)
-    print("duration of the 10% latest starters (median us):", round(float(np.median(du[late])), 1), " earliest 10%:", round(float(np.median(du[st <= np.percentile(st, 10)])), 1))
-    mid = s[:, 1:7]
-    dd = np.diff(mid, axis=1)
-    for i, n in enumerate(names[1:6]):
-        print(f"  {n:28s} median {np.median(dd[:, i]):9.0f} cycles")
