@@ -132,7 +132,7 @@ struct DevArgs {
 };
 
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
-constexpr int kLanesPerTarget = 8;  // k_param: lanes sharing one target's Phi table entries
+constexpr int kLanesPerTarget = 4;  // k_param: lanes sharing one target's Phi table entries
 constexpr int kAMax = 8;
 constexpr int kWaveMisc = 6;  // k_guide_wave: per-guide values staged in LDS (count totals, a0, allele counts)
 constexpr int kBMax = 8;  // n_condits <= 8 (bean_hip_create)
