@@ -257,7 +257,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.not_loss_owner = (s->flags & BEAN_FLAG_NOT_LOSS_OWNER) ? 1 : 0;
     c->gsum_ws = nullptr;
     const uint64_t Rr = d.R;
-    const uint64_t n_gblk = (G + 255) / 256;
+    const uint64_t n_gblk = (G + kParamBlock - 1) / kParamBlock;
     d.n_gamma_blocks = (int)n_gblk;
     const uint64_t n_surv = (surv_mix ? 2 * G + Rr * G + n_gblk * (Rr + 1) + (Rr + 1) : 0) +
                             (surv_norm ? 2 * Rr * G + n_gblk * (Rr + 1) + (Rr + 1) + Rr : 0) +
@@ -445,10 +445,10 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
 // ------------------------------------------------------------------ launches
 static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_blocks) {
     const DevArgs& d = c->d;
-    n_target_blocks = d.wide_targets ? d.T : (int)(((long)d.T * kLanesPerTarget + 255) / 256);
+    n_target_blocks = d.wide_targets ? d.T : (int)(((long)d.T * kLanesPerTarget + kParamBlock - 1) / kParamBlock);
     int guide_blocks = 0;
-    if (d.family == kMultiMixture) guide_blocks = (int)(((long)d.G * kAMax + 255) / 256);  // kAMax lanes per guide
-    else if (d.family == kMixture || d.surv_q0lik) guide_blocks = (d.G + 255) / 256;
+    if (d.family == kMultiMixture) guide_blocks = (int)(((long)d.G * kAMax + kParamBlock - 1) / kParamBlock);  // kAMax lanes per guide
+    else if (d.family == kMixture || d.surv_q0lik) guide_blocks = (d.G + kParamBlock - 1) / kParamBlock;
     n_blocks = n_target_blocks + guide_blocks;
 }
 
@@ -458,7 +458,7 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
     grid_param(c, ntb, nb);
     DevArgs d = c->d;
     d.tgrad = tgrad;
-    hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP>), dim3(nb), dim3(256), 0, stream, d, ntb);
+    hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP>), dim3(nb), dim3(kParamBlock), 0, stream, d, ntb);
 }
 
 template <int B>
@@ -564,7 +564,7 @@ static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
 static void launch_sums(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     if (d.survival && (d.family == kMixture || d.surv_q0lik)) {
-        hipLaunchKernelGGL(k_q0_draws, dim3(d.n_gamma_blocks, (d.R + 1) / 2), dim3(256), 0, stream, d);
+        hipLaunchKernelGGL(k_q0_draws, dim3(d.n_gamma_blocks, (d.R + 1) / 2), dim3(kParamBlock), 0, stream, d);
         hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, stream, d);
     }
 }
@@ -769,7 +769,7 @@ extern "C" int bean_hip_sharded_guide(bean_hip_ctx* c, void* stream_) {
     if (c->slot_ptr[BEAN_BUF_XCHG_TGRAD]) {
         int ntb, nb;
         grid_param(c, ntb, nb);
-        hipLaunchKernelGGL(k_target_reduce, dim3(ntb), dim3(256), 0, stream, c->d,
+        hipLaunchKernelGGL(k_target_reduce, dim3(ntb), dim3(kParamBlock), 0, stream, c->d,
                            (double*)c->slot_ptr[BEAN_BUF_XCHG_TGRAD]);
     }
     HIP_OK(hipGetLastError());

@@ -132,6 +132,10 @@ struct DevArgs {
 };
 
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
+#ifndef BEAN_PARAM_BLOCK
+#define BEAN_PARAM_BLOCK 256
+#endif
+constexpr int kParamBlock = BEAN_PARAM_BLOCK;  // threads per block of k_param / k_target_reduce / k_q0_draws
 constexpr int kLanesPerTarget = 4;  // k_param: lanes sharing one target's Phi table entries
 constexpr int kAMax = 8;
 constexpr int kWaveMisc = 6;  // k_guide_wave: per-guide values staged in LDS (count totals, a0, allele counts)
@@ -450,7 +454,7 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
 // Sharded runs of families whose per-target parameters are replicated on every rank
 // (ControlNormal, tiling per-edit parameters): this rank's part of every target's likelihood
 // gradient, (2, T) doubles, for the host to all-reduce before k_param.
-__global__ __launch_bounds__(256) void k_target_reduce(DevArgs c, double* out) {
+__global__ __launch_bounds__(kParamBlock) void k_target_reduce(DevArgs c, double* out) {
     __shared__ double scratch[16];
     int t;
     bool active;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(256) void k_target_reduce(DevArgs c, double* out) {
 // -------------------------------------------------------------------- k_param
 // grid = n_target_blocks + n_guide_blocks, 256 threads.
 template <bool FINISH, bool ADAM, bool PREP>
-__global__ __launch_bounds__(256) void k_param(DevArgs c, int n_target_blocks) {
+__global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_blocks) {
     __shared__ double scratch[16];
     const StepCtr ctr = *c.ctrA;
     const unsigned long long s_fin = ctr.step;
@@ -1557,7 +1561,7 @@ void k_pi_terms(DevArgs c) {
 // parameter: gam[r, g] and the block partial sums gpart[block, r].  grid = (n_gamma_blocks, ceil(R/2)).
 // torch draws this site in float32 (the concentration is a float32 parameter): the gamma underflows
 // to 0 and is floored at FLT_MIN (ATen _s_dirichlet_cpu).
-__global__ __launch_bounds__(256) void k_q0_draws(DevArgs c) {
+__global__ __launch_bounds__(kParamBlock) void k_q0_draws(DevArgs c) {
     __shared__ double scratch[16];
     // replicates are drawn two at a time (one rejection loop per pair): grid.y = ceil(R / 2)
     const int gb = blockIdx.x, r0 = 2 * blockIdx.y, r1 = r0 + 1;
