@@ -228,6 +228,22 @@ __device__ __forceinline__ void emit_grad(const DevArgs& c, int which, long idx,
     }
 }
 
+// Same with the parameter and its moments already in registers (loaded before the gradient sums,
+// so that no load sits behind them); the updated parameter stays in `p` for the next draw.
+template <bool ADAM>
+__device__ __forceinline__ void emit_grad_pre(const DevArgs& c, int which, long idx, double grad, AdamCoef k,
+                                              float& p, float m, float v) {
+    const float gf = (float)grad;
+    if (ADAM) {
+        adam_update(p, m, v, gf, k);
+        c.p[which][idx] = p;
+        c.m[which][idx] = m;
+        c.v[which][idx] = v;
+    } else {
+        c.g[which][idx] = gf;
+    }
+}
+
 // --------------------------------------------------- tiling: per-guide finish
 // Guide part of k_param for MultiMixtureNormal: Dirichlet normalisers of the
 // A-component pi site, chain to alpha_pi through the two concentration maps the
@@ -489,6 +505,27 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         bool active;
         double gmu = 0.0, gy = 0.0, tab_mu = 0.0, tab_y = 0.0;
         target_of_thread(c, t, active);
+        // sorting families: the target's parameters, moments and last draw are loaded BEFORE the
+        // gradient sums (independent of them), not after
+        const bool sorting_t = active && !c.survival;
+        float pf[4] = {0.f, 0.f, 0.f, 0.f}, mf[4] = {0.f, 0.f, 0.f, 0.f}, vf[4] = {0.f, 0.f, 0.f, 0.f};
+        double eps1_f = 0.0, eps2_f = 0.0, mu_f = 0.0, y_f = 0.0;
+        if (sorting_t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pf[i] = c.p[i][t];
+                if (FINISH && ADAM) {
+                    mf[i] = c.m[i][t];
+                    vf[i] = c.v[i][t];
+                }
+            }
+            if (FINISH) {
+                eps1_f = c.eps_mu[t];
+                eps2_f = c.eps_sd[t];
+                mu_f = c.mu_t[t];
+                y_f = c.y_t[t];
+            }
+        }
         if (FINISH) {
             if (c.tgrad) {
                 // sharded run of a family whose per-target parameters are shared across shards: the
@@ -543,9 +580,6 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 if (c.eps_mu_out) c.eps_mu_out[t] = eps1;
             }
         } else if (active) {
-            float pf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pf[i] = c.p[i][t];
             const double l0 = c.pr_sd_loc ? c.pr_sd_loc[t] : 0.0;
             // LogNormal(sd_loc, sd_scale) prior: the default scale lives in a float32
             // tensor in the reference (model.py:405-406), so torch forms scale**2 and
@@ -561,8 +595,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 logs0 = (double)logf(s0f);
             }
             if (FINISH) {
-                const double eps1 = c.eps_mu[t], eps2 = c.eps_sd[t];
-                const double mu = c.mu_t[t], y = c.y_t[t];
+                const double eps1 = eps1_f, eps2 = eps2_f;
+                const double mu = mu_f, y = y_f;
                 const double s_mu = exp((double)pf[1]), s_sd = exp((double)pf[3]);
                 double logp_mu, dlogp_mu;
                 if (c.flags & kPriorNormalMu) {
@@ -583,13 +617,10 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 loss_fin = -logp_mu - logp_sd + logq_mu + logq_sd;
                 const double Gmu = gmu - dlogp_mu;
                 const double Gy = gy - dlogp_dy;
-                emit_grad<ADAM>(c, 0, t, Gmu, ak);
-                emit_grad<ADAM>(c, 1, t, Gmu * eps1 * s_mu - 1.0, ak);
-                emit_grad<ADAM>(c, 2, t, Gy - 1.0, ak);
-                emit_grad<ADAM>(c, 3, t, Gy * eps2 * s_sd - 1.0 - eps2 * s_sd, ak);
-                if (ADAM)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pf[i] = c.p[i][t];
+                emit_grad_pre<ADAM>(c, 0, t, Gmu, ak, pf[0], mf[0], vf[0]);
+                emit_grad_pre<ADAM>(c, 1, t, Gmu * eps1 * s_mu - 1.0, ak, pf[1], mf[1], vf[1]);
+                emit_grad_pre<ADAM>(c, 2, t, Gy - 1.0, ak, pf[2], mf[2], vf[2]);
+                emit_grad_pre<ADAM>(c, 3, t, Gy * eps2 * s_sd - 1.0 - eps2 * s_sd, ak, pf[3], mf[3], vf[3]);
             }
             if (PREP) {
                 double eps1, eps2;
