@@ -1,5 +1,6 @@
 // libbean_hip.so: C ABI over the BEAN SVI kernels (see include/bean_hip.h).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -541,9 +542,21 @@ static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
     const bool prof = c->profile && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {
+        // profile mode: the events carry the kernel's own begin / end timestamps (hipExtLaunchKernelGGL),
+        // i.e. the duration rocprofv3 --kernel-trace reports, without the dispatch gap
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, stream);
+        if (d.family == kMixture) {
+            if (d.flags & kAcc)
+                hipExtLaunchKernelGGL((k_guide_wave<kMixture, true>), grid, block, lds, stream, e0, e1, 0, d);
+            else
+                hipExtLaunchKernelGGL((k_guide_wave<kMixture, false>), grid, block, lds, stream, e0, e1, 0, d);
+        } else {
+            hipExtLaunchKernelGGL((k_guide_wave<kNormal, false>), grid, block, lds, stream, e0, e1, 0, d);
+        }
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+        return;
     }
     if (d.family == kMixture) {
         if (d.flags & kAcc)
@@ -552,11 +565,6 @@ static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
             hipLaunchKernelGGL((k_guide_wave<kMixture, false>), grid, block, lds, stream, d);
     } else {
         hipLaunchKernelGGL((k_guide_wave<kNormal, false>), grid, block, lds, stream, d);
-    }
-    if (prof) {
-        (void)hipEventRecord(e1, stream);
-        c->ev.push_back(e0);
-        c->ev.push_back(e1);
     }
 }
 
