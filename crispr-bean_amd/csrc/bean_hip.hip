@@ -585,23 +585,25 @@ static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
     const size_t lds = (size_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * 64 * sizeof(double) +
                        (size_t)2 * d.B * 64 * sizeof(float);
     const bool prof = c->profile && c->ev.size() < 8192;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof) {
+    if (prof) {  // events with the kernel's own timestamps, as in launch_guide_wave
+        hipEvent_t e0 = nullptr, e1 = nullptr;
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, stream);
-    }
-    if (d.survival) {
+        if (d.survival) {
+            if (acc) hipExtLaunchKernelGGL((k_guide_tiling_wave<true, true>), grid, block, lds, stream, e0, e1, 0, d);
+            else hipExtLaunchKernelGGL((k_guide_tiling_wave<false, true>), grid, block, lds, stream, e0, e1, 0, d);
+        } else {
+            if (acc) hipExtLaunchKernelGGL((k_guide_tiling_wave<true, false>), grid, block, lds, stream, e0, e1, 0, d);
+            else hipExtLaunchKernelGGL((k_guide_tiling_wave<false, false>), grid, block, lds, stream, e0, e1, 0, d);
+        }
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+    } else if (d.survival) {
         if (acc) hipLaunchKernelGGL((k_guide_tiling_wave<true, true>), grid, block, lds, stream, d);
         else hipLaunchKernelGGL((k_guide_tiling_wave<false, true>), grid, block, lds, stream, d);
     } else {
         if (acc) hipLaunchKernelGGL((k_guide_tiling_wave<true, false>), grid, block, lds, stream, d);
         else hipLaunchKernelGGL((k_guide_tiling_wave<false, false>), grid, block, lds, stream, d);
-    }
-    if (prof) {
-        (void)hipEventRecord(e1, stream);
-        c->ev.push_back(e0);
-        c->ev.push_back(e1);
     }
     hipLaunchKernelGGL(k_sum_trow, dim3((d.G + 255) / 256, kTNumPart), dim3(256), 0, stream, d);
 }
