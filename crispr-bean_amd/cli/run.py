@@ -108,7 +108,19 @@ def main(args, return_data=False):
     info(f"Running inference for {model_label}...")
     save_dict = dict()
     param_history_dict_negctrl = None
-    if args.fit_negctrl:
+    if args.load_existing:
+        # re-write the tables from a `--save-raw` pickle instead of fitting.  (The reference's branch,
+        # bean/cli/run.py:229-231, indexes the loaded dict as if it were the parameter store and
+        # fails; here the stored parameters are used.)
+        from ..model.run import ParamStore
+
+        with open(f"{prefix}/{model_label}.result{args.result_suffix}.pkl", "rb") as handle:
+            loaded = pkl.load(handle)
+        param_history_dict = ParamStore(loaded["params"])
+        if "negctrl" in loaded:
+            param_history_dict_negctrl = ParamStore(loaded["negctrl"]["params"])
+        save_dict = loaded
+    elif args.fit_negctrl:
         negctrl_model, negctrl_guide = identify_negctrl_model_guide(args, "X_bcmatch" in bdata.layers)
         idx = is_neg(ndata.screen)
         info(f"Using {len(idx)} negative control elements to adjust phenotypic effect sizes...")
@@ -118,9 +130,10 @@ def main(args, return_data=False):
         if args.selection == "survival":
             model = partial(model, mu_negctrl=(param_history_dict_negctrl["mu_loc"].detach().mean(),
                                                param_history_dict_negctrl["mu_scale"].detach().mean()))
-    save_dict["data"] = ndata
-    param_history_dict, save_dict_model = deepcopy(run_inference(model, guide, ndata, num_steps=args.n_iter))
-    save_dict.update(save_dict_model)
+    if not args.load_existing:
+        save_dict["data"] = ndata
+        param_history_dict, save_dict_model = deepcopy(run_inference(model, guide, ndata, num_steps=args.n_iter))
+        save_dict.update(save_dict_model)
     outfile = f"{prefix}/bean_element[sgRNA]_result.{model_label}{args.result_suffix}.csv"
     info(f"Done running inference. Writing result at {outfile}...")
     if args.save_raw:

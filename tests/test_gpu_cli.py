@@ -162,6 +162,12 @@ def test_longer_fit_moves_parameters_and_saves_raw(tmp_path):
     assert len(loss) == 300 and loss[-1] < loss[0]
     assert set(raw["params"]) == {"mu_loc", "mu_scale", "sd_loc", "sd_scale", "alpha_pi"}
     assert raw["params"]["mu_loc"].shape == (6, 1) and raw["params"]["alpha_pi"].shape == (30, 2)
+    # --load-existing re-writes the same tables from the pickle without fitting
+    el = pd.read_csv(f"{d}/bean_element_result.MixtureNormal.csv")
+    os.remove(f"{d}/bean_element_result.MixtureNormal.csv")
+    d2 = _run(tmp_path, "sorting", "variant", VAR, "--n-iter", "300", "--fit-negctrl", "--load-existing")
+    assert d2 == d
+    pd.testing.assert_frame_equal(pd.read_csv(f"{d}/bean_element_result.MixtureNormal.csv"), el)
 
 
 def test_build_prior_then_run_with_prior_params(tmp_path):
