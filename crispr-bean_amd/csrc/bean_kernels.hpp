@@ -1116,6 +1116,25 @@ void k_guide_wave(DevArgs c) {
         const double* sm = c.smask + r * B;
         const double epsB = kEps / (double)B;
         double a_mu = 0.0, a_y = 0.0, g0 = 0.0, g1 = 0.0, nll = 0.0;
+        // pass 1 of both likelihoods: S = sum_b e_b sf_b with the same e_b and each one's size factors
+        double S_x = 0.0, S_bc = 0.0;
+        {
+            const double* sfx = c.sf + r * B;
+            const double* sfb = use_bc ? c.sf_bc + r * B : sfx;
+            double ev[kBMax], s0v[kBMax], s1v[kBMax];
+#pragma unroll
+            for (int b = 0; b < kBMax; ++b) {
+                const int bb = b < B ? b : B - 1;
+                ev[b] = w0 * (MIX ? uniform_ld(c.P0, bb) : 0.0) + w1 * tp[bb * ntm];
+                s0v[b] = uniform_ld(sfx, bb);
+                s1v[b] = uniform_ld(sfb, bb);
+            }
+#pragma unroll
+            for (int b = 0; b < kBMax; ++b) {
+                S_x += b < B ? ev[b] * s0v[b] : 0.0;
+                S_bc += b < B ? ev[b] * s1v[b] : 0.0;
+            }
+        }
 #pragma unroll 1
         for (int lik = 0; lik < 2; ++lik) {
             if (lik == 1 && !use_bc) break;
@@ -1126,20 +1145,7 @@ void k_guide_wave(DevArgs c) {
             // n = sum x_b is data: k_prepare leaves it in nobs (-1 where the (rep, guide) is masked)
             const double nn = ms[lik * 64];
             if (nn < 0.0) continue;
-            // pass 1: S = sum e_b sf_b
-            double S = 0.0;
-            {
-                double pv[kBMax], sv[kBMax], qv[kBMax];
-#pragma unroll
-                for (int b = 0; b < kBMax; ++b) {
-                    const int bb = b < B ? b : B - 1;
-                    pv[b] = tp[bb * ntm];
-                    sv[b] = uniform_ld(sf, bb);
-                    qv[b] = MIX ? uniform_ld(c.P0, bb) : 0.0;
-                }
-#pragma unroll
-                for (int b = 0; b < kBMax; ++b) S += b < B ? (w0 * qv[b] + w1 * pv[b]) * sv[b] : 0.0;
-            }
+            const double S = lik ? S_bc : S_x;  // pass 1 (S = sum e_b sf_b) was done for both at once
             if (lik == 0) BEAN_STAMP_AT(3);
             const double a0 = ms[(2 + lik) * 64];
             const double inv = frcp(S + kEps);
