@@ -993,6 +993,11 @@ void k_guide_wave(DevArgs c) {
     double* ms = tabs + 3 * B * ntm + lane;               // ms[q * 64], q < kWaveMisc
     float* xs = (float*)(tabs + 3 * B * ntm + kWaveMisc * 64);  // counts: xs[(lik * B + b) * 64 + lane]
     const bool use_bc = (c.flags & kUseBc) != 0;
+    // per-guide scalars needed right after the barrier: loaded with the batch, kept in registers
+    int tcol = 0;
+    bool rgm = false;
+    float api0 = 0.f, api1 = 0.f;
+    double pa0 = 0.0;
     {
         // Everything the wave reads from global memory, issued as one batch before the first wait:
         // the counts of both likelihoods, the table columns, and the per-guide values that are only
@@ -1024,6 +1029,13 @@ void k_guide_wave(DevArgs c) {
             const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
             tv[q] = tab[(long)bb * T + t0 + (ok ? j : 0)];
             wbv[q] = ok ? wb : -1;
+        }
+        tcol = c.g2t[gc] - t0;
+        rgm = c.rg[rgc] != 0;
+        if (MIX) {
+            api0 = c.p[4][2 * gc];
+            api1 = c.p[4][2 * gc + 1];
+            pa0 = c.pi_a0[gc];
         }
         const double nn0 = c.nobs[rgc], nn1 = use_bc ? c.nobs[(long)c.R * G + rgc] : -1.0;
         const double a00 = c.a0[gc], a01 = use_bc ? c.a0_bc[gc] : 0.0;
@@ -1064,15 +1076,14 @@ void k_guide_wave(DevArgs c) {
     if (valid) {
         const long rgi = (long)r * G + g;
         const long RG = (long)c.R * G;
-        const double* tp = tabs + (c.g2t[g] - t0);  // this guide's column: tp[(which * B + b) * ntm]
-        const bool rgm = c.rg[rgi] != 0;
+        const double* tp = tabs + tcol;  // this guide's column: tp[(which * B + b) * ntm]
         double cp0 = 1.0, cp1 = 1.0, cq0 = 1.0, cq1 = 1.0;
         bool cl0 = false, cl1 = false;
         double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0;
         double dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
         if (MIX) {
-            const double al0 = (double)expf(c.p[4][2 * g]), al1 = (double)expf(c.p[4][2 * g + 1]);
-            const double rs = frcp(al0 + al1) * c.pi_a0[g];
+            const double al0 = (double)expf(api0), al1 = (double)expf(api1);
+            const double rs = frcp(al0 + al1) * pa0;
             cp0 = al0 * rs;
             cp1 = al1 * rs;
             cl0 = cp0 < 1e-5;
