@@ -103,38 +103,70 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [INCLUDE]
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+# Two builds of the same source: the tiling kernels keep per-allele state in registers, so the
+# number of alleles per guide they hold is a compile-time constant.  libbean_hip.so holds 8 (fast
+# path, everything that is not a tiling screen with more alleles), libbean_hip_a16.so holds 16.
+AMAX_BUILDS = (8, 16)
+
+
+def lib_path(amax: int = 8) -> str:
+    if amax == 8:
+        return LIB_PATH
+    return os.path.join(LIB_DIR, f"libbean_hip_a{amax}.so")
+
+
+def is_stale(amax: int = 8) -> bool:
+    path = lib_path(amax)
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile ``csrc/bean_hip.hip`` for gfx950 into ``lib/libbean_hip.so``."""
-    if not force and not is_stale():
-        return LIB_PATH
+def build_library(force: bool = False, verbose: bool = False, amax: int = 8) -> str:
+    """Compile ``csrc/bean_hip.hip`` for gfx950 into ``lib/libbean_hip[_a16].so``."""
+    path = lib_path(amax)
+    if not force and not is_stale(amax):
+        return path
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libbean_hip.so")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "bean_hip.hip"), "-o", LIB_PATH]
+    cmd = [hipcc] + HIPCC_FLAGS + ([] if amax == 8 else [f"-DBEAN_AMAX={amax}"]) + [
+        os.path.join(CSRC, "bean_hip.hip"), "-o", path]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
-    return LIB_PATH
+    return path
 
 
 _lib = None
+_libs = {}
 
 
-def load():
-    """Load the in-tree library; raises if it has not been built."""
+def load(amax: int = 8):
+    """Load the in-tree library (the build that holds ``amax`` alleles per guide); raises if it has
+    not been built."""
     global _lib
-    if _lib is not None:
+    if amax == 8 and _lib is not None:
         return _lib
+    if amax != 8:
+        if amax not in _libs:
+            import torch  # noqa: F401  (see below)
+
+            path = lib_path(amax)
+            if not os.path.exists(path):
+                raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                                   "crispr-bean_amd has no CPU fallback.")
+            lib = ctypes.CDLL(path)
+            for name, res, args in SYMBOLS:
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _libs[amax] = lib
+        return _libs[amax]
     # torch ships its own libamdhip64 (same SONAME as /opt/rocm's): import it
     # first so that this library binds to the one HIP runtime of the process.
     # Loaded the other way round, two runtimes coexist and device discovery
@@ -156,7 +188,7 @@ def load():
     return lib
 
 
-def check(status: int, what: str = ""):
+def check(status: int, what: str = "", lib=None):
     if status != 0:
-        msg = load().bean_hip_last_error().decode()
+        msg = (lib or load()).bean_hip_last_error().decode()
         raise RuntimeError(f"libbean_hip {what} failed: {msg}")

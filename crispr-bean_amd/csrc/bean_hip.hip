@@ -48,7 +48,9 @@ struct bean_hip_ctx {
     std::vector<hipEvent_t> ev;  // start/stop pairs
 };
 
-extern "C" const char* bean_hip_version(void) { return "bean_hip 0.1.0 (gfx950)"; }
+extern "C" const char* bean_hip_version(void) {
+    return BEAN_AMAX <= 8 ? "bean_hip 0.1.0 (gfx950)" : "bean_hip 0.1.0 (gfx950, 16 alleles per guide)";
+}
 extern "C" const char* bean_hip_last_error(void) { return g_err.c_str(); }
 
 static bool is_survival(const bean_hip_shape& s) { return s.selection == BEAN_SELECTION_SURVIVAL; }
@@ -202,7 +204,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         return fail("bean_hip_create: MixtureNormal requires n_max_alleles == 2");
     if (is_tiling(*s)) {
         if (s->n_max_alleles < 2 || s->n_max_alleles > kAMax)
-            return fail("bean_hip_create: MultiMixtureNormal requires n_max_alleles in [2, 8]");
+            return fail("bean_hip_create: MultiMixtureNormal requires n_max_alleles in [2, " + std::to_string(kAMax) +
+                        "] (libbean_hip.so holds 8 alleles per guide, libbean_hip_a16.so 16)");
         if (s->n_edits < 1 || s->n_targets != s->n_edits)
             return fail("bean_hip_create: MultiMixtureNormal requires n_targets == n_edits >= 1");
         if (s->n_a2e_nnz < 0) return fail("bean_hip_create: n_a2e_nnz must be >= 0");
@@ -229,6 +232,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         c->wave_guide = c->fused_guide;
         const char* tmode = getenv("BEAN_HIP_TILING");
         c->tiling_wave = !(tmode && !strcmp(tmode, "block"));
+#if BEAN_AMAX > 8
+        c->tiling_wave = true;  // this build has no block form
+#endif
     }
     c->graph_exec = nullptr;
     c->graph_chunk = 0;
@@ -475,6 +481,7 @@ static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 
             hipLaunchKernelGGL((k_guide_survival<B, kNormal, false>), grid, block, lds, stream, d);
         }
     } else if (d.family == kMultiMixture) {
+#if BEAN_AMAX <= 8
         const size_t tl = ((size_t)kTNumPart * 64 + 16) * sizeof(double);
         if (d.survival) {
             if (d.flags & kAcc)
@@ -486,6 +493,7 @@ static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 
         } else {
             hipLaunchKernelGGL((k_guide_tiling<B, false, false>), grid, block, tl, stream, d);
         }
+#endif
     }
 }
 

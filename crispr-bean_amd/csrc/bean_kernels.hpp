@@ -137,7 +137,10 @@ struct DevArgs {
 #endif
 constexpr int kParamBlock = BEAN_PARAM_BLOCK;  // threads per block of k_param / k_target_reduce / k_q0_draws
 constexpr int kLanesPerTarget = 4;  // k_param: lanes sharing one target's Phi table entries
-constexpr int kAMax = 8;
+#ifndef BEAN_AMAX
+#define BEAN_AMAX 8
+#endif
+constexpr int kAMax = BEAN_AMAX;  // alleles per guide the tiling kernels hold (8 in libbean_hip.so, 16 in libbean_hip_a16.so)
 constexpr int kWaveMisc = 6;  // k_guide_wave: per-guide values staged in LDS (count totals, a0, allele counts)
 constexpr int kBMax = 8;  // n_condits <= 8 (bean_hip_create)
 enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2 * kAMax,
@@ -1966,6 +1969,7 @@ __global__ __launch_bounds__(256) void k_allele(DevArgs c) {
     }
 }
 
+#if BEAN_AMAX <= 8  // the block form is the A/B reference of the default build only
 // ------------------------------------------------------------- k_guide_tiling
 // MultiMixtureNormal per (rep, guide): A-component Dirichlet draw, mixture over
 // the guide's alleles, both DirMult terms, Multinomial on control allele counts,
@@ -2283,6 +2287,8 @@ void k_guide_tiling(DevArgs c) {
         if (blockIdx.x == 0) *c.ctrA = ctr;
     }
 }
+
+#endif  // BEAN_AMAX <= 8
 
 // ------------------------------------------------------- k_guide_tiling_wave
 // Wave form of k_guide_tiling (same arithmetic): one single-wave workgroup per (64-guide tile,

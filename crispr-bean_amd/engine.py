@@ -74,7 +74,11 @@ class HipSVI:
         self.survival = survival
         if not torch.cuda.is_available():
             raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
-        self.lib = _lib.load()
+        # the tiling kernels hold 8 alleles per guide in the default build, 16 in the second one
+        amax = 8
+        if family == "MultiMixtureNormal" and int(getattr(data, "n_max_alleles", 2)) > 8:
+            amax = 16
+        self.lib = _lib.load(amax)
         self.device = torch.device(device if device is not None else "cuda:0")
         self.family = family
         self.data = data
@@ -152,7 +156,7 @@ class HipSVI:
         self._shape = shape
         handle = ctypes.c_void_p()
         with torch.cuda.device(dev):
-            _lib.check(self.lib.bean_hip_create(ctypes.byref(shape), ctypes.byref(handle)), "create")
+            self._check(self.lib.bean_hip_create(ctypes.byref(shape), ctypes.byref(handle)), "create")
         self._h = handle
         self._keep: Dict[str, torch.Tensor] = {}
         self.stream = torch.cuda.Stream(device=dev)
@@ -290,20 +294,23 @@ class HipSVI:
                 self._bind("EPS_NOISE_OUT", self._noise_out["eps_noise"])
         self.steps_done = 0
         with self._on_stream():
-            _lib.check(self.lib.bean_hip_prepare(self._h, self._sptr()), "prepare")
+            self._check(self.lib.bean_hip_prepare(self._h, self._sptr()), "prepare")
 
     # -------------------------------------------------------------- plumbing
+    def _check(self, status: int, what: str = ""):
+        _lib.check(status, what, self.lib)
+
     def _bind(self, slot_name: str, t: torch.Tensor):
         self._bind_slot(_lib.BUF[slot_name], t, slot_name)
 
     def _bind_slot(self, slot: int, t: Optional[torch.Tensor], key: str):
         if t is None:
             self._keep.pop(key, None)
-            _lib.check(self.lib.bean_hip_bind(self._h, slot, None, 0), f"bind {key}")
+            self._check(self.lib.bean_hip_bind(self._h, slot, None, 0), f"bind {key}")
             return
         assert t.is_cuda and t.is_contiguous(), key
         self._keep[key] = t
-        _lib.check(
+        self._check(
             self.lib.bean_hip_bind(self._h, slot, ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size()),
             f"bind {key}",
         )
@@ -351,15 +358,15 @@ class HipSVI:
         x = self.exchange_buffers()
         sp = self._sptr()
         with self._on_stream(), torch.cuda.stream(self.stream):
-            _lib.check(self.lib.bean_hip_sharded_begin(self._h, int(seed), first, int(n_steps), sp), "sharded_begin")
+            self._check(self.lib.bean_hip_sharded_begin(self._h, int(seed), first, int(n_steps), sp), "sharded_begin")
             for i in range(n_steps):
-                _lib.check(self.lib.bean_hip_sharded_sums(self._h, sp), "sharded_sums")
+                self._check(self.lib.bean_hip_sharded_sums(self._h, sp), "sharded_sums")
                 if "gsum" in x:
                     all_reduce(x["gsum"])
-                _lib.check(self.lib.bean_hip_sharded_guide(self._h, sp), "sharded_guide")
+                self._check(self.lib.bean_hip_sharded_guide(self._h, sp), "sharded_guide")
                 if "tgrad" in x:
                     all_reduce(x["tgrad"])
-                _lib.check(self.lib.bean_hip_sharded_update(self._h, 1 if i == n_steps - 1 else 0, sp),
+                self._check(self.lib.bean_hip_sharded_update(self._h, 1 if i == n_steps - 1 else 0, sp),
                            "sharded_update")
         self.steps_done = first + n_steps
 
@@ -367,7 +374,7 @@ class HipSVI:
     def phase(self, name: str, *args):
         fn = getattr(self.lib, "bean_hip_sharded_" + name)
         with self._on_stream():
-            _lib.check(fn(self._h, *args, self._sptr()), "sharded_" + name)
+            self._check(fn(self._h, *args, self._sptr()), "sharded_" + name)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -412,7 +419,7 @@ class HipSVI:
         """One ELBO evaluation: returns ``(loss, {name: grad})`` w.r.t. the
         unconstrained parameters; parameters are not modified."""
         with self._on_stream():
-            _lib.check(
+            self._check(
                 self.lib.bean_hip_elbo_grad(self._h, int(seed), int(step), int(loss_index), self._sptr()),
                 "elbo_grad",
             )
@@ -441,7 +448,7 @@ class HipSVI:
 
     def adam(self, t: int):
         with self._on_stream():
-            _lib.check(self.lib.bean_hip_adam(self._h, int(t), self._sptr()), "adam")
+            self._check(self.lib.bean_hip_adam(self._h, int(t), self._sptr()), "adam")
 
     def run(self, n_steps: int, seed: int = 101, graph_chunk: int = 50, first_step: Optional[int] = None):
         """Enqueue ``n_steps`` fused SVI steps (no host synchronisation)."""
@@ -449,7 +456,7 @@ class HipSVI:
         if first + n_steps > self.loss_hist.numel():
             raise ValueError("loss history too small: raise num_steps / loss_capacity")
         with self._on_stream():
-            _lib.check(
+            self._check(
                 self.lib.bean_hip_svi_run(self._h, int(seed), first, int(n_steps), int(graph_chunk), self._sptr()),
                 "svi_run",
             )
@@ -460,11 +467,11 @@ class HipSVI:
         return self.loss_hist[: self.steps_done].cpu().tolist()
 
     def set_profile(self, enable: bool):
-        _lib.check(self.lib.bean_hip_set_profile(self._h, int(bool(enable))), "set_profile")
+        self._check(self.lib.bean_hip_set_profile(self._h, int(bool(enable))), "set_profile")
 
     def get_profile(self):
         avg, n = ctypes.c_double(0.0), ctypes.c_uint64(0)
-        _lib.check(self.lib.bean_hip_get_profile(self._h, ctypes.byref(avg), ctypes.byref(n)), "get_profile")
+        self._check(self.lib.bean_hip_get_profile(self._h, ctypes.byref(avg), ctypes.byref(n)), "get_profile")
         return avg.value, n.value
 
     @property

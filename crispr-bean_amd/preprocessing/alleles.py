@@ -14,9 +14,10 @@ Two deliberate differences, both stated to the user when they apply:
   objects whose hash depends on the process' string-hash seed, so its edit numbering is not
   reproducible run to run; any numbering is equivalent up to a permutation of the rows of the
   result table);
-* the HIP kernels hold at most ``MAX_ALLELES`` = 8 alleles per guide (7 edited + the unedited one).
-  A table with more alleles per guide - normally one that has not been through ``bean filter`` -
-  is reduced to each guide's 7 most abundant alleles; the reads of the dropped alleles fall into
+* the HIP kernels hold at most ``MAX_ALLELES`` = 16 alleles per guide (15 edited + the unedited one;
+  the default library build holds 8, ``libbean_hip_a16.so`` 16).  A table with more alleles per
+  guide - normally one that has not been through ``bean filter`` - is reduced to each guide's 15
+  most abundant alleles; the reads of the dropped alleles fall into
   the unedited allele exactly as they do for alleles ``bean filter`` removes
   (``data_class.py:773-777``).
 """
@@ -30,7 +31,7 @@ import numpy as np
 import pandas as pd
 import torch
 
-MAX_ALLELES = 8
+MAX_ALLELES = 16
 _REV = {"A": "T", "C": "G", "T": "A", "G": "C", "-": "-"}
 _NT_EDIT = re.compile(r"(((chr)?\w+|nan):)?-?\d+:-?\d+:[+-]:[A-Z*-]>[A-Z*-]")
 

@@ -80,22 +80,22 @@ def test_tiling_mini_screen_builds_consistent_tensors():
     with pytest.warns(UserWarning, match="most abundant alleles"):
         d = DATACLASS_DICT["sorting"]["MultiMixtureNormal"](
             s, sample_mask_column=None, allele_df_key="allele_counts", control_condition="bulk")
-    assert (d.n_reps, d.n_condits, d.n_guides, d.n_max_alleles) == (2, 5, 30, 8)
+    assert (d.n_reps, d.n_condits, d.n_guides, d.n_max_alleles) == (2, 5, 30, 16)
     assert d.n_edits == len(d.edit_index) == d.n_targets and d.n_edits > 20
     d.validate()
     # alleles partition the barcode-matched reads
     assert torch.equal(d.allele_counts.sum(-1), d.X_bcmatch)
     assert torch.equal(d.allele_counts_control.sum(-1), d.X_bcmatch_control)
-    assert d.allele_counts_control.shape == (2, 1, 30, 8) and d.pi_a0.shape == (30,)
+    assert d.allele_counts_control.shape == (2, 1, 30, 16) and d.pi_a0.shape == (30,)
     # the dense view agrees with a direct parse of the kept rows
     dense = d.allele_to_edit_dense()
-    assert dense.shape == (30, 7, d.n_edits) and set(np.unique(dense.numpy())) <= {0.0, 1.0}
+    assert dense.shape == (30, 15, d.n_edits) and set(np.unique(dense.numpy())) <= {0.0, 1.0}
     tbl = s.uns["allele_counts"]
     tot = tbl[[c for c in tbl.columns if c.startswith("rep")]].sum(axis=1)
     g0 = s.guides.index[0]
     top = tbl.loc[tbl.guide == g0].assign(t=tot[tbl.guide == g0]).sort_values("t", ascending=False, kind="stable")
     kept = set()
-    for a in top["allele"].head(7):
+    for a in top["allele"].head(15):
         kept.update(alleles.allele_edits(a))
     got = {e for e, j in d.edit_index.items() if dense[0, :, j].sum() > 0}
     assert got == kept

@@ -406,6 +406,8 @@ def _compare_tiling(engine, data, kw, seed=7, step=2):
     (dict(n_guides=130, n_reps=9, n_max_alleles=3), {}),
     (dict(n_guides=65, n_reps=1, n_max_alleles=2), {}),
     (dict(n_guides=200, n_reps=2, n_max_alleles=8, bins=((0.0, 0.3), (0.3, 1.0))), {}),
+    (dict(n_guides=150, n_reps=2, n_max_alleles=13), {}),  # > 8 alleles per guide: the 16-allele build
+    (dict(n_guides=100, n_reps=3, n_max_alleles=16, with_accessibility=True), dict(scale_by_accessibility=True)),
 ])
 def test_tiling_elbo_and_gradients_match_oracle(engine, gen_kw, kw):
     data = make_sorting_tiling_screen(seed=4, **gen_kw)
@@ -428,7 +430,7 @@ def test_tiling_screen_built_from_h5ad_matches_oracle(engine):
         warnings.simplefilter("ignore")
         data = DATACLASS_DICT["sorting"]["MultiMixtureNormal"](
             s, sample_mask_column=None, allele_df_key="allele_counts", control_condition="bulk")
-    assert data.n_max_alleles == 8 and data.n_guides == 30
+    assert data.n_max_alleles == 16 and data.n_guides == 30  # fitted by libbean_hip_a16.so
     _compare_tiling(engine, data, {})
 
 
