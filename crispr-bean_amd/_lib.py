@@ -103,9 +103,10 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [INCLUDE]
 
 
-# Two builds of the same source: the tiling kernels keep per-allele state in registers, so the
-# number of alleles per guide they hold is a compile-time constant.  libbean_hip.so holds 8 (fast
-# path, everything that is not a tiling screen with more alleles), libbean_hip_a16.so holds 16.
+# Two builds of the same source: the kernels keep per-allele / per-condition state in registers and
+# unrolled loops, so the number of alleles per guide and of conditions (sorting bins / timepoints)
+# they hold are compile-time constants.  libbean_hip.so holds 8 of each (the fast path);
+# libbean_hip_a16.so holds 16 of each and is loaded for the screens that need it.
 AMAX_BUILDS = (8, 16)
 
 
@@ -132,7 +133,7 @@ def build_library(force: bool = False, verbose: bool = False, amax: int = 8) -> 
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libbean_hip.so")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ([] if amax == 8 else [f"-DBEAN_AMAX={amax}"]) + [
+    cmd = [hipcc] + HIPCC_FLAGS + ([] if amax == 8 else [f"-DBEAN_AMAX={amax}", f"-DBEAN_BMAX={amax}"]) + [
         os.path.join(CSRC, "bean_hip.hip"), "-o", path]
     if verbose:
         print(" ".join(cmd))

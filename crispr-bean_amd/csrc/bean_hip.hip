@@ -49,7 +49,7 @@ struct bean_hip_ctx {
 };
 
 extern "C" const char* bean_hip_version(void) {
-    return BEAN_AMAX <= 8 ? "bean_hip 0.1.0 (gfx950)" : "bean_hip 0.1.0 (gfx950, 16 alleles per guide)";
+    return BEAN_AMAX <= 8 ? "bean_hip 0.1.0 (gfx950)" : "bean_hip 0.1.0 (gfx950, 16 alleles per guide / 16 conditions)";
 }
 extern "C" const char* bean_hip_last_error(void) { return g_err.c_str(); }
 
@@ -198,8 +198,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         return fail("bean_hip_create: unknown family");
     if (s->n_reps < 1 || s->n_guides < 1 || s->n_targets < 1)
         return fail("bean_hip_create: R, G, T must be >= 1");
-    if (s->n_condits < 1 || s->n_condits > 8)
-        return fail("bean_hip_create: n_condits must be in [1, 8]");
+    if (s->n_condits < 1 || s->n_condits > kBMax)
+        return fail("bean_hip_create: n_condits must be in [1, " + std::to_string(kBMax) +
+                    "] (libbean_hip.so holds 8 conditions, libbean_hip_a16.so 16)");
     if (s->family == BEAN_FAMILY_MIXTURE_NORMAL && s->n_max_alleles != 2)
         return fail("bean_hip_create: MixtureNormal requires n_max_alleles == 2");
     if (is_tiling(*s)) {
@@ -653,7 +654,19 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
         case 5: launch_guide_b<5>(c, stream, grid, block, lds); break;
         case 6: launch_guide_b<6>(c, stream, grid, block, lds); break;
         case 7: launch_guide_b<7>(c, stream, grid, block, lds); break;
+#if BEAN_BMAX <= 8
         default: launch_guide_b<8>(c, stream, grid, block, lds); break;
+#else
+        case 8: launch_guide_b<8>(c, stream, grid, block, lds); break;
+        case 9: launch_guide_b<9>(c, stream, grid, block, lds); break;
+        case 10: launch_guide_b<10>(c, stream, grid, block, lds); break;
+        case 11: launch_guide_b<11>(c, stream, grid, block, lds); break;
+        case 12: launch_guide_b<12>(c, stream, grid, block, lds); break;
+        case 13: launch_guide_b<13>(c, stream, grid, block, lds); break;
+        case 14: launch_guide_b<14>(c, stream, grid, block, lds); break;
+        case 15: launch_guide_b<15>(c, stream, grid, block, lds); break;
+        default: launch_guide_b<16>(c, stream, grid, block, lds); break;
+#endif
     }
     if (d.surv_q0lik)  // projection term of the G-dimensional Dirichlet's pathwise gradient
         hipLaunchKernelGGL(k_sum_q, dim3(d.R), dim3(1024), 0, stream, d);

@@ -142,7 +142,10 @@ constexpr int kLanesPerTarget = 4;  // k_param: lanes sharing one target's Phi t
 #endif
 constexpr int kAMax = BEAN_AMAX;  // alleles per guide the tiling kernels hold (8 in libbean_hip.so, 16 in libbean_hip_a16.so)
 constexpr int kWaveMisc = 6;  // k_guide_wave: per-guide values staged in LDS (count totals, a0, allele counts)
-constexpr int kBMax = 8;  // n_condits <= 8 (bean_hip_create)
+#ifndef BEAN_BMAX
+#define BEAN_BMAX 8
+#endif
+constexpr int kBMax = BEAN_BMAX;  // n_condits <= kBMax (bean_hip_create): 8 in libbean_hip.so, 16 in libbean_hip_a16.so
 enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2 * kAMax,
              kTGsig = 2 + 2 * kAMax + (kAMax - 1), kTNumPart = 2 + 2 * kAMax + 2 * (kAMax - 1) };
 

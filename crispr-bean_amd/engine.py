@@ -76,7 +76,7 @@ class HipSVI:
             raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
         # the tiling kernels hold 8 alleles per guide in the default build, 16 in the second one
         amax = 8
-        if family == "MultiMixtureNormal" and int(getattr(data, "n_max_alleles", 2)) > 8:
+        if (family == "MultiMixtureNormal" and int(getattr(data, "n_max_alleles", 2)) > 8) or data.n_condits > 8:
             amax = 16
         self.lib = _lib.load(amax)
         self.device = torch.device(device if device is not None else "cuda:0")

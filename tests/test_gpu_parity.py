@@ -160,7 +160,7 @@ def test_ragged_shapes(engine, n_guides, n_reps):
     _compare(engine, "MixtureNormal", data, {})
 
 
-@pytest.mark.parametrize("n_bins", [1, 2, 3, 5, 7])
+@pytest.mark.parametrize("n_bins", [1, 2, 3, 5, 7, 8, 11, 15])  # > 7 bins (+ bulk): the 16-condition build
 def test_bin_counts(engine, n_bins):
     edges = np.linspace(0, 1, n_bins + 1)
     bins = tuple((float(edges[i]), float(edges[i + 1])) for i in range(n_bins))
@@ -407,6 +407,8 @@ def _compare_tiling(engine, data, kw, seed=7, step=2):
     (dict(n_guides=65, n_reps=1, n_max_alleles=2), {}),
     (dict(n_guides=200, n_reps=2, n_max_alleles=8, bins=((0.0, 0.3), (0.3, 1.0))), {}),
     (dict(n_guides=150, n_reps=2, n_max_alleles=13), {}),  # > 8 alleles per guide: the 16-allele build
+    (dict(n_guides=120, n_reps=2, n_max_alleles=4,
+          bins=tuple((i / 10, (i + 1) / 10) for i in range(10))), {}),  # 10 bins + bulk
     (dict(n_guides=100, n_reps=3, n_max_alleles=16, with_accessibility=True), dict(scale_by_accessibility=True)),
 ])
 def test_tiling_elbo_and_gradients_match_oracle(engine, gen_kw, kw):
@@ -520,6 +522,7 @@ def _compare_survival(engine, family, data, kw, seed=7, step=2):
     (dict(n_guides=130, n_reps=9, times=(0.0, 7.0, 14.0)), {}),
     (dict(n_guides=300, n_reps=2), dict(mu_negctrl=(0.05, 0.2))),
     (dict(n_guides=65, n_reps=1, times=(0.0, 2.0, 4.0, 6.0, 8.0, 10.0, 12.0, 14.0)), {}),
+    (dict(n_guides=120, n_reps=2, times=tuple(float(t) for t in range(0, 22, 2))), {}),  # 11 timepoints
 ])
 def test_survival_mixture_matches_oracle(engine, gen_kw, kw):
     data = make_survival_variant_screen(seed=4, **gen_kw)
