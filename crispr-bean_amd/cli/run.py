@@ -28,7 +28,31 @@ logger = logging.getLogger("bean_run")
 info, warn = logger.info, logger.warning
 
 
+def _init_distributed():
+    """`torchrun --nproc-per-node N bin/bean run ...`: one process per GPU; every rank builds the
+    same screen, `run_inference` shards the guides, rank 0 writes the tables.  Returns (rank, world).
+    BEAN_DIST_BACKEND=gloo and BEAN_DIST_SINGLE_DEVICE=1 exist for rehearsals on a one-GPU box."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    if not dist.is_initialized():
+        local = 0 if os.environ.get("BEAN_DIST_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        backend = os.environ.get("BEAN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
 def main(args, return_data=False):
+    rank, world = (0, 1) if return_data else _init_distributed()
+    if rank != 0:  # one banner / one log / one set of tables
+        logger.setLevel(logging.ERROR)
     print(r"""
     _ _
   /  \ '\                       
@@ -69,7 +93,7 @@ def main(args, return_data=False):
         allele_df_key=args.allele_df_key,
         control_guide_tag=args.control_guide_tag,
     )
-    if args.save_raw:
+    if args.save_raw and rank == 0:
         pkl.dump(bdata, open(f"{prefix}/ndata.pkl", "wb"))
     if return_data:
         return ndata
@@ -134,6 +158,8 @@ def main(args, return_data=False):
         save_dict["data"] = ndata
         param_history_dict, save_dict_model = deepcopy(run_inference(model, guide, ndata, num_steps=args.n_iter))
         save_dict.update(save_dict_model)
+    if rank != 0:
+        return prefix
     outfile = f"{prefix}/bean_element[sgRNA]_result.{model_label}{args.result_suffix}.csv"
     info(f"Done running inference. Writing result at {outfile}...")
     if args.save_raw:

@@ -192,3 +192,35 @@ def test_build_prior_then_run_with_prior_params(tmp_path):
     d2 = _run(tmp_path / "b2", "sorting", "variant", VAR, "--n-iter", "10", "--prior-params", prior_path)
     el = pd.read_csv(f"{d2}/bean_element_result.MixtureNormal.csv")
     assert len(el) == 6 and np.isfinite(el[["mu", "mu_sd", "mu_z", "sd"]].values).all()
+
+
+def test_two_rank_cli_writes_the_single_process_tables(tmp_path):
+    """`torchrun --nproc-per-node 2 bin/bean run ...` (rehearsed on one GPU over gloo): the guides
+    are sharded over the ranks, rank 0 writes the tables; for the variant sorting family the result
+    is the single-process result bit for bit, for tiling up to the regrouping of float64 sums."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BEAN_DIST_BACKEND="gloo", BEAN_DIST_SINGLE_DEVICE="1")
+    for design, path, extra, label in (
+        ("variant", VAR, [], "MixtureNormal"),
+        ("tiling", TILING, ["--allele-df-key", "allele_counts", "--control-guide-tag", "None"], "MultiMixtureNormal"),
+    ):
+        argv = ["sorting", design, path, "--n-iter", "30", "--repguide-mask", "None", *extra]
+        d1 = _run(tmp_path / f"single_{design}", *argv)
+        out2 = str(tmp_path / f"two_{design}")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(root, "bin", "bean"), "run",
+               *argv, "-o", out2, "--sample-mask-col", ""]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        (d2,) = [os.path.join(out2, p) for p in os.listdir(out2) if p.startswith("bean_run_result.")]
+        a = pd.read_csv(f"{d1}/bean_element_result.{label}.csv")
+        b = pd.read_csv(f"{d2}/bean_element_result.{label}.csv")
+        assert list(a.columns) == list(b.columns) and len(a) == len(b)
+        num = [c for c in ("mu", "mu_sd", "mu_z", "sd") if c in a.columns]
+        if design == "variant":
+            pd.testing.assert_frame_equal(a, b)
+        else:
+            np.testing.assert_allclose(a[num].values, b[num].values, rtol=1e-5, atol=1e-7)
