@@ -39,6 +39,7 @@ struct bean_hip_ctx {
     int* tile_targets_dev;
     bool tiling_wave;  // tiling families, default: k_guide_tiling_wave (BEAN_HIP_TILING=block: k_guide_tiling)
     double* gsum_ws;  // library-owned normaliser buffer (replaced by BEAN_BUF_XCHG_GSUM when bound)
+    double* sq_ws;    // library-owned projection sums (replaced by BEAN_BUF_XCHG_SQ when bound)
     // graph cache
     hipGraphExec_t graph_exec;
     int graph_chunk;
@@ -101,7 +102,9 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_X0_IN: case BEAN_BUF_X0_OUT:
             return ((is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) || is_surv_normal(s)) ? 8 * R * G : 0;
         case BEAN_BUF_NEGCTRL_MASK: return is_surv_normal(s) ? G : 0;
-        case BEAN_BUF_XCHG_GSUM: return (is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) ? 8 * (R + 1) : 0;
+        case BEAN_BUF_XCHG_GSUM:
+            return ((is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) || is_surv_normal(s)) ? 8 * (R + 1) : 0;
+        case BEAN_BUF_XCHG_SQ: return is_surv_normal(s) ? 8 * R : 0;
         case BEAN_BUF_XCHG_TGRAD: return 8 * 2 * T;
         case BEAN_BUF_EPS_U_IN: case BEAN_BUF_EPS_U_OUT: return (is_survival(s) && is_mixture(s)) ? 8 * G : 0;
         case BEAN_BUF_TARGET_OFFSETS: return is_tiling(s) ? 0 : 4 * (T + 1);
@@ -169,6 +172,8 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.negctrl = (const uint8_t*)P(BEAN_BUF_NEGCTRL_MASK);
     if (P(BEAN_BUF_XCHG_GSUM)) d.gsum = (double*)P(BEAN_BUF_XCHG_GSUM);
     else d.gsum = c->gsum_ws;
+    if (P(BEAN_BUF_XCHG_SQ)) d.sq = (double*)P(BEAN_BUF_XCHG_SQ);
+    else d.sq = c->sq_ws;
     d.ctrl_time = (const double*)P(BEAN_BUF_CONTROL_TIME);
     d.log_obs0 = (const double*)P(BEAN_BUF_LOG_OBS0);
     d.x0_in = (const double*)P(BEAN_BUF_X0_IN);
@@ -191,8 +196,6 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (!s || !out) return fail("bean_hip_create: null argument");
     if (s->selection != BEAN_SELECTION_SORTING && s->selection != BEAN_SELECTION_SURVIVAL)
         return fail("bean_hip_create: unknown selection");
-    if (is_surv_normal(*s) && s->n_guides_total > 0 && s->n_guides_total != s->n_guides)
-        return fail("bean_hip_create: the survival NormalModel couples all guides and cannot be guide-sharded");
     if (is_survival(*s) && !(s->negctrl_scale > 0.0)) return fail("bean_hip_create: negctrl_scale must be > 0");
     if (s->family < BEAN_FAMILY_NORMAL || s->family > BEAN_FAMILY_MULTI_MIXTURE)
         return fail("bean_hip_create: unknown family");
@@ -264,6 +267,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.surv_q0lik = surv_norm ? 1 : 0;
     d.not_loss_owner = (s->flags & BEAN_FLAG_NOT_LOSS_OWNER) ? 1 : 0;
     c->gsum_ws = nullptr;
+    c->sq_ws = nullptr;
     const uint64_t Rr = d.R;
     const uint64_t n_gblk = (G + kParamBlock - 1) / kParamBlock;
     d.n_gamma_blocks = (int)n_gblk;
@@ -348,6 +352,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         c->gsum_ws = d.gsum;
         d.gq = w; w += Rr * G;
         d.sq = w; w += Rr;
+        c->sq_ws = d.sq;
     }
     d.ctrA = (StepCtr*)w; w += 2;
     d.ctrB = (StepCtr*)w; w += 2;
@@ -383,7 +388,8 @@ extern "C" int bean_hip_bind(bean_hip_ctx* c, int slot, void* ptr, uint64_t nbyt
     c->slot_bytes[slot] = ptr ? nbytes : 0;
     sync_devargs(c);
     drop_graph(c);
-    if (slot < BEAN_BUF_P_MU_LOC && slot != BEAN_BUF_XCHG_GSUM && slot != BEAN_BUF_XCHG_TGRAD)
+    if (slot < BEAN_BUF_P_MU_LOC && slot != BEAN_BUF_XCHG_GSUM && slot != BEAN_BUF_XCHG_TGRAD &&
+        slot != BEAN_BUF_XCHG_SQ)
         c->prepared = false;  // data changed: the data-only precomputation is stale
     return 0;
 }
@@ -774,6 +780,9 @@ extern "C" int bean_hip_sharded_begin(bean_hip_ctx* c, uint64_t seed, uint64_t f
         return fail("bean_hip_sharded_begin: loss_hist too small for first_step + n_steps");
     if (is_survival(c->shape) && c->shape.family == BEAN_FAMILY_MIXTURE_NORMAL && !c->slot_ptr[BEAN_BUF_XCHG_GSUM])
         return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_GSUM for a sharded survival MixtureNormal fit");
+    if (is_surv_normal(c->shape) && (!c->slot_ptr[BEAN_BUF_XCHG_GSUM] || !c->slot_ptr[BEAN_BUF_XCHG_SQ]))
+        return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_GSUM and BEAN_BUF_XCHG_SQ for a sharded survival "
+                    "NormalModel fit");
     if ((c->shape.family == BEAN_FAMILY_CONTROL_NORMAL || is_tiling(c->shape)) && !c->slot_ptr[BEAN_BUF_XCHG_TGRAD])
         return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_TGRAD for a sharded ControlNormal / tiling fit");
     hipStream_t stream = (hipStream_t)stream_;

@@ -843,7 +843,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
             double lg_p, dg_p;
             lgamma_digamma(pr, lg_p, dg_p);
             loss_fin += Rf * (lg_p - lg_a);
-            if (g == 0) {
+            if (c.g_off + g == 0) {  // once per screen (guide 0 of the whole screen)
                 double lg_ps, dg_ps;
                 lgamma_digamma(pr * (double)c.G_tot, lg_ps, dg_ps);
                 loss_fin += Rf * (lg_tot - lg_ps);

@@ -69,8 +69,6 @@ class HipSVI:
         self.surv_normal = surv_normal
         if surv_normal and prior_params is not None and "initial_abundance" in prior_params:
             raise NotImplementedError("prior_params['initial_abundance'] is not supported by the HIP engine")
-        if surv_normal and n_guides_total and n_guides_total != data.n_guides:
-            raise NotImplementedError("the survival NormalModel couples all guides (Dirichlet over guides): single GPU")
         self.survival = survival
         if not torch.cuda.is_available():
             raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
@@ -239,8 +237,9 @@ class HipSVI:
         if survival and family == "MixtureNormal":  # q0 = ones(G) / G over the WHOLE screen (survival_model.py:660-664)
             g_all = int(n_guides_total) if n_guides_total else G
             init["q0"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(g_all))))
-        if surv_normal:  # initial_abundance = ones(G) / G (survival_model.py:630-634)
-            init["initial_abundance"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(G))))
+        if surv_normal:  # initial_abundance = ones(G) / G over the WHOLE screen (survival_model.py:630-634)
+            g_all = int(n_guides_total) if n_guides_total else G
+            init["initial_abundance"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(g_all))))
         if mixture:
             init["alpha_pi"] = torch.zeros((G, A))
             if tiling:  # alpha_pi0[~allele_mask] = epsilon (model.py:643)
@@ -341,9 +340,12 @@ class HipSVI:
         if getattr(self, "_xchg", None) is None:
             self._xchg = {}
             R = self.data.n_reps
-            if self.survival and self.family == "MixtureNormal":
+            if self.survival and self.family in ("MixtureNormal", "Normal"):
                 self._xchg["gsum"] = torch.zeros(R + 1, dtype=torch.float64, device=self.device)
                 self._bind("XCHG_GSUM", self._xchg["gsum"])
+            if self.surv_normal:
+                self._xchg["sq"] = torch.zeros(R, dtype=torch.float64, device=self.device)
+                self._bind("XCHG_SQ", self._xchg["sq"])
             if self.family in ("ControlNormal", "MultiMixtureNormal"):
                 self._xchg["tgrad"] = torch.zeros(2 * self.T, dtype=torch.float64, device=self.device)
                 self._bind("XCHG_TGRAD", self._xchg["tgrad"])
@@ -366,6 +368,8 @@ class HipSVI:
                 self._check(self.lib.bean_hip_sharded_guide(self._h, sp), "sharded_guide")
                 if "tgrad" in x:
                     all_reduce(x["tgrad"])
+                if "sq" in x:
+                    all_reduce(x["sq"])
                 self._check(self.lib.bean_hip_sharded_update(self._h, 1 if i == n_steps - 1 else 0, sp),
                            "sharded_update")
         self.steps_done = first + n_steps

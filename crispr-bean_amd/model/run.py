@@ -111,9 +111,8 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
     spec = _resolve(model)
     # ControlNormal has screen-wide scalar parameters and only sees the (small)
     # negative-control subset: every rank fits it redundantly instead of sharding (the engine can
-    # shard it - bean_hip_sharded_* - but a per-step collective costs more than the fit).  The
-    # survival NormalModel couples all guides through its Dirichlet-over-guides draw: same.
-    redundant = spec.family == "ControlNormal" or (spec.selection == "survival" and spec.family == "Normal")
+    # shard it - bean_hip_sharded_* - but a per-step collective costs more than the fit).
+    redundant = spec.family == "ControlNormal"
     sharded = world > 1 and not redundant
     engines = []
 

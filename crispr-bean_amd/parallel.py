@@ -117,7 +117,7 @@ class _Group:
 
 
 PER_TARGET = ("mu_loc", "mu_scale", "sd_loc", "sd_scale")
-PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale", "q0")
+PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale", "q0", "initial_abundance")
 
 
 def run_sharded(

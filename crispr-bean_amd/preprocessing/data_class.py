@@ -150,6 +150,10 @@ class ScreenTensors:
             if isinstance(v, torch.Tensor):
                 setattr(out, k, v.index_select(ax, idx.to(v.device)))
         out.n_guides = int(idx.numel())
+        if self.negctrl_guide_idx is not None:  # positions of the kept negative-control guides
+            neg = np.zeros(self.n_guides, dtype=bool)
+            neg[np.asarray(self.negctrl_guide_idx, dtype=np.int64)] = True
+            out.negctrl_guide_idx = np.nonzero(neg[idx.numpy()])[0]
         if getattr(self, "target_lengths", None) is not None:
             g2t = self.guide_to_target.cpu()[idx]
             if idx.numel():

@@ -136,6 +136,8 @@ enum bean_hip_buf {
     BEAN_BUF_XCHG_GSUM,       /* f64 (R+1) survival MixtureNormal: sum_g of the Dirichlet(q0) site's gamma
                                  draws per replicate, sum_g q0                               opt  */
     BEAN_BUF_XCHG_TGRAD,      /* f64 (2,T) ControlNormal / tiling: per-target likelihood gradient opt  */
+    BEAN_BUF_XCHG_SQ,         /* f64 (R)   survival NormalModel: sum_g q_0[r,g] * d loss / d q_0[r,g], the
+                                 projection term of the Dirichlet-over-guides pathwise gradient opt  */
     /* ---- parameters: unconstrained values as Pyro's param store keeps them */
     BEAN_BUF_P_MU_LOC = 32,   /* f32 (T)                                              */
     BEAN_BUF_P_MU_SCALE,      /* f32 (T)   log mu_scale                               */
@@ -230,10 +232,11 @@ int bean_hip_svi_run(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step,
  *
  *   bean_hip_sharded_begin(first_step, n_steps)     once per run: zero the loss window, draw step 0
  *   per step:
- *     bean_hip_sharded_sums      -> BEAN_BUF_XCHG_GSUM   (survival MixtureNormal: normalisers of the
- *                                                         Dirichlet-over-guides draw; no-op otherwise)
+ *     bean_hip_sharded_sums      -> BEAN_BUF_XCHG_GSUM   (survival MixtureNormal / NormalModel: normalisers
+ *                                                         of the Dirichlet-over-guides draw; no-op otherwise)
  *     bean_hip_sharded_guide     -> BEAN_BUF_XCHG_TGRAD  (ControlNormal, tiling: per-target likelihood
  *                                                         gradients; not written when the slot is unbound)
+ *                                -> BEAN_BUF_XCHG_SQ     (survival NormalModel: projection sums)
  *     bean_hip_sharded_update(last)                       gradients, ClippedAdam, draws of the next step
  *
  * Families whose parameters are all per-target or per-guide with target-aligned shards (sorting

@@ -61,7 +61,8 @@ def test_slot_numbers_match_header():
     assert table["BEAN_BUF_LOSS_HIST"] == _lib.BUF["LOSS_HIST"]
     assert table["BEAN_BUF_P_Q0"] - table["BEAN_BUF_P_MU_LOC"] == len(_lib.PARAM_ORDER) - 1
     assert table["BEAN_BUF_V_Q0"] - table["BEAN_BUF_V_MU_LOC"] == len(_lib.PARAM_ORDER) - 1
-    for name in ("A2E_PTR", "ALLELE_MASK", "TIMEPOINTS", "LOG_OBS0", "X0_IN", "EPS_U_OUT"):
+    for name in ("A2E_PTR", "ALLELE_MASK", "TIMEPOINTS", "LOG_OBS0", "NEGCTRL_MASK", "XCHG_GSUM", "XCHG_TGRAD",
+                 "XCHG_SQ", "X0_IN", "EPS_U_OUT"):
         assert table["BEAN_BUF_" + name] == _lib.BUF[name], name
 
 
@@ -77,7 +78,6 @@ def _shape(**kw):
 @pytest.mark.parametrize("kw,msg", [
     (dict(family=7), "family"),
     (dict(selection=2), "selection"),
-    (dict(selection=1, family=0, n_guides_total=400), "cannot be guide-sharded"),
     (dict(family=3, n_max_alleles=9, n_edits=2, n_targets=2), "n_max_alleles"),
     (dict(family=3, n_max_alleles=4, n_edits=3, n_targets=2), "n_targets == n_edits"),
     (dict(n_condits=9), "n_condits"),

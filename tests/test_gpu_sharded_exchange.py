@@ -50,6 +50,7 @@ def _run_interleaved(engines, n_steps, seed):
         for e in engines:
             e.phase("guide")
         _all_reduce(engines, "tgrad")
+        _all_reduce(engines, "sq")
         for e in engines:
             e.phase("update", 1 if i == n_steps - 1 else 0)
     torch.cuda.synchronize()
@@ -114,6 +115,25 @@ def test_survival_mixture_shards_share_the_abundance_normalisers(engine):
     engines = [engine.HipSVI("MixtureNormal", parallel.shard_screen(data, sh).to(DEV), num_steps=200,
                              guide_offset=sh[0], target_offset=sh[2], n_guides_total=data.n_guides,
                              t0_totals=t0_totals) for sh in shards]
+    _run_interleaved(engines, N, seed=9)
+    for name in ref:
+        _close(torch.cat([e.constrained()[name] for e in engines]), ref[name], 2e-5, name)
+    np.testing.assert_allclose(sum(np.array(e.losses()) for e in engines), ref_loss, rtol=1e-6)
+    for e in engines + [whole]:
+        e.close()
+
+
+def test_survival_normal_shards_share_draw_normalisers_and_projection(engine):
+    """survival NormalModel: the Dirichlet-over-guides draw enters every guide's likelihood, so its
+    normalisers AND the projection sums of its pathwise gradient are exchanged."""
+    data = make_survival_variant_screen(600, 3, seed=34, frac_effect=0.4)
+    whole = engine.HipSVI("Normal", data.to(DEV), num_steps=200)
+    whole.run(N, seed=9)
+    ref, ref_loss = whole.constrained(), np.array(whole.losses())
+    shards = parallel.plan_shards(data.target_lengths.numpy(), 3)
+    engines = [engine.HipSVI("Normal", parallel.shard_screen(data, sh).to(DEV), num_steps=200, guide_offset=sh[0],
+                             target_offset=sh[2], n_guides_total=data.n_guides) for sh in shards]
+    assert sum(len(e.data.negctrl_guide_idx) for e in engines) == len(data.negctrl_guide_idx)
     _run_interleaved(engines, N, seed=9)
     for name in ref:
         _close(torch.cat([e.constrained()[name] for e in engines]), ref[name], 2e-5, name)
