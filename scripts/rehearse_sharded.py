@@ -27,6 +27,8 @@ cases = [
      partial(sm.MultiMixtureNormalModel), partial(sm.MultiMixtureNormalGuide)),
     ("survival", make_survival_variant_screen(800, 3, seed=42, frac_effect=0.4), "MixtureNormal",
      partial(vm.MixtureNormalModel), partial(vm.MixtureNormalGuide)),
+    ("survival-normal", make_survival_variant_screen(600, 3, seed=43, frac_effect=0.4), "Normal",
+     partial(vm.NormalModel), vm.NormalGuide),
 ]
 for name, data, family, model, guide in cases:
     store, out = run_inference(model, guide, data, num_steps=STEPS, verbose=False)
