@@ -588,7 +588,7 @@ static void launch_sums(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     if (d.survival && (d.family == kMixture || d.surv_q0lik)) {
         hipLaunchKernelGGL(k_q0_draws, dim3(d.n_gamma_blocks, (d.R + 1) / 2), dim3(kParamBlock), 0, stream, d);
-        hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, stream, d);
+        hipLaunchKernelGGL(k_sum_parts, dim3(d.R + 1), dim3(256), 0, stream, d);
     }
 }
 

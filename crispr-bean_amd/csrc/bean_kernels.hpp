@@ -1646,14 +1646,14 @@ __global__ __launch_bounds__(kParamBlock) void k_q0_draws(DevArgs c) {
 }
 
 // gsum[r] = sum_g gamma[r, g] (normaliser of the Dirichlet(q0) draw), gsum[R] = sum_g q0.
+// grid = R + 1 blocks, one per total (fixed order: strided partials, block tree).
 __global__ __launch_bounds__(256) void k_sum_parts(DevArgs c) {
     __shared__ double scratch[16];
-    for (int j = 0; j <= c.R; ++j) {
-        double v = 0.0;
-        for (int b = threadIdx.x; b < c.n_gamma_blocks; b += blockDim.x) v += c.gpart[(long)b * (c.R + 1) + j];
-        const double tot = block_sum(v, scratch);
-        if (threadIdx.x == 0) c.gsum[j] = tot;
-    }
+    const int j = blockIdx.x;
+    double v = 0.0;
+    for (int b = threadIdx.x; b < c.n_gamma_blocks; b += blockDim.x) v += c.gpart[(long)b * (c.R + 1) + j];
+    const double tot = block_sum(v, scratch);
+    if (threadIdx.x == 0) c.gsum[j] = tot;
 }
 
 // survival NormalModel: sq[r] = sum_g q_0[r, g] * gq[r, g] (fixed order: strided partials, block tree)
