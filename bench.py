@@ -85,6 +85,44 @@ def pmc_traffic():
         return float(json.load(fh)["hbm_bytes_per_launch"]), os.path.basename(files[-1])
 
 
+def valu_issue_roofline(kernel_name, kernel_ms):
+    """Secondary roofline of the dominant kernel (it is bound by float64 VALU issue, not by HBM):
+    VALU wave-instructions per launch from the committed rocprofv3 --pmc summary
+    (profiles/*_counters.txt, SQ_INSTS_VALU) over the live kernel duration, against what a gfx950
+    SIMD sustains on v_fma_f64 with 4 resident waves (profiles/*_valu_issue.txt, measured by
+    scripts/micro/valu_rate.hip) times the 1024 SIMDs.  None when the summaries are absent."""
+    import glob
+    import re
+
+    cfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.txt")))
+    vfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_issue.txt")))
+    if not cfiles or not vfiles or kernel_ms <= 0:
+        return None
+    insts = None
+    lines = open(cfiles[-1]).read().splitlines()
+    for i, ln in enumerate(lines):
+        if ln.startswith("bean::" + kernel_name):
+            for l2 in lines[i + 1:i + 12]:
+                m = re.match(r"\s+SQ_INSTS_VALU\s+n=\s*\d+\s+mean=([0-9.e+]+)", l2)
+                if m:
+                    insts = float(m.group(1))
+                    break
+            if insts:
+                break
+    ns = None
+    for ln in open(vfiles[-1]):
+        m = re.match(r"fma_f64\s+waves/SIMD 4: .*-> ([0-9.]+) ns per wave-instr per SIMD", ln)
+        if m:
+            ns = float(m.group(1))
+    if not insts or not ns:
+        return None
+    peak = 1024 / (ns * 1e-9)  # wave-instructions per second, 256 CUs x 4 SIMDs
+    achieved = insts / (kernel_ms * 1e-3)
+    return {"bound": "f64 VALU issue", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
+            "frac": achieved / peak, "valu_insts_per_launch": insts,
+            "source": [os.path.basename(cfiles[-1]), os.path.basename(vfiles[-1])]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +254,10 @@ def main():
                 "kernel_launches_timed": k_n,
             },
         }
+        if args.guides == GUIDES_PER_GPU:
+            valu = valu_issue_roofline(kernel_name, k_ms)
+            if valu is not None:
+                out["roofline"]["valu_issue"] = valu
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data_cpu)
             out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
