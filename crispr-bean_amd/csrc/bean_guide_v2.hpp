@@ -1,0 +1,370 @@
+// k_guide_wave2: the per-(replicate, guide) kernel of the variant sorting families, second form.
+//
+// Same arithmetic as k_guide_wave (bean_kernels.hpp); what changed is where state lives and what
+// leaves the kernel:
+//   * rows: everything k_param needs from a (replicate, guide) is five numbers - d/dmu_t, d/dy_t,
+//     d/dnoise and, per Dirichlet component a, GA_a = [unclamped] (log pi_a + path_a) - [rg] log pi_a -
+//     because the (c_p - 1) log pi / (c_q - 1) log pi terms of the two Dirichlet log-densities are
+//     added to the loss here, where c_p / c_q are known.  v1 wrote eight to nine rows.
+//   * count totals n = sum_b x_b are re-summed from the staged counts (exact: integer-valued
+//     float32), so the (2, R, G) `nobs` array is gone.
+//   * the bin loop that contains the lgamma / digamma differences carries two accumulators (A0 and the
+//     lgamma sum); the digamma differences are parked in a thread-private LDS column and the twelve
+//     gradient sums of v1 become a light second loop with eight.  Nothing is spilled to scratch.
+//   * wave-uniform per-bin constants (size factors, sample mask, P0) are staged in LDS with the first
+//     batch of loads: the bin loops contain no scalar-memory loads (LDS and scalar loads share one
+//     counter, so mixing them forces full drains).
+//   * 1-D grid with an XCD-aware decode: the R waves of a tile have equal blockIdx % 8, i.e. share an
+//     L2, so the tile's per-guide values and table columns are fetched from HBM once, not R times.
+//
+// Reference semantics as k_guide_wave: bean/model/model.py:378-547 (model), 785-858 (guide),
+// bean/model/utils.py:10-31, 106-178.
+#pragma once
+
+namespace bean {
+
+// per-replicate rows of the v2 wave form, (kW2Rows, R, G) doubles in DevArgs::wrow
+enum W2Row { kW2Gmu = 0, kW2Gy = 1, kW2Gnoise = 2, kW2GA0 = 3, kW2GA1 = 4, kW2Rows = 5 };
+constexpr int kW2Misc = 6;  // per-guide values staged in LDS: a0, a0_bc, allele counts (2), c_p (2)
+
+// bytes of dynamic LDS of one wave
+__host__ __device__ inline size_t guide_wave2_lds(int B, int ntm) {
+    return ((size_t)3 * B * ntm + 4 * B + (size_t)B * 64 + (size_t)kW2Misc * 64) * sizeof(double) +
+           (size_t)2 * B * 64 * sizeof(float);
+}
+
+// alpha_b before its floor, from the mixture weights: evaluated with explicit roundings so that the
+// two bin loops (which both need "is alpha_b on its floor?") agree bit for bit
+__device__ __forceinline__ double alpha_raw(double w0, double p0, double w1, double p1, double sfb, double epsB,
+                                            double km) {
+    const double e = fma(w0, p0, w1 * p1);
+    return fma(e, sfb, epsB) * km;
+}
+
+template <int FAM, bool ACC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BEAN_WAVE_EU)))
+void k_guide_wave2(DevArgs c) {
+    constexpr bool MIX = FAM == kMixture;
+    extern __shared__ double tabs[];
+    const int lane = threadIdx.x;
+    const int G = c.G, T = c.T, B = c.B, R = c.R;
+    // ---- which (tile, replicate): blocks b and b + 8 share an XCD (observed placement; a speed
+    // choice only), so the R waves of a tile are given ids that are equal modulo 8
+    const int wg = blockIdx.x;
+    const int kk = wg >> 3;
+    const int r = kk % R;
+    const int tile = (kk / R) * 8 + (wg & 7);
+    if (tile * 64 >= G) return;
+    const int g = tile * 64 + lane;
+    const bool valid = g < G;
+    const StepCtr ctr = *c.ctrB;
+    double loss = 0.0;
+#ifdef BEAN_STAMP
+    const long wave_gid = wg;
+#endif
+    BEAN_STAMP_AT(0);
+    BEAN_SETPRIO(0);
+
+    const int g_first = tile * 64;
+    const int g_last = (g_first + 63 < G ? g_first + 63 : G - 1);
+    const int t0 = __builtin_amdgcn_readfirstlane(c.g2t[g_first]);
+    const int nt = __builtin_amdgcn_readfirstlane(c.g2t[g_last]) - t0 + 1;
+    const int ntm = c.tile_targets;
+    // LDS: [3][B][ntm] table columns | [4][B] sf, sf_bc, sample mask, P0 of this replicate |
+    //      [B][64] digamma differences | [kW2Misc][64] per-guide values | [2][B][64] counts (float)
+    double* cst = tabs + 3 * B * ntm;
+    double* dps = cst + 4 * B + lane;                 // dps[b * 64]
+    double* ms = cst + 4 * B + B * 64 + lane;         // ms[q * 64]
+    float* xs = (float*)(cst + 4 * B + B * 64 + kW2Misc * 64);
+    const bool use_bc = (c.flags & kUseBc) != 0;
+    int tcol = 0;
+    bool rgm = false;
+    float api0 = 0.f, api1 = 0.f;
+    double pa0 = 0.0;
+    {
+        // everything the wave reads from global memory, issued as one batch before the first wait
+        const int gc = valid ? g : G - 1;
+        const long rgc = (long)r * G + gc;
+        float xv[2][kBMax];
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) {
+            const long xo = ((long)r * B + (b < B ? b : B - 1)) * G + gc;
+            xv[0][b] = c.X[xo];
+            xv[1][b] = use_bc ? c.Xbc[xo] : 0.f;
+        }
+        // table rows (which, b) are packed `per` rows to a load: P = pow2 >= nt lanes per row
+        int lg2 = 0;
+        while ((1 << lg2) < nt) ++lg2;
+        const int per = 64 >> lg2;
+        const int j = lane & ((1 << lg2) - 1), sub = lane >> lg2;
+        const int n_rows = 3 * B;
+        constexpr int kTabLoads = 6;
+        double tv[kTabLoads];
+        int wbv[kTabLoads];
+#pragma unroll
+        for (int q = 0; q < kTabLoads; ++q) {
+            const int wb = q * per + sub;
+            const bool ok = wb < n_rows && j < nt;
+            const int wbc = ok ? wb : 0;
+            const int which = (wbc >= B) + (wbc >= 2 * B), bb = wbc - which * B;
+            const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
+            tv[q] = tab[(long)bb * T + t0 + (ok ? j : 0)];
+            wbv[q] = ok ? wb : -1;
+        }
+        // wave-uniform per-bin constants of this replicate: lane k * 8 + b loads constant k of bin b
+        double cv = 0.0;
+        {
+            const int kq = lane >> 3, bq = lane & 7;  // kBMax <= 16: two rounds when B > 8
+            const double* src = kq == 0 ? c.sf + r * B : (kq == 1 ? (use_bc ? c.sf_bc : c.sf) + r * B
+                                                                  : (kq == 2 ? c.smask + r * B : c.P0));
+            if (kq < 4 && bq < B && (MIX || kq != 3)) cv = src[bq];
+        }
+        tcol = c.g2t[gc] - t0;
+        rgm = c.rg[rgc] != 0;
+        if (MIX) {
+            api0 = c.p[4][2 * gc];
+            api1 = c.p[4][2 * gc + 1];
+            pa0 = c.pi_a0[gc];
+        }
+        const double a00 = c.a0[gc], a01 = use_bc ? c.a0_bc[gc] : 0.0;
+        double cnt0 = 0.0, cnt1 = 0.0;
+        if (MIX)
+            for (int cc = 0; cc < c.C; ++cc) {
+                const float* al = c.allele + (((long)r * c.C + cc) * G + gc) * 2;
+                cnt0 += (double)al[0];
+                cnt1 += (double)al[1];
+            }
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) {
+            const int bb = b < B ? b : B - 1;
+            xs[(0 * B + bb) * 64 + lane] = xv[0][b];
+            xs[(1 * B + bb) * 64 + lane] = xv[1][b];
+        }
+#pragma unroll
+        for (int q = 0; q < kTabLoads; ++q)
+            if (wbv[q] >= 0) tabs[wbv[q] * ntm + j] = tv[q];
+        for (int wb0 = kTabLoads * per; wb0 < n_rows; wb0 += per) {
+            const int wb = wb0 + sub;
+            if (wb < n_rows && j < nt) {
+                const int which = (wb >= B) + (wb >= 2 * B), bb = wb - which * B;
+                const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
+                tabs[wb * ntm + j] = tab[(long)bb * T + t0 + j];
+            }
+        }
+        {
+            const int kq = lane >> 3, bq = lane & 7;
+            if (kq < 4 && bq < B) cst[kq * B + bq] = cv;
+            if (B > 8) {  // the 16-condition build: bins 8 .. B - 1
+                const int b2 = 8 + bq;
+                if (kq < 4 && b2 < B) {
+                    const double* src = kq == 0 ? c.sf + r * B : (kq == 1 ? (use_bc ? c.sf_bc : c.sf) + r * B
+                                                                          : (kq == 2 ? c.smask + r * B : c.P0));
+                    cst[kq * B + b2] = (MIX || kq != 3) ? src[b2] : 0.0;
+                }
+            }
+        }
+        ms[0 * 64] = a00;
+        ms[1 * 64] = a01;
+        ms[2 * 64] = cnt0;
+        ms[3 * 64] = cnt1;
+    }
+    __syncthreads();
+
+    if (valid) {
+        const long rgi = (long)r * G + g;
+        const long RG = (long)R * G;
+        const double* tp = tabs + tcol;  // this guide's column: tp[(which * B + b) * ntm]
+        const double* c_sf = cst;        // c_sf[lik * B + b], c_sm[b], c_p0[b]
+        const double* c_sm = cst + 2 * B;
+        const double* c_p0 = cst + 3 * B;
+        double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0;
+        double dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
+        if (MIX) {
+            const double al0 = (double)expf(api0), al1 = (double)expf(api1);
+            const double rs = frcp(al0 + al1) * pa0;
+            const double cp0 = al0 * rs, cp1 = al1 * rs;
+            ms[4 * 64] = cp0;  // needed again after the likelihoods
+            ms[5 * 64] = cp1;
+            const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
+            if (c.pi_in) {
+                pi0 = c.pi_in[rgi * 2];
+                pi1 = c.pi_in[rgi * 2 + 1];
+            } else {
+                BEAN_STAMP_AT(1);
+                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+                const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng);
+                const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
+                const double rs2 = frcp(gm0 + gm1);
+                pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
+                pi1 = fmin(fmax(gm1 * rs2, kDblMin), kOneMinus);
+            }
+            if (c.flags & kDumpPi) {
+                c.pi_out[rgi * 2] = pi0;
+                c.pi_out[rgi * 2 + 1] = pi1;
+            }
+            pe1 = pi1;
+            if (ACC) {
+                // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
+                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double s1 = pi1 * kacc;
+                const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+                const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+                const double l = flog(p1c * frcp(1.0 - p1c)) + c.lpn[g];
+                const double el = exp(l);
+                const double pn = el * frcp(1.0 + el);
+                const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+                pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+                dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
+                dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+            }
+        }
+        const double w0 = MIX ? (ACC ? 1.0 - pe1 : pi0) : 0.0;  // weight of the wild-type component
+        const double w1 = MIX ? (ACC ? pe1 : pi1) : 1.0;        // weight of the edited component
+        const double epsB = kEps / (double)B;
+        double a_mu = 0.0, a_y = 0.0, g0 = 0.0, g1 = 0.0, nll = 0.0;
+        // pass 1 of both likelihoods: n = sum x_b (data) and S = sum_b e_b sf_b
+        double S_x = 0.0, S_bc = 0.0, n_x = 0.0, n_bc = 0.0;
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            const double e = fma(w0, MIX ? c_p0[b] : 0.0, w1 * tp[b * ntm]);
+            S_x += e * c_sf[b];
+            S_bc += e * c_sf[B + b];
+            n_x += (double)xs[b * 64 + lane];
+            n_bc += (double)xs[(B + b) * 64 + lane];
+        }
+#pragma unroll 1
+        for (int lik = 0; lik < 2; ++lik) {
+            if (lik == 1 && !use_bc) break;
+            if (lik == 0) BEAN_STAMP_AT(2);
+            else BEAN_STAMP_AT(5);
+            if (lik == 0) BEAN_SETPRIO(1);
+            else BEAN_SETPRIO(2);
+            // the site is masked by (sum_b x > mask_thres) & repguide_mask (model.py:526-547)
+            const double nn = lik ? n_bc : n_x;
+            if (!(rgm && nn > (double)c.mask_thres)) continue;
+            const float* xp = xs + lik * B * 64 + lane;  // xp[b * 64]
+            const double* sf = c_sf + lik * B;
+            const double S = lik ? S_bc : S_x;
+            const double a0 = ms[lik * 64];
+            const double inv = frcp(S + kEps);
+            const double ai = a0 * inv;
+            // loop 1: the lgamma / digamma differences; digamma differences parked in LDS
+            double A0 = 0.0, lsum = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const double x = (double)xp[b * 64];
+                const double araw = alpha_raw(w0, MIX ? c_p0[b] : 0.0, w1, tp[b * ntm], sf[b], epsB, ai * c_sm[b]);
+                const double alpha = araw < kEps ? kEps : araw;
+                A0 += alpha;
+                const DD db = lgamma_digamma_diff_inl(alpha, x);
+                lsum += db.d;
+                dps[b * 64] = db.dp;
+            }
+            if (lik == 0) BEAN_STAMP_AT(3);
+            const DD d0 = lgamma_digamma_diff_inl(A0, nn);
+            nll += d0.d - lsum;
+            // loop 2: with ga_b = d0.dp - dpsi_b (0 where alpha_b sits on its floor) and
+            // k_b = a0 m_b inv sf_b:  S_Q = sum ga_b k_b Q_b,  t_Q = sum sf_b Q_b,
+            // Wa = sum ga_b alpha_b;  d nll / d(weight of Q) = S_Q - Wa inv t_Q
+            double Wa = 0.0;
+            double S_mu = 0.0, S_y = 0.0, S_0 = 0.0, S_1 = 0.0;
+            double t_mu = 0.0, t_y = 0.0, t_0 = 0.0, t_1 = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const double p0 = MIX ? c_p0[b] : 0.0;
+                const double p1 = tp[b * ntm], pmu = tp[(B + b) * ntm], py = tp[(2 * B + b) * ntm];
+                const double sfb = sf[b];
+                const double km = ai * c_sm[b];
+                const double araw = alpha_raw(w0, p0, w1, p1, sfb, epsB, km);
+                const double ga = araw < kEps ? 0.0 : d0.dp - dps[b * 64];
+                Wa += ga * araw;
+                const double cb = ga * km * sfb;
+                S_mu += cb * pmu;
+                t_mu += sfb * pmu;
+                S_y += cb * py;
+                t_y += sfb * py;
+                S_1 += cb * p1;
+                t_1 += sfb * p1;
+                if (MIX) {
+                    S_0 += cb * p0;
+                    t_0 += sfb * p0;
+                }
+            }
+            if (lik == 0) BEAN_STAMP_AT(4);
+            const double W = Wa * inv;
+            a_mu += w1 * (S_mu - W * t_mu);
+            a_y += w1 * (S_y - W * t_y);
+            g0 += S_0 - W * t_0;
+            g1 += S_1 - W * t_1;
+        }
+        BEAN_STAMP_AT(6);
+        BEAN_SETPRIO(3);
+        double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
+        row[kW2Gmu * RG] = a_mu;
+        row[kW2Gy * RG] = a_y;
+        if (MIX) {
+            const double cp0 = ms[4 * 64], cp1 = ms[5 * 64];
+            const bool cl0 = cp0 < 1e-5, cl1 = cp1 < 1e-5;
+            const double cq0 = cl0 ? 1e-5 : cp0, cq1 = cl1 ? 1e-5 : cp1;
+            // d loss / d pi through the likelihood
+            double gpi0 = g0, gpi1 = g1;
+            if (ACC) {
+                gpi0 = 0.0;
+                gpi1 = (g1 - g0) * dpe1_dpi1;
+                row[kW2Gnoise * RG] = (g1 - g0) * dpe1_dl;
+            }
+            const double lpi0 = flog(pi0), lpi1 = flog(pi1);
+            const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
+            if (rgm) {
+                // Multinomial(probs = pi) on control allele counts (model.py:470-474):
+                // torch renormalises the probabilities and clamps them to [eps, 1 - eps]
+                const double s = pi0 + pi1;
+                const double ls = s == 1.0 ? 0.0 : flog(s);
+                const double rs = s == 1.0 ? 1.0 : frcp(s);
+                const double cnt0 = ms[2 * 64], cnt1 = ms[3 * 64];
+                const double pr0 = pi0 * rs, pr1 = pi1 * rs;
+                const bool in0 = pr0 > kProbEps && pr0 < 1.0 - kProbEps;
+                const bool in1 = pr1 > kProbEps && pr1 < 1.0 - kProbEps;
+                const double lg0 = in0 ? lpi0 - ls : flog(fmin(fmax(pr0, kProbEps), 1.0 - kProbEps));
+                const double lg1 = in1 ? lpi1 - ls : flog(fmin(fmax(pr1, kProbEps), 1.0 - kProbEps));
+                nll -= cnt0 * lg0;
+                nll -= cnt1 * lg1;
+                if (in0) gpi0 -= cnt0 * rpi0;
+                if (in1) gpi1 -= cnt1 * rpi1;
+                // - log p(pi): Dirichlet(c_p) under the repguide mask (model.py:454-463); its
+                // normaliser is per guide (k_param)
+                gpi0 -= (cp0 - 1.0) * rpi0;
+                gpi1 -= (cp1 - 1.0) * rpi1;
+                nll -= (cp0 - 1.0) * lpi0 + (cp1 - 1.0) * lpi1;
+            }
+            // + log q(pi): Dirichlet(c_q), unmasked in the guide (model.py:839-847)
+            gpi0 += (cq0 - 1.0) * rpi0;
+            gpi1 += (cq1 - 1.0) * rpi1;
+            nll += (cq0 - 1.0) * lpi0 + (cq1 - 1.0) * lpi1;
+            const double proj = pi0 * gpi0 + pi1 * gpi1;
+            const double total = cq0 + cq1;
+            double path0 = 0.0, path1 = 0.0;
+#pragma unroll 1
+            for (int a = 0; a < 2; ++a) {
+                if (a ? cl1 : cl0) continue;
+                const double v = dirichlet_grad_one(a ? pi1 : pi0, a ? cq1 : cq0, total) *
+                                 ((a ? gpi1 : gpi0) - proj);
+                path0 = a ? path0 : v;
+                path1 = a ? v : path1;
+            }
+            // d loss / d c_a of this replicate apart from the per-guide normaliser terms:
+            // (c_q unclamped) log pi_a + pathwise term, minus (masked) log pi_a of the model site
+            row[kW2GA0 * RG] = (cl0 ? 0.0 : lpi0 + path0) - (rgm ? lpi0 : 0.0);
+            row[kW2GA1 * RG] = (cl1 ? 0.0 : lpi1 + path1) - (rgm ? lpi1 : 0.0);
+        }
+        loss = nll;
+    }
+    const double tot = wave_sum(loss);
+    if (lane == 0) {
+        loss_add(c, ctr.slot, tot);
+        if (wg == 0) *c.ctrA = ctr;
+    }
+    BEAN_STAMP_AT(7);
+}
+
+}  // namespace bean

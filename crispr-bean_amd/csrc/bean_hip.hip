@@ -36,13 +36,14 @@ struct bean_hip_ctx {
     bool prepared;
     bool fused_guide;  // false: BEAN_HIP_GUIDE=split selects the sample / lik / pi-terms launches
     bool wave_guide;   // sorting variant families, default: one wave per (guide tile, replicate)
+    bool wave2;        // ... in its second form, k_guide_wave2 (BEAN_HIP_GUIDE=wave1 selects the first)
+    long long* loss_acc;  // library-owned fixed-point loss accumulators, kLossWords per loss_hist slot
     int* tile_targets_dev;
     bool tiling_wave;  // tiling families, default: k_guide_tiling_wave (BEAN_HIP_TILING=block: k_guide_tiling)
     double* gsum_ws;  // library-owned normaliser buffer (replaced by BEAN_BUF_XCHG_GSUM when bound)
     double* sq_ws;    // library-owned projection sums (replaced by BEAN_BUF_XCHG_SQ when bound)
-    // graph cache
-    hipGraphExec_t graph_exec;
-    int graph_chunk;
+    // graph cache: graphs[k] replays 2^k {k_param, guide} pairs
+    std::vector<hipGraphExec_t> graphs;
     unsigned long long graph_seed;
     // profiling of the dominant kernel
     bool profile;
@@ -168,6 +169,7 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.pi_out = (double*)P(BEAN_BUF_PI_OUT);
     d.eps_noise_out = (double*)P(BEAN_BUF_EPS_NOISE_OUT);
     d.loss_hist = (double*)P(BEAN_BUF_LOSS_HIST);
+    d.loss_acc = c->loss_acc;
     d.time = (const double*)P(BEAN_BUF_TIMEPOINTS);
     d.negctrl = (const uint8_t*)P(BEAN_BUF_NEGCTRL_MASK);
     if (P(BEAN_BUF_XCHG_GSUM)) d.gsum = (double*)P(BEAN_BUF_XCHG_GSUM);
@@ -185,11 +187,9 @@ static void sync_devargs(bean_hip_ctx* c) {
 }
 
 static void drop_graph(bean_hip_ctx* c) {
-    if (c->graph_exec) {
-        (void)hipGraphExecDestroy(c->graph_exec);
-        c->graph_exec = nullptr;
-    }
-    c->graph_chunk = 0;
+    for (hipGraphExec_t g : c->graphs)
+        if (g) (void)hipGraphExecDestroy(g);
+    c->graphs.clear();
 }
 
 extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
@@ -234,15 +234,15 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         const char* mode = getenv("BEAN_HIP_GUIDE");
         c->fused_guide = !((env && env[0] == '1') || (mode && !strcmp(mode, "split")));
         c->wave_guide = c->fused_guide;
+        c->wave2 = !(mode && !strcmp(mode, "wave1"));
         const char* tmode = getenv("BEAN_HIP_TILING");
         c->tiling_wave = !(tmode && !strcmp(tmode, "block"));
 #if BEAN_AMAX > 8
         c->tiling_wave = true;  // this build has no block form
 #endif
     }
-    c->graph_exec = nullptr;
-    c->graph_chunk = 0;
     c->graph_seed = 0;
+    c->loss_acc = nullptr;
     c->profile = false;
     c->loss_capacity = 0;
     DevArgs& d = c->d;
@@ -277,16 +277,19 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const bool split_ok = !is_survival(*s) && !is_tiling(*s);
     const bool use_split = split_ok && !c->fused_guide;
     c->wave_guide = c->wave_guide && split_ok;
+    c->wave2 = c->wave2 && c->wave_guide;
+    d.rows_v2 = c->wave2 ? 1 : 0;
     c->tiling_wave = c->tiling_wave && is_tiling(*s);
     const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G : 0;
     const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G
-                                       : (c->wave_guide ? (uint64_t)(kNumPart + 2) * Rr * G : 0);
+                                       : (c->wave_guide ? (uint64_t)(c->wave2 ? kW2Rows : kNumPart + 2) * Rr * G : 0);
 #ifdef BEAN_STAMP
-    const uint64_t n_dbg = 8 * 2 * Rr * ((G + 63) / 64);
+    const uint64_t n_dbg = 8 * 2 * Rr * (((G + 63) / 64 + 7) / 8 * 8);
 #else
     const uint64_t n_dbg = 0;
 #endif
-    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + n_surv + n_split + n_dbg + n_trow;
+    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
+                           n_split + n_dbg + n_trow;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
     if (e != hipSuccess) {
@@ -314,6 +317,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.lpn = w; w += G;
     d.eps_noise = w; w += G;
     d.loss_const = w; w += 1;
+    d.const_acc = (long long*)w; w += kLossWords;
     c->tile_targets_dev = (int*)w; w += 1;
     d.tile_targets = 64;
     if (n_dbg) {
@@ -322,7 +326,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (c->tiling_wave) {
         d.trow = w; w += n_trow;
     }
-    if (c->wave_guide) {
+    if (c->wave_guide && c->wave2) {
+        d.wrow = w; w += (uint64_t)kW2Rows * Rr * G;  // count totals are re-summed in the kernel: no nobs
+    } else if (c->wave_guide) {
         d.wrow = w; w += (uint64_t)kNumPart * Rr * G;
         d.nobs = w; w += 2 * Rr * G;
     }
@@ -365,6 +371,7 @@ extern "C" int bean_hip_destroy(bean_hip_ctx* c) {
     drop_graph(c);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->workspace) (void)hipFree(c->workspace);
+    if (c->loss_acc) (void)hipFree(c->loss_acc);
     delete c;
     return 0;
 }
@@ -378,6 +385,12 @@ extern "C" int bean_hip_bind(bean_hip_ctx* c, int slot, void* ptr, uint64_t nbyt
             return fail("bean_hip_bind: slot " + std::to_string(slot) + " is not used by this shape");
         if (slot == BEAN_BUF_LOSS_HIST) {
             if (nbytes < 8 || nbytes % 8) return fail("bean_hip_bind: loss_hist must hold >= 1 double");
+            if (nbytes / 8 != c->loss_capacity || !c->loss_acc) {
+                if (c->loss_acc) (void)hipFree(c->loss_acc);
+                c->loss_acc = nullptr;
+                HIP_OK(hipMalloc((void**)&c->loss_acc, (nbytes / 8) * kLossSub * kLossWords * sizeof(long long)));
+                HIP_OK(hipMemset(c->loss_acc, 0, (nbytes / 8) * kLossSub * kLossWords * sizeof(long long)));
+            }
             c->loss_capacity = nbytes / 8;
         } else if (nbytes != want) {
             return fail("bean_hip_bind: slot " + std::to_string(slot) + " expects " + std::to_string(want) +
@@ -434,7 +447,7 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
     if (!c) return fail("bean_hip_prepare: null handle");
     if (check_bound(c, false, false)) return -1;
     hipStream_t stream = (hipStream_t)stream_;
-    HIP_OK(hipMemsetAsync(c->d.loss_const, 0, 8, stream));
+    HIP_OK(hipMemsetAsync(c->d.const_acc, 0, kLossWords * sizeof(long long), stream));
     const long n = (long)c->d.R * c->d.G;
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c->d);
     HIP_OK(hipGetLastError());
@@ -548,6 +561,39 @@ static void launch_guide_split(bean_hip_ctx* c, hipStream_t stream) {
     }
 }
 
+// sorting variant families, one wave per (guide tile, replicate), second form (bean_guide_v2.hpp)
+static void launch_guide_wave2(bean_hip_ctx* c, hipStream_t stream) {
+    const DevArgs& d = c->d;
+    const int tiles = (d.G + 63) / 64;
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8) * (unsigned)d.R), block(64);
+    const size_t lds = guide_wave2_lds(d.B, d.tile_targets);
+    const bool prof = c->profile && c->ev.size() < 8192;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        if (d.family == kMixture) {
+            if (d.flags & kAcc)
+                hipExtLaunchKernelGGL((k_guide_wave2<kMixture, true>), grid, block, lds, stream, e0, e1, 0, d);
+            else
+                hipExtLaunchKernelGGL((k_guide_wave2<kMixture, false>), grid, block, lds, stream, e0, e1, 0, d);
+        } else {
+            hipExtLaunchKernelGGL((k_guide_wave2<kNormal, false>), grid, block, lds, stream, e0, e1, 0, d);
+        }
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+        return;
+    }
+    if (d.family == kMixture) {
+        if (d.flags & kAcc)
+            hipLaunchKernelGGL((k_guide_wave2<kMixture, true>), grid, block, lds, stream, d);
+        else
+            hipLaunchKernelGGL((k_guide_wave2<kMixture, false>), grid, block, lds, stream, d);
+    } else {
+        hipLaunchKernelGGL((k_guide_wave2<kNormal, false>), grid, block, lds, stream, d);
+    }
+}
+
 // sorting variant families, one wave per (guide tile, replicate)
 static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
@@ -630,7 +676,8 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
         return;
     }
     if (c->wave_guide) {
-        launch_guide_wave(c, stream);
+        if (c->wave2) launch_guide_wave2(c, stream);
+        else launch_guide_wave(c, stream);
         return;
     }
     const int nw = waves_per_block(c);
@@ -683,6 +730,20 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
     }
 }
 
+static void launch_finalize(bean_hip_ctx* c, hipStream_t stream, uint64_t first, uint64_t n, bool cur) {
+    const unsigned blocks = cur ? 1u : (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(blocks), dim3(cur ? 64 : 256), 0, stream, c->d, (unsigned long long)first,
+                       (unsigned long long)n, cur ? 1 : 0);
+}
+
+static int clear_loss(bean_hip_ctx* c, hipStream_t stream, uint64_t first, uint64_t n) {
+    if (!n) return 0;
+    HIP_OK(hipMemsetAsync(c->d.loss_hist + first, 0, 8 * n, stream));
+    HIP_OK(hipMemsetAsync(c->d.loss_acc + (uint64_t)kLossSub * kLossWords * first, 0,
+                          sizeof(long long) * kLossSub * kLossWords * n, stream));
+    return 0;
+}
+
 extern "C" int bean_hip_elbo_grad(bean_hip_ctx* c, uint64_t seed, uint64_t step, uint64_t loss_index,
                                   void* stream_) {
     if (!c) return fail("bean_hip_elbo_grad: null handle");
@@ -691,12 +752,13 @@ extern "C" int bean_hip_elbo_grad(bean_hip_ctx* c, uint64_t seed, uint64_t step,
     if (loss_index >= c->loss_capacity) return fail("bean_hip_elbo_grad: loss_index beyond loss_hist");
     hipStream_t stream = (hipStream_t)stream_;
     c->d.seed = seed;
-    HIP_OK(hipMemsetAsync(c->d.loss_hist + loss_index, 0, 8, stream));
+    if (clear_loss(c, stream, loss_index, 1)) return -1;
     hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d.ctrA, c->d.ctrB,
                        (unsigned long long)step, (unsigned long long)loss_index);
     launch_param<false, false, true>(c, stream);
     launch_guide(c, stream);
     launch_param<true, false, false>(c, stream);
+    launch_finalize(c, stream, loss_index, 1, false);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -724,6 +786,33 @@ static void enqueue_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n) {
     }
 }
 
+// Capture 2^k {k_param, guide} pairs into an executable graph.  On any failure the stream is taken
+// out of capture mode before returning.
+static int capture_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n, hipGraphExec_t* out) {
+    hipGraph_t graph = nullptr;
+    HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    enqueue_pairs(c, stream, n);
+    hipError_t e = hipStreamEndCapture(stream, &graph);
+    if (e != hipSuccess) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            hipGraph_t junk = nullptr;
+            (void)hipStreamEndCapture(stream, &junk);
+            if (junk) (void)hipGraphDestroy(junk);
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
+
 extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
                                 int32_t graph_chunk, void* stream_) {
     if (!c) return fail("bean_hip_svi_run: null handle");
@@ -733,39 +822,45 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
     if (first_step + n_steps > c->loss_capacity)
         return fail("bean_hip_svi_run: loss_hist too small for first_step + n_steps");
     hipStream_t stream = (hipStream_t)stream_;
-    if (c->graph_exec && (c->graph_seed != seed)) drop_graph(c);
+    if (!c->graphs.empty() && (c->graph_seed != seed)) drop_graph(c);
     c->d.seed = seed;
-    HIP_OK(hipMemsetAsync(c->d.loss_hist + first_step, 0, 8 * n_steps, stream));
+    const bool use_graph = graph_chunk > 0 && stream != nullptr && !c->profile;
+    if (use_graph) {
+        // Graphs of 1, 2, 4, ... <= graph_chunk pairs, all instantiated at the first call (nothing is
+        // instantiated inside a later, possibly timed, call); any number of pairs is then replayed
+        // as a sum of powers of two.  The step counters live on the device, so the graphs do not
+        // depend on the step.
+        int kmax = 0;
+        while ((2ull << kmax) <= (uint64_t)graph_chunk && kmax < 10) ++kmax;
+        if ((int)c->graphs.size() != kmax + 1) {
+            drop_graph(c);
+            for (int k = 0; k <= kmax; ++k) {
+                hipGraphExec_t ge = nullptr;
+                if (capture_pairs(c, stream, 1ull << k, &ge)) {
+                    drop_graph(c);
+                    return -1;
+                }
+                c->graphs.push_back(ge);
+            }
+            c->graph_seed = seed;
+        }
+    }
+    if (clear_loss(c, stream, first_step, n_steps)) return -1;
     hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d.ctrA, c->d.ctrB,
                        (unsigned long long)first_step, (unsigned long long)first_step);
     launch_param<false, false, true>(c, stream);
     launch_guide(c, stream);
     uint64_t pairs = n_steps - 1;
-    const bool use_graph = graph_chunk > 0 && stream != nullptr && !c->profile;
     if (use_graph) {
-        if (c->graph_exec && c->graph_chunk != graph_chunk) drop_graph(c);
-        if (!c->graph_exec && pairs >= (uint64_t)graph_chunk) {
-            hipGraph_t graph = nullptr;
-            HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            enqueue_pairs(c, stream, (uint64_t)graph_chunk);
-            hipError_t e = hipStreamEndCapture(stream, &graph);
-            if (e != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-            e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (e != hipSuccess) {
-                c->graph_exec = nullptr;
-                return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        for (int k = (int)c->graphs.size() - 1; k >= 0; --k)
+            while (pairs >= (1ull << k)) {
+                HIP_OK(hipGraphLaunch(c->graphs[k], stream));
+                pairs -= 1ull << k;
             }
-            c->graph_chunk = graph_chunk;
-            c->graph_seed = seed;
-        }
-        while (c->graph_exec && pairs >= (uint64_t)graph_chunk) {
-            HIP_OK(hipGraphLaunch(c->graph_exec, stream));
-            pairs -= (uint64_t)graph_chunk;
-        }
     }
     enqueue_pairs(c, stream, pairs);
     launch_param<true, true, false>(c, stream);
+    launch_finalize(c, stream, first_step, n_steps, false);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -787,7 +882,7 @@ extern "C" int bean_hip_sharded_begin(bean_hip_ctx* c, uint64_t seed, uint64_t f
         return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_TGRAD for a sharded ControlNormal / tiling fit");
     hipStream_t stream = (hipStream_t)stream_;
     c->d.seed = seed;
-    if (n_steps) HIP_OK(hipMemsetAsync(c->d.loss_hist + first_step, 0, 8 * n_steps, stream));
+    if (clear_loss(c, stream, first_step, n_steps)) return -1;
     hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d.ctrA, c->d.ctrB,
                        (unsigned long long)first_step, (unsigned long long)first_step);
     launch_param<false, false, true>(c, stream);
@@ -824,6 +919,7 @@ extern "C" int bean_hip_sharded_update(bean_hip_ctx* c, int32_t last, void* stre
         launch_param<true, true, false>(c, stream, tg);
     else
         launch_param<true, true, true>(c, stream, tg);
+    launch_finalize(c, stream, 0, 1, true);  // the slot of the step that has just finished
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -846,7 +942,7 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
 extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
     if (c && c->d.family == kMultiMixture) return c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling";
     if (c && c->d.survival) return "k_guide_survival";
-    if (c && c->wave_guide) return "k_guide_wave";
+    if (c && c->wave_guide) return c->wave2 ? "k_guide_wave2" : "k_guide_wave";
     return "k_lik";
 }
 

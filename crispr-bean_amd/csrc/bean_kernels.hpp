@@ -88,6 +88,10 @@ struct DevArgs {
     const double *eps_mu_in, *eps_sd_in, *pi_in, *eps_noise_in;
     double *eps_mu_out, *eps_sd_out, *pi_out, *eps_noise_out;
     double* loss_hist;
+    // order-independent loss accumulators (loss_add): kLossSub lines of kLossWords int64 words per
+    // loss_hist slot, and one line for the data-only constant
+    long long *loss_acc, *const_acc;
+    int rows_v2;                       // wrow holds the five rows of k_guide_wave2 (bean_guide_v2.hpp)
     // workspace
     double *tabP, *tabPmu, *tabPy;     // (B, T)
     double* P0;                        // (B)
@@ -154,6 +158,46 @@ enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2
 __device__ __forceinline__ double uniform_ld(const double* p, int i) {
     typedef const double __attribute__((address_space(4))) * cptr;
     return ((cptr)(unsigned long long)p)[i];
+}
+
+// ---------------------------------------------------------------- loss accumulation
+// Every wave / block adds its part of the step's loss with INTEGER atomics: the part is split exactly
+// into a multiple of 2^-10 and a remainder rounded to 2^-40, so the sum does not depend on the order
+// in which the parts arrive and the loss history is bitwise reproducible (a float64 atomicAdd is not).
+// Range |loss| < 2^52, resolution 2^-40.  One address would serialise the chip's ~4000 waves at ~12 ns
+// per atomic (tens of microseconds per launch - measured: it dominated the guide kernel), so a slot is
+// kLossSub accumulators in separate 64-byte lines and a part goes to the one its block id selects;
+// integer sums make the choice irrelevant for the result.  k_loss_finalize adds them up into the
+// double in loss_hist.
+constexpr int kLossWords = 8;   // int64 words per accumulator line: 2^-10 units, 2^-40 units, poison count
+constexpr int kLossSub = 64;    // accumulator lines per loss_hist slot
+__device__ __forceinline__ void fixed_add(long long* acc, double v) {
+    if (!(fabs(v) < 4.0e15)) {  // NaN / inf / out of range: poison the slot (k_loss_finalize reports NaN)
+        atomicAdd((unsigned long long*)acc + 2, 1ull);
+        return;
+    }
+    const double hi = rint(v * 1024.0);
+    const double lo = rint((v - hi * (1.0 / 1024.0)) * 1099511627776.0);
+    atomicAdd((unsigned long long*)acc, (unsigned long long)(long long)hi);
+    atomicAdd((unsigned long long*)acc + 1, (unsigned long long)(long long)lo);
+}
+// sum of `n` accumulator lines as a double (NaN when poisoned)
+__device__ __forceinline__ double fixed_value(const long long* acc, int n) {
+    long long hi = 0, lo = 0, bad = 0;
+    for (int i = 0; i < n; ++i) {
+        hi += acc[i * kLossWords];
+        lo += acc[i * kLossWords + 1];
+        bad |= acc[i * kLossWords + 2];
+    }
+    if (bad != 0) return __builtin_nan("");
+    return (double)hi * (1.0 / 1024.0) + (double)lo * (1.0 / 1099511627776.0);
+}
+__device__ __forceinline__ void loss_add(const DevArgs& c, unsigned long long slot, double v) {
+#ifdef BEAN_NO_LOSS  // diagnostic builds: what do the loss atomics cost?
+    return;
+#endif
+    const unsigned sub = (blockIdx.x + blockIdx.y * gridDim.x) & (kLossSub - 1);
+    fixed_add(c.loss_acc + ((long)slot * kLossSub + sub) * kLossWords, v);
 }
 
 // ---------------------------------------------------------------- reductions
@@ -733,7 +777,20 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 }
                 // per-replicate rows of the wave form: independent loads, four replicates in flight
                 double Lp_[2] = {0.0, 0.0}, Lq_[2] = {0.0, 0.0}, path_[2] = {0.0, 0.0}, nrg = 0.0;
-                if (c.wrow) {
+                double GA_[2] = {0.0, 0.0};
+                if (c.wrow && c.rows_v2) {
+                    // k_guide_wave2 rows: GA_a = sum_r of everything d loss / d c_a owes to the draws;
+                    // the (c - 1) log pi terms of the loss were added by the guide kernel
+                    const long RG = (long)c.R * c.G;
+                    const double* w = c.wrow + g;
+                    nrg = c.part[(long)kPNrg * c.G + g];  // data only (k_prepare)
+#pragma unroll 4
+                    for (int r = 0; r < c.R; ++r) {
+                        const double* wr = w + (long)r * c.G;
+                        GA_[0] += wr[3 * RG];
+                        GA_[1] += wr[4 * RG];
+                    }
+                } else if (c.wrow) {
                     const long RG = (long)c.R * c.G;
                     const double* w = c.wrow + g;
                     nrg = c.part[(long)kPNrg * c.G + g];  // data only (k_prepare)
@@ -768,6 +825,13 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                     const double g_cp = -(Lp + nrg * (dgS_p - dg_p[a]));
                     const double g_cq = cl[a] ? 0.0 : (Lq + Rf * (dgS_q - dg_q[a]) + gpath);
                     gc[a] = g_cp + g_cq;
+                }
+                if (c.wrow && c.rows_v2) {
+                    lp = nrg * (lgS_p - lg_p[0] - lg_p[1]);
+                    lq = Rf * (lgS_q - lg_q[0] - lg_q[1]);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        gc[a] = -nrg * (dgS_p - dg_p[a]) + (cl[a] ? 0.0 : Rf * (dgS_q - dg_q[a])) + GA_[a];
                 }
                 loss_fin = -lp + lq;
                 const double dot = (gc[0] * al0 + gc[1] * al1) / s;
@@ -901,9 +965,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         if ((int)blockIdx.x < n_target_blocks && c.not_loss_owner) loss_fin = 0.0;
         const double tot = block_sum(loss_fin, scratch);
         if (threadIdx.x == 0) {
-            double add = tot;
-            if (blockIdx.x == 0) add += *c.loss_const;
-            atomicAdd(&c.loss_hist[ctr.slot], add);
+            loss_add(c, ctr.slot, tot);
         }
     }
     (void)loss_prep;
@@ -967,8 +1029,22 @@ __device__ __forceinline__ double dirmult_nll(const float* __restrict__ xp, long
 // everything downstream is linear in it, see k_lik).  No LDS, no barrier; table entries and
 // counts of bin b + 1 are fetched while bin b is computed.  The per-replicate rows go to
 // wrow[(q, r, g)]; k_param sums them over r in fixed order (part_row).
+#ifndef BEAN_WAVE_EU
+#define BEAN_WAVE_EU 4
+#endif
+// Experiment knob: wave priority by phase (s_setprio), see DESIGN.md "k_guide_wave"
+#ifndef BEAN_PRIO
+#define BEAN_PRIO 0
+#endif
+#if BEAN_PRIO == 1
+#define BEAN_SETPRIO(phase) __builtin_amdgcn_s_setprio(3 - (phase))
+#elif BEAN_PRIO == 2
+#define BEAN_SETPRIO(phase) __builtin_amdgcn_s_setprio(phase)
+#else
+#define BEAN_SETPRIO(phase) do {} while (0)
+#endif
 template <int FAM, bool ACC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BEAN_WAVE_EU)))
 void k_guide_wave(DevArgs c) {
     constexpr bool MIX = FAM == kMixture;
     // dynamic LDS: [3][B][ntm] doubles (P, dP/dmu, dP/dy columns of the tile's targets; ntm =
@@ -986,6 +1062,7 @@ void k_guide_wave(DevArgs c) {
     const long wave_gid = (long)blockIdx.y * gridDim.x + blockIdx.x;
 #endif
     BEAN_STAMP_AT(0);
+    BEAN_SETPRIO(0);
 
     // Guides are target-sorted, so the tile's targets are one contiguous range of at most 64:
     // lane i stages the 3 B table entries of target t0 + i (coalesced); every lane then reads its
@@ -1157,6 +1234,8 @@ void k_guide_wave(DevArgs c) {
             if (lik == 1 && !use_bc) break;
             if (lik == 0) BEAN_STAMP_AT(2);
             else BEAN_STAMP_AT(5);
+            if (lik == 0) BEAN_SETPRIO(1);
+            else BEAN_SETPRIO(2);
             const float* xp = xs + lik * B * 64 + lane;  // xp[b * 64]
             const double* sf = (lik ? c.sf_bc : c.sf) + r * B;
             // n = sum x_b is data: k_prepare leaves it in nobs (-1 where the (rep, guide) is masked)
@@ -1217,6 +1296,7 @@ void k_guide_wave(DevArgs c) {
             g1 += d0.dp * U_1 - V_1 - W * t_1;
         }
         BEAN_STAMP_AT(6);
+        BEAN_SETPRIO(3);
         double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
         row[kPGmu * RG] = a_mu;
         row[kPGy * RG] = a_y;
@@ -1262,8 +1342,13 @@ void k_guide_wave(DevArgs c) {
 #pragma unroll 1
             for (int a = 0; a < 2; ++a) {
                 if (a ? cl1 : cl0) continue;
+#if BEAN_DG_INLINE
+                const double v = dirichlet_grad_one_inl(a ? pi1 : pi0, a ? cq1 : cq0, total) *
+                                 ((a ? gpi1 : gpi0) - proj);
+#else
                 const double v = dirichlet_grad_one(a ? pi1 : pi0, a ? cq1 : cq0, total) *
                                  ((a ? gpi1 : gpi0) - proj);
+#endif
                 path0 = a ? path0 : v;
                 path1 = a ? v : path1;
             }
@@ -1274,7 +1359,7 @@ void k_guide_wave(DevArgs c) {
     }
     const double tot = wave_sum(loss);
     if (lane == 0) {
-        atomicAdd(&c.loss_hist[ctr.slot], tot);
+        loss_add(c, ctr.slot, tot);
         if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = ctr;
     }
     BEAN_STAMP_AT(7);
@@ -1518,7 +1603,7 @@ void k_lik(DevArgs c) {
     const double tot = block_sum(loss, scratch);
     BEAN_STAMP_AT(7);
     if (threadIdx.x == 0) {
-        atomicAdd(&c.loss_hist[c.ctrB->slot], tot);
+        loss_add(c, c.ctrB->slot, tot);
         if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = *c.ctrB;
     }
 }
@@ -1605,7 +1690,7 @@ void k_pi_terms(DevArgs c) {
     }
     double* scratch = lds + (long)nw * 7 * 64;
     const double tot = block_sum(loss, scratch);
-    if (threadIdx.x == 0) atomicAdd(&c.loss_hist[c.ctrB->slot], tot);
+    if (threadIdx.x == 0) loss_add(c, c.ctrB->slot, tot);
 }
 
 // ------------------------------------------------------------ survival kernels
@@ -1899,7 +1984,7 @@ void k_guide_survival(DevArgs c) {
     double* scratch = lds + (long)nw * kNumPart * 64;
     const double tot = block_sum(loss, scratch);
     if (threadIdx.x == 0) {
-        atomicAdd(&c.loss_hist[ctr.slot], tot);
+        loss_add(c, ctr.slot, tot);
         if (blockIdx.x == 0) *c.ctrA = ctr;
     }
 }
@@ -2286,7 +2371,7 @@ void k_guide_tiling(DevArgs c) {
     double* scratch = lds + kTNumPart * 64;
     const double tot = block_sum(loss, scratch);
     if (threadIdx.x == 0) {
-        atomicAdd(&c.loss_hist[ctr.slot], tot);
+        loss_add(c, ctr.slot, tot);
         if (blockIdx.x == 0) *c.ctrA = ctr;
     }
 }
@@ -2586,7 +2671,7 @@ void k_guide_tiling_wave(DevArgs c) {
     }
     const double tot = wave_sum(loss);
     if (lane == 0) {
-        atomicAdd(&c.loss_hist[ctr.slot], tot);
+        loss_add(c, ctr.slot, tot);
         if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = ctr;
     }
 }
@@ -2632,13 +2717,13 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
         }
         if (rgm && n > (double)c.mask_thres) v -= lgamma(1.0 + n) - lf;
         if ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) v -= lgamma(1.0 + nb) - lfb;
+        if (c.wrow && r == 0) {
+            // wave forms: per-guide count of unmasked replicates (the kPNrg row is data)
+            double cnt = 0.0;
+            for (int rr = 0; rr < c.R; ++rr) cnt += c.rg[(long)rr * c.G + g] != 0 ? 1.0 : 0.0;
+            c.part[(long)kPNrg * c.G + g] = cnt;
+        }
         if (c.nobs) {
-            // wave form: per-guide count of unmasked replicates (the kPNrg row is data)
-            if (r == 0) {
-                double cnt = 0.0;
-                for (int rr = 0; rr < c.R; ++rr) cnt += c.rg[(long)rr * c.G + g] != 0 ? 1.0 : 0.0;
-                c.part[(long)kPNrg * c.G + g] = cnt;
-            }
             c.nobs[idx] = (rgm && n > (double)c.mask_thres) ? n : -1.0;
             c.nobs[n_rg + idx] = ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) ? nb : -1.0;
         }
@@ -2655,7 +2740,7 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
         }
     }
     const double tot = block_sum(v, scratch);
-    if (threadIdx.x == 0) atomicAdd(c.loss_const, tot);
+    if (threadIdx.x == 0) fixed_add(c.const_acc, tot);
     if (blockIdx.x == 0 && (int)threadIdx.x < c.B && !c.survival) {
         const double zh = c.z_hi[threadIdx.x], zl = c.z_lo[threadIdx.x];
         const double ch = isinf(zh) ? 1.0 : norm_cdf(zh);
@@ -2670,6 +2755,20 @@ __global__ __launch_bounds__(256) void k_tile_targets(const int* g2t, int G, int
     if (tile * 64 >= G) return;
     const int first = tile * 64, last = first + 63 < G ? first + 63 : G - 1;
     atomicMax(out, g2t[last] - g2t[first] + 1);
+}
+
+// loss_hist[i] = accumulated parts of step i + the data-only constant, for n slots from `first`
+// (cur != 0: the one slot of the step that has just finished, read from the device step counter)
+__global__ __launch_bounds__(256) void k_loss_finalize(DevArgs c, unsigned long long first, unsigned long long n,
+                                                       int cur) {
+    unsigned long long i = first + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cur) {
+        if (blockIdx.x != 0 || threadIdx.x != 0) return;
+        i = c.ctrA->slot;
+    } else if (i >= first + n) {
+        return;
+    }
+    c.loss_hist[i] = fixed_value(c.loss_acc + (long)i * kLossSub * kLossWords, kLossSub) + fixed_value(c.const_acc, 1);
 }
 
 __global__ void k_set_step(StepCtr* a, StepCtr* b, unsigned long long step, unsigned long long slot) {
@@ -2725,3 +2824,5 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
 }
 
 }  // namespace bean
+
+#include "bean_guide_v2.hpp"

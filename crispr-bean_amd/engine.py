@@ -61,6 +61,7 @@ class HipSVI:
         mu_negctrl=(0.0, 0.1),
         t0_totals: Optional[torch.Tensor] = None,
         loss_owner: bool = True,
+        alpha_prior: float = 1.0,
     ):
         if family not in _lib.FAMILY:
             raise ValueError(f"unknown model family {family!r}")
@@ -226,6 +227,16 @@ class HipSVI:
                     v = torch.as_tensor(prior_params[key], dtype=torch.float64).reshape(-1)
                     if v.numel() == 1:
                         v = v.expand(T)
+                    elif v.numel() != T:
+                        # guide shard of a target-aligned fit: the caller holds the whole screen's
+                        # per-target priors (`--prior-params`); this rank's targets are
+                        # [target_offset, target_offset + T).  (Tiling shards replicate the per-edit
+                        # parameters, so T is the whole edit count there and nothing is cut.)
+                        if tiling or v.numel() < int(target_offset) + T:
+                            raise ValueError(f"prior_params[{key!r}] has {v.numel()} entries, expected {T}"
+                                             + ("" if tiling else f" (or at least {int(target_offset) + T} "
+                                                                  "for this shard)"))
+                        v = v[int(target_offset): int(target_offset) + T]
                     self._bind(slot, f64(v))
 
         # ---- parameters (unconstrained), as pyro.param initialises them
@@ -241,7 +252,11 @@ class HipSVI:
             g_all = int(n_guides_total) if n_guides_total else G
             init["initial_abundance"] = torch.full((G,), float(np.log(np.float32(1.0) / np.float32(g_all))))
         if mixture:
-            init["alpha_pi"] = torch.zeros((G, A))
+            # pyro.param("alpha_pi", ones * alpha_prior) in the guide, which runs first
+            # (model.py:820-830, 927-937)
+            if not float(alpha_prior) > 0:
+                raise ValueError("alpha_prior must be positive")
+            init["alpha_pi"] = torch.full((G, A), float(np.log(np.float32(alpha_prior))))
             if tiling:  # alpha_pi0[~allele_mask] = epsilon (model.py:643)
                 init["alpha_pi"][~data.allele_mask.cpu()] = float(np.log(1e-5))
         if self.fit_noise:

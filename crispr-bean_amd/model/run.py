@@ -81,6 +81,8 @@ def build_engine(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000,
         sd_scale=float(m.get("sd_scale", 0.01)),
         prior_params=m.get("prior_params"),
         mask_thres=int(m.get("mask_thres", 10)),
+        # the guide runs first, so its `alpha_prior` is the one pyro.param("alpha_pi", ...) is created with
+        alpha_prior=float(g.get("alpha_prior", m.get("alpha_prior", 1)) or 1),
         initial_lr=initial_lr,
         gamma=gamma,
         num_steps=num_steps,
@@ -128,15 +130,14 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
         if verbose:
             print(f"loss {loss} @ iter {step}")
 
+    rank = dist.get_rank() if world > 1 else 0
     try:
         if sharded:
             constrained, losses = parallel.run_sharded(
                 factory, data, num_steps, seed=seed, report_every=report_every, on_report=report)
         else:
-            g = parallel._Group.__new__(parallel._Group)  # single-process group: no collectives
-            g.on, g.group = False, None
             whole = (0, data.n_guides, 0, getattr(data, "n_targets", 0))
-            eng = factory(data, whole, data.n_guides)
+            eng = factory(data, whole, data.n_guides)  # configuration errors surface as they are
             done = 0
             while done < num_steps:
                 k = min(report_every, num_steps - done)
@@ -149,10 +150,13 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
             constrained = eng.constrained()
         if not all(l == l and abs(l) != float("inf") for l in losses):
             bad = next(i for i, l in enumerate(losses) if not (l == l and abs(l) != float("inf")))
-            raise ValueError(f"non-finite loss at iteration {bad}")
-    except ValueError as exc:
-        error("Error occurred during fitting. Saving temporary output at tmp_result.pkl.")
-        with open("tmp_result.pkl", "wb") as handle:
+            raise FloatingPointError(f"non-finite loss at iteration {bad}")
+    except FloatingPointError as exc:
+        # the reference dumps the parameter store when the fit itself fails (run.py:381-390); every
+        # rank holds its own shard's parameters, so the file name carries the rank when there are several
+        name = "tmp_result.pkl" if world == 1 else f"tmp_result.rank{rank}.pkl"
+        error(f"Error occurred during fitting. Saving temporary output at {name}.")
+        with open(name, "wb") as handle:
             dump = {k: v.cpu() for k, v in engines[-1].constrained().items()} if engines else {}
             pkl.dump({"param": dump}, handle)
         for e in engines:
@@ -160,6 +164,10 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
         raise ValueError(
             f"Fitting halted for command: {' '.join(sys.argv)} with following error: \n {exc}"
         )
+    except Exception:
+        for e in engines:
+            e.close()
+        raise
     for e in engines:
         e.close()
     store = ParamStore(constrained)

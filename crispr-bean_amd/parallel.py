@@ -100,13 +100,15 @@ class _Group:
         return dist.get_rank(self.group) if self.on else 0
 
     def all_reduce_sum(self, t: torch.Tensor):
-        if self.on and self.world > 1:
+        # also with one rank: the collective is then a copy, but the call (RCCL stream interplay with
+        # the engine's stream and graph replay) is the same one an N-rank fit makes
+        if self.on:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_gather_rows(self, t: torch.Tensor, sizes: Sequence[int]) -> torch.Tensor:
         """Concatenate per-rank tensors with different leading sizes."""
-        if not self.on or self.world == 1:
+        if not self.on:
             return t
         m = max(max(sizes), 1)
         pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -145,9 +147,13 @@ def run_sharded(
     else:
         shards = plan_shards(data.target_lengths.cpu().numpy(), grp.world)
     mine = shards[grp.rank]
-    if mine[1] - mine[0] == 0:
+    # `shards` is identical on every rank: all of them raise (before any engine or collective exists),
+    # so no rank is left waiting in an all-reduce for one that has gone
+    empty = [k for k, s in enumerate(shards) if s[1] - s[0] == 0]
+    if empty:
         raise ValueError(
-            f"rank {grp.rank} received no guides: {data.n_targets} targets cannot feed {grp.world} ranks"
+            f"rank(s) {empty} would receive no guides: {getattr(data, 'n_targets', 0)} targets / "
+            f"{data.n_guides} guides cannot feed {grp.world} ranks"
         )
     extra = {}
     if replicated_targets:

@@ -339,14 +339,39 @@ def mixture_normal_loss(data, params, noise=None, use_bcmatch=True, sd_scale=0.0
     return _finish(model_lp, guide_lp, record)
 
 
+def allele_moments(data, mu_e, sd_e, sparse: bool):
+    """Per-allele mean and scale from the per-edit draws (``model.py:618-622``):
+    ``matmul(allele_to_edit, mu_edits)`` and ``linalg.norm(allele_to_edit * sd_edits, dim=-1)``.
+
+    ``sparse=False`` is the reference's dense 0/1 ``(G, A-1, E)`` form.  ``sparse=True`` evaluates
+    the same two sums through the CSR map with ``index_add`` (one term per nonzero instead of
+    ``G (A-1) E`` products), which is what lets the oracle run at BASELINE config 3's size (193k
+    allele slots x 30k edits would be 46 GB dense); ``tests/test_oracle_kat.py`` pins it to the
+    dense form at small sizes.  Rows without edits have scale 0 in both forms (the reference
+    masks them through ``allele_mask``)."""
+    G, A1 = data.n_guides, data.n_max_alleles - 1
+    if not sparse:
+        a2e = data.allele_to_edit_dense().to(mu_e.dtype)  # f32 in the reference
+        return torch.matmul(a2e, mu_e), torch.linalg.norm(a2e * sd_e[None, None, :], dim=-1)
+    ptr = data.a2e_ptr.to(torch.int64)
+    idx = data.a2e_idx.to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(G * A1, dtype=torch.int64), ptr[1:] - ptr[:-1])
+    mu_a = torch.zeros(G * A1, dtype=mu_e.dtype).index_add(0, rows, mu_e[idx])
+    var_a = torch.zeros(G * A1, dtype=sd_e.dtype).index_add(0, rows, sd_e[idx] ** 2)
+    # d sqrt(v) / dv at v = 0 is infinite: keep empty rows out of the graph as norm() does (its
+    # subgradient at 0 is 0)
+    live = var_a > 0
+    sd_a = torch.where(live, torch.sqrt(torch.where(live, var_a, torch.ones_like(var_a))), torch.zeros_like(var_a))
+    return mu_a.reshape(G, A1), sd_a.reshape(G, A1)
+
+
 def multi_mixture_normal_loss(data, params, noise=None, use_bcmatch=True, sd_scale=0.01,
                               scale_by_accessibility=False, fit_noise=True,
-                              prior_params=None, record=None, eps=EPS):
+                              prior_params=None, record=None, eps=EPS, sparse=False):
     """``MultiMixtureNormalModel`` + ``MultiMixtureNormalGuide``
     (``model.py:550-751,878-962``): per-edit latents, allele = sum of edits."""
     P = constrained(params)
     R, B, G, A, E = data.n_reps, data.n_condits, data.n_guides, data.n_max_alleles, data.n_edits
-    a2e = data.allele_to_edit_dense().to(P["mu_loc"].dtype)  # f32 in the reference
     mu_e = normal_rsample(P["mu_loc"], P["mu_scale"], _noise(noise, "eps_mu"))
     sd_e = normal_rsample(P["sd_loc"], P["sd_scale"], _noise(noise, "eps_sd")).exp()
     guide_lp = {
@@ -371,8 +396,7 @@ def multi_mixture_normal_loss(data, params, noise=None, use_bcmatch=True, sd_sca
     p_mu, p_sd = _priors((E,), sd_scale, prior_params)
     model_lp["mu_targets"] = p_mu.log_prob(mu_e).sum()
     model_lp["sd_targets"] = p_sd.log_prob(sd_e).sum()
-    mu_a = torch.matmul(a2e, mu_e)
-    sd_a = torch.linalg.norm(a2e * sd_e[None, None, :], dim=-1)
+    mu_a, sd_a = allele_moments(data, mu_e, sd_e, sparse)
     mu = torch.cat([torch.zeros((G, 1)), mu_a], -1)
     sd = torch.cat([torch.ones((G, 1)), sd_a], -1)
     conc_p = (alpha_pi + eps / A) / (alpha_pi.sum(-1)[:, None] + eps) * data.pi_a0[:, None]

@@ -8,15 +8,16 @@ data = make_sorting_variant_screen(50000, 5, seed=20240502).to("cuda:0")
 eng = engine.HipSVI("MixtureNormal", data, num_steps=100)
 eng.run(20, graph_chunk=0); torch.cuda.synchronize()
 WAVE = os.environ.get("BEAN_HIP_GUIDE") != "split"
-n_waves = (1 if WAVE else 2) * 5 * ((50000 + 63) // 64)
+n_waves = (1 if WAVE else 2) * 5 * (((50000 + 63) // 64 + 7) // 8 * 8)
 buf = np.zeros(n_waves * 8, dtype=np.uint64)
 lib = _lib.load()
 lib.bean_hip_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
 assert lib.bean_hip_debug_stamps(eng._h, buf.ctypes.data, buf.size) == 0
 s = buf.reshape(n_waves, 8).astype(np.int64)
+s = s[s[:, 0] != 0]  # padded wave ids of the XCD-aware grid exit at once
 d = np.diff(s, axis=1)
 if WAVE:
-    names = ["setup loads", "pi draw", "lik X pass 1", "lik X bin loop", "lik X total term", "lik X_bcmatch", "pi terms + dirichlet grads + rows"]
+    names = ["setup loads", "pi draw + pass 1", "lik X loop 1 (lgamma)", "lik X total + loop 2", "(gap)", "lik X_bcmatch", "pi terms + dirichlet grads + rows"]
 else:
   names = ["prologue loads+LDS store", "barrier", "pass1 (+pi loads)", "pass2", "d0+final math", "exchange+writes", "block_sum"]
 print("median cycles per segment:")

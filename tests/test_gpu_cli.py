@@ -194,25 +194,44 @@ def test_build_prior_then_run_with_prior_params(tmp_path):
     assert len(el) == 6 and np.isfinite(el[["mu", "mu_sd", "mu_z", "sd"]].values).all()
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_two_rank_cli_writes_the_single_process_tables(tmp_path):
     """`torchrun --nproc-per-node 2 bin/bean run ...` (rehearsed on one GPU over gloo): the guides
     are sharded over the ranks, rank 0 writes the tables; for the variant sorting family the result
-    is the single-process result bit for bit, for tiling up to the regrouping of float64 sums."""
+    is the single-process result bit for bit (also with per-target `--prior-params`, which every rank
+    cuts to its own targets), for tiling up to the regrouping of float64 sums."""
     import subprocess
     import sys
 
+    import torch
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BEAN_DIST_BACKEND="gloo", BEAN_DIST_SINGLE_DEVICE="1")
-    for design, path, extra, label in (
-        ("variant", VAR, [], "MixtureNormal"),
-        ("tiling", TILING, ["--allele-df-key", "allele_counts", "--control-guide-tag", "None"], "MultiMixtureNormal"),
+    g = torch.Generator().manual_seed(3)
+    prior = {"mu_loc": torch.randn((6, 1), generator=g) * 0.3, "mu_scale": torch.rand((6, 1), generator=g) + 0.5,
+             "sd_loc": torch.randn((6, 1), generator=g) * 0.1, "sd_scale": torch.rand((6, 1), generator=g) * 0.05 + 0.01}
+    prior_path = str(tmp_path / "prior.pkl")
+    with open(prior_path, "wb") as fh:
+        pickle.dump(prior, fh)
+    for tag, design, path, extra, label in (
+        ("variant", "variant", VAR, [], "MixtureNormal"),
+        ("prior", "variant", VAR, ["--prior-params", prior_path], "MixtureNormal"),
+        ("tiling", "tiling", TILING, ["--allele-df-key", "allele_counts", "--control-guide-tag", "None"],
+         "MultiMixtureNormal"),
     ):
         argv = ["sorting", design, path, "--n-iter", "30", "--repguide-mask", "None", *extra]
-        d1 = _run(tmp_path / f"single_{design}", *argv)
-        out2 = str(tmp_path / f"two_{design}")
+        d1 = _run(tmp_path / f"single_{tag}", *argv)
+        out2 = str(tmp_path / f"two_{tag}")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-               "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(root, "bin", "bean"), "run",
-               *argv, "-o", out2, "--sample-mask-col", ""]
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bin", "bean"),
+               "run", *argv, "-o", out2, "--sample-mask-col", ""]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stderr[-2000:]
         (d2,) = [os.path.join(out2, p) for p in os.listdir(out2) if p.startswith("bean_run_result.")]

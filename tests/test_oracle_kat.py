@@ -214,3 +214,34 @@ def test_oracle_fit_decreases_loss_and_recovers_effects():
     big = np.abs(truth) > 0.8
     # the fit has moved the strong effects in the right direction
     assert np.mean(np.sign(mu[big]) == np.sign(truth[big])) > 0.8
+
+
+@pytest.mark.parametrize("n_alleles,mode", [(4, "ref"), (8, "f64"), (13, "f64")])
+def test_sparse_allele_moments_equal_the_dense_form(n_alleles, mode):
+    """The gather / index_add form of allele_to_edit @ mu_edits and ||allele_to_edit * sd_edits||
+    (bean/model/model.py:618-622) used at BASELINE config 3's size equals the reference's dense
+    form: loss and every gradient."""
+    from bean_amd.preprocessing.synthetic import make_sorting_tiling_screen
+
+    data = make_sorting_tiling_screen(150, 2, seed=21, n_max_alleles=n_alleles, mask_fraction=0.05)
+    torch.manual_seed(3)
+    params = elbo.init_params("MultiMixtureNormal", data)
+    if mode == "f64":
+        data = elbo.as_float64(data)
+        params = {k: v.detach().double().requires_grad_(True) for k, v in params.items()}
+    with torch.no_grad():
+        for k, v in params.items():
+            noise = 0.3 * torch.randn_like(v)
+            v.add_(noise * data.allele_mask if k == "alpha_pi" else noise)
+    g = torch.Generator().manual_seed(5)
+    conc = torch.rand((data.n_reps, 1, data.n_guides, n_alleles), generator=g, dtype=torch.float64) + 0.2
+    draws = {"eps_mu": torch.randn(data.n_edits, generator=g), "eps_sd": torch.randn(data.n_edits, generator=g),
+             "pi": torch.distributions.Dirichlet(conc).sample()}
+    dense = svi.loss_and_grads(elbo.multi_mixture_normal_loss, data, params, noise=draws)
+    sparse = svi.loss_and_grads(elbo.multi_mixture_normal_loss, data, params, noise=draws, sparse=True)
+    tol = 1e-12 if mode == "f64" else 2e-6
+    assert abs(dense[0] - sparse[0]) <= tol * abs(dense[0])
+    for k in dense[1]:
+        ref = dense[1][k].double()
+        err = (sparse[1][k].double() - ref).abs().max().item()
+        assert err <= max(tol * 10, 1e-11) * (ref.abs().max().item() + 1e-30), (k, err)
