@@ -362,7 +362,7 @@ void k_guide_wave2(DevArgs c) {
     const double tot = wave_sum(loss);
     if (lane == 0) {
         loss_add(c, ctr.slot, tot);
-        if (wg == 0) *c.ctrA = ctr;
+        if (wg == 0) publish_ctr(c, ctr);
     }
     BEAN_STAMP_AT(7);
 }

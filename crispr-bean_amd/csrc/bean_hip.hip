@@ -37,6 +37,7 @@ struct bean_hip_ctx {
     bool fused_guide;  // false: BEAN_HIP_GUIDE=split selects the sample / lik / pi-terms launches
     bool wave_guide;   // sorting variant families, default: one wave per (guide tile, replicate)
     bool wave2;        // ... in its second form, k_guide_wave2 (BEAN_HIP_GUIDE=wave1 selects the first)
+    bool surv_wave;    // survival variant families: k_guide_survival_wave (BEAN_HIP_SURVIVAL=block: k_guide_survival)
     long long* loss_acc;  // library-owned fixed-point loss accumulators, kLossWords per loss_hist slot
     int* tile_targets_dev;
     bool tiling_wave;  // tiling families, default: k_guide_tiling_wave (BEAN_HIP_TILING=block: k_guide_tiling)
@@ -47,6 +48,7 @@ struct bean_hip_ctx {
     unsigned long long graph_seed;
     // profiling of the dominant kernel
     bool profile;
+    bool profile_param;  // profile mode 2: time k_param<FINISH, ADAM, PREP> instead of the guide kernel
     std::vector<hipEvent_t> ev;  // start/stop pairs
 };
 
@@ -235,6 +237,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         c->fused_guide = !((env && env[0] == '1') || (mode && !strcmp(mode, "split")));
         c->wave_guide = c->fused_guide;
         c->wave2 = !(mode && !strcmp(mode, "wave1"));
+        const char* smode = getenv("BEAN_HIP_SURVIVAL");
+        c->surv_wave = !(smode && !strcmp(smode, "block"));
         const char* tmode = getenv("BEAN_HIP_TILING");
         c->tiling_wave = !(tmode && !strcmp(tmode, "block"));
 #if BEAN_AMAX > 8
@@ -244,6 +248,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->graph_seed = 0;
     c->loss_acc = nullptr;
     c->profile = false;
+    c->profile_param = false;
     c->loss_capacity = 0;
     DevArgs& d = c->d;
     d.R = s->n_reps; d.B = s->n_condits; d.G = s->n_guides; d.T = s->n_targets;
@@ -278,11 +283,13 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const bool use_split = split_ok && !c->fused_guide;
     c->wave_guide = c->wave_guide && split_ok;
     c->wave2 = c->wave2 && c->wave_guide;
-    d.rows_v2 = c->wave2 ? 1 : 0;
+    c->surv_wave = c->surv_wave && is_survival(*s) && !is_tiling(*s);
+    d.rows_v2 = (c->wave2 || c->surv_wave) ? 1 : 0;
     c->tiling_wave = c->tiling_wave && is_tiling(*s);
     const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G : 0;
     const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G
-                                       : (c->wave_guide ? (uint64_t)(c->wave2 ? kW2Rows : kNumPart + 2) * Rr * G : 0);
+                                       : (c->wave_guide ? (uint64_t)(c->wave2 ? kW2Rows : kNumPart + 2) * Rr * G
+                                                        : (c->surv_wave ? (uint64_t)kW2Rows * Rr * G : 0));
 #ifdef BEAN_STAMP
     const uint64_t n_dbg = 8 * 2 * Rr * (((G + 63) / 64 + 7) / 8 * 8);
 #else
@@ -331,6 +338,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     } else if (c->wave_guide) {
         d.wrow = w; w += (uint64_t)kNumPart * Rr * G;
         d.nobs = w; w += 2 * Rr * G;
+    } else if (c->surv_wave) {
+        d.wrow = w; w += (uint64_t)kW2Rows * Rr * G;
     }
     if (use_split) {
         d.rrow = w; w += 3 * Rr * G;
@@ -485,6 +494,15 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
     grid_param(c, ntb, nb);
     DevArgs d = c->d;
     d.tgrad = tgrad;
+    if (c->profile && c->profile_param && FINISH && PREP && c->ev.size() < 8192) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        hipExtLaunchKernelGGL((k_param<FINISH, ADAM, PREP>), dim3(nb), dim3(kParamBlock), 0, stream, e0, e1, 0, d, ntb);
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+        return;
+    }
     hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP>), dim3(nb), dim3(kParamBlock), 0, stream, d, ntb);
 }
 
@@ -542,7 +560,7 @@ static void launch_guide_split(bean_hip_ctx* c, hipStream_t stream) {
         const long n = (long)d.R * d.G;
         hipLaunchKernelGGL(k_sample_pi, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
     }
-    const bool prof = c->profile && c->ev.size() < 8192;
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {
         (void)hipEventCreate(&e0);
@@ -567,7 +585,7 @@ static void launch_guide_wave2(bean_hip_ctx* c, hipStream_t stream) {
     const int tiles = (d.G + 63) / 64;
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8) * (unsigned)d.R), block(64);
     const size_t lds = guide_wave2_lds(d.B, d.tile_targets);
-    const bool prof = c->profile && c->ev.size() < 8192;
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {
         (void)hipEventCreate(&e0);
@@ -600,7 +618,7 @@ static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
     const dim3 grid((d.G + 63) / 64, d.R), block(64);
     const size_t lds = ((size_t)3 * d.B * d.tile_targets + (size_t)kWaveMisc * 64) * sizeof(double) +
                        (size_t)2 * d.B * 64 * sizeof(float);
-    const bool prof = c->profile && c->ev.size() < 8192;
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {
         // profile mode: the events carry the kernel's own begin / end timestamps (hipExtLaunchKernelGGL),
@@ -645,7 +663,7 @@ static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
     const dim3 grid((d.G + 63) / 64, d.R), block(64);
     const size_t lds = (size_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * 64 * sizeof(double) +
                        (size_t)2 * d.B * 64 * sizeof(float);
-    const bool prof = c->profile && c->ev.size() < 8192;
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     if (prof) {  // events with the kernel's own timestamps, as in launch_guide_wave
         hipEvent_t e0 = nullptr, e1 = nullptr;
         (void)hipEventCreate(&e0);
@@ -669,6 +687,39 @@ static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
     hipLaunchKernelGGL(k_sum_trow, dim3((d.G + 255) / 256, kTNumPart), dim3(256), 0, stream, d);
 }
 
+// survival variant families, one wave per (guide tile, replicate) (bean_survival_v2.hpp)
+static void launch_guide_survival_wave(bean_hip_ctx* c, hipStream_t stream) {
+    const DevArgs& d = c->d;
+    const int tiles = (d.G + 63) / 64;
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8) * (unsigned)d.R), block(64);
+    const size_t lds = guide_survival_wave_lds(d.B);
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        if (d.family == kMixture) {
+            if (d.flags & kAcc)
+                hipExtLaunchKernelGGL((k_guide_survival_wave<kMixture, true>), grid, block, lds, stream, e0, e1, 0, d);
+            else
+                hipExtLaunchKernelGGL((k_guide_survival_wave<kMixture, false>), grid, block, lds, stream, e0, e1, 0, d);
+        } else {
+            hipExtLaunchKernelGGL((k_guide_survival_wave<kNormal, false>), grid, block, lds, stream, e0, e1, 0, d);
+        }
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+    } else if (d.family == kMixture) {
+        if (d.flags & kAcc)
+            hipLaunchKernelGGL((k_guide_survival_wave<kMixture, true>), grid, block, lds, stream, d);
+        else
+            hipLaunchKernelGGL((k_guide_survival_wave<kMixture, false>), grid, block, lds, stream, d);
+    } else {
+        hipLaunchKernelGGL((k_guide_survival_wave<kNormal, false>), grid, block, lds, stream, d);
+    }
+    if (d.surv_q0lik)  // projection term of the G-dimensional Dirichlet's pathwise gradient
+        hipLaunchKernelGGL(k_sum_q, dim3(d.R), dim3(1024), 0, stream, d);
+}
+
 static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = true) {
     const DevArgs& d = c->d;
     if (!c->fused_guide && !d.survival && d.family != kMultiMixture) {
@@ -682,6 +733,10 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
     }
     const int nw = waves_per_block(c);
     if (with_sums) launch_sums(c, stream);
+    if (c->surv_wave) {
+        launch_guide_survival_wave(c, stream);
+        return;
+    }
     if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
         const long n = (long)(d.A - 1) * d.G;
         hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
@@ -692,7 +747,7 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
     }
     const dim3 grid((d.G + 63) / 64), block(64 * nw);
     const size_t lds = ((size_t)nw * kNumPart * 64 + 16) * sizeof(double);
-    const bool prof = c->profile && c->ev.size() < 8192;
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {
         (void)hipEventCreate(&e0);
@@ -941,7 +996,7 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
 
 extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
     if (c && c->d.family == kMultiMixture) return c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling";
-    if (c && c->d.survival) return "k_guide_survival";
+    if (c && c->d.survival) return c->surv_wave ? "k_guide_survival_wave" : "k_guide_survival";
     if (c && c->wave_guide) return c->wave2 ? "k_guide_wave2" : "k_guide_wave";
     return "k_lik";
 }
@@ -949,6 +1004,7 @@ extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
 extern "C" int bean_hip_set_profile(bean_hip_ctx* c, int32_t enable) {
     if (!c) return fail("bean_hip_set_profile: null handle");
     c->profile = enable != 0;
+    c->profile_param = enable == 2;
     if (c->profile) drop_graph(c);
     return 0;
 }

@@ -59,6 +59,8 @@ enum Flags { kUseBc = 1, kAcc = 2, kFitNoise = 4, kPriorNormalMu = 8, kDumpPi = 
 struct StepCtr {
     unsigned long long step;  // SVI step (RNG offset, Adam t = step + 1)
     unsigned long long slot;  // index into loss_hist
+    float step_size;          // ClippedAdam step size of update t = step + 1 (publish_ctr)
+    float pad_;
 };
 
 // partial-sum rows written by k_guide, (kNumPart, G) doubles
@@ -139,8 +141,11 @@ struct DevArgs {
 #ifndef BEAN_PARAM_BLOCK
 #define BEAN_PARAM_BLOCK 256
 #endif
+#ifndef BEAN_KP_DIAG
+#define BEAN_KP_DIAG 0
+#endif
 constexpr int kParamBlock = BEAN_PARAM_BLOCK;  // threads per block of k_param / k_target_reduce / k_q0_draws
-constexpr int kLanesPerTarget = 4;  // k_param: lanes sharing one target's Phi table entries
+constexpr int kLanesPerTarget = 16;  // k_param: lanes sharing one target: its (guide, replicate) rows and the 2 B bin edges of its Phi table
 #ifndef BEAN_AMAX
 #define BEAN_AMAX 8
 #endif
@@ -249,6 +254,15 @@ __device__ __forceinline__ AdamCoef adam_coef(const DevArgs& c, unsigned long lo
     k.clip = (float)c.clip;
     return k;
 }
+// The guide kernel of step s hands the step counter back to k_param (ctrA) together with the
+// ClippedAdam step size of the update that follows: exp + two pow in float64 are ~500 instructions,
+// which every k_param thread used to evaluate for itself at the head of its dependency chain; one
+// lane of the (long) guide kernel computes them instead.
+__device__ __forceinline__ void publish_ctr(const DevArgs& c, StepCtr ctr) {
+    ctr.step_size = adam_coef(c, ctr.step + 1).step_size;
+    *c.ctrA = ctr;
+}
+
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float grad, AdamCoef k) {
     // every rounding is pinned (no implicit contraction) so that the stand-alone
     // k_adam and the fused update inside k_param produce identical bits
@@ -429,15 +443,34 @@ __device__ __forceinline__ void write_phi_entry(const DevArgs& c, int t, int b, 
     c.tabPy[o] = -(ufh - ufl) * inv * dsig_dy;
 }
 
-// Target handled by this thread of a k_param / k_target_reduce target block, and whether the
-// thread is the one that owns the target's parameters.
+// Thin mode (the usual one): a target block of kParamBlock threads holds kTargetsPerBlock targets and
+// works in three phases with two thread -> work maps:
+//   A  sums      kLanesPerTarget lanes per target (group map): the target's (guide, replicate) rows
+//   B  scalar    ONE lane per target, packed into the block's first lanes (owner map): priors,
+//                entropies, ClippedAdam, the next draw.  Packing matters: this is a long serial chain,
+//                and a wave issues it whether one or all of its lanes are active
+//   C  tables    group map again: one lane per bin edge
+// with the hand-over through LDS.  Wide mode (few or very long targets): one target per block.
+constexpr int kTargetsPerBlock = kParamBlock / kLanesPerTarget;
+
+// owner map: the target whose parameters this thread updates (phase B)
 __device__ __forceinline__ void target_of_thread(const DevArgs& c, int& t, bool& active) {
     if (c.wide_targets) {
         t = blockIdx.x;
         active = threadIdx.x == 0;
     } else {
+        t = blockIdx.x * kTargetsPerBlock + threadIdx.x;
+        active = (int)threadIdx.x < kTargetsPerBlock && t < c.T;
+    }
+}
+// group map: the target this thread's lane group sums rows / tabulates edges for (phases A and C)
+__device__ __forceinline__ void target_of_group(const DevArgs& c, int& t, bool& lead) {
+    if (c.wide_targets) {
+        t = blockIdx.x;
+        lead = threadIdx.x == 0;
+    } else {
         t = (blockIdx.x * blockDim.x + threadIdx.x) / kLanesPerTarget;
-        active = t < c.T && (threadIdx.x & (kLanesPerTarget - 1)) == 0;
+        lead = t < c.T && (threadIdx.x & (kLanesPerTarget - 1)) == 0;
     }
 }
 
@@ -523,11 +556,11 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
 __global__ __launch_bounds__(kParamBlock) void k_target_reduce(DevArgs c, double* out) {
     __shared__ double scratch[16];
     int t;
-    bool active;
-    target_of_thread(c, t, active);
+    bool lead;
+    target_of_group(c, t, lead);
     double gmu, gy;
-    target_grad_sums(c, t, active, scratch, gmu, gy);
-    if (active) {
+    target_grad_sums(c, t, lead, scratch, gmu, gy);
+    if (lead) {
         out[t] = gmu;
         out[c.T + t] = gy;
     }
@@ -538,6 +571,12 @@ __global__ __launch_bounds__(kParamBlock) void k_target_reduce(DevArgs c, double
 template <bool FINISH, bool ADAM, bool PREP>
 __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_blocks) {
     __shared__ double scratch[16];
+    __shared__ double hand[4][kTargetsPerBlock];  // phase hand-over: gmu, gy (A -> B), mu, y (B -> C)
+#if BEAN_KP_DIAG == 1  // diagnostic builds (wrong results): time the target part alone ...
+    if ((int)blockIdx.x >= n_target_blocks) return;
+#elif BEAN_KP_DIAG == 2  // ... or the guide part alone
+    if ((int)blockIdx.x < n_target_blocks && blockIdx.x != 0) return;
+#endif
     const StepCtr ctr = *c.ctrA;
     const unsigned long long s_fin = ctr.step;
     const unsigned long long s_prep = FINISH ? ctr.step + 1 : ctr.step;
@@ -545,7 +584,10 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     AdamCoef ak;
     ak.step_size = 0.f;
     ak.clip = 0.f;
-    if (FINISH && ADAM) ak = adam_coef(c, s_fin + 1);
+    if (FINISH && ADAM) {
+        ak.step_size = ctr.step_size;  // of update t = s_fin + 1, computed by the guide kernel (publish_ctr)
+        ak.clip = (float)c.clip;
+    }
     double loss_fin = 0.0, loss_prep = 0.0;
     const bool mixture = c.family == kMixture;
 
@@ -584,8 +626,24 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                     gmu = c.tgrad[t];
                     gy = c.tgrad[c.T + t];
                 }
-            } else {
+            } else if (c.wide_targets) {
                 target_grad_sums(c, t, active, scratch, gmu, gy);
+            } else {
+                // phase A (group map) -> phase B (owner map) through LDS
+                int tg;
+                bool lead;
+                target_of_group(c, tg, lead);
+                double a, b;
+                target_grad_sums(c, tg, lead, scratch, a, b);
+                if (lead) {
+                    hand[0][threadIdx.x / kLanesPerTarget] = a;
+                    hand[1][threadIdx.x / kLanesPerTarget] = b;
+                }
+                __syncthreads();
+                if (active) {
+                    gmu = hand[0][threadIdx.x];
+                    gy = hand[1][threadIdx.x];
+                }
             }
         }
         if (active && c.survival) {
@@ -711,11 +769,41 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 if ((int)threadIdx.x < c.B) write_phi_entry(c, t, threadIdx.x, scratch[0], scratch[1]);
                 __syncthreads();
             } else {
-                const int lead = (threadIdx.x & 63) & ~(kLanesPerTarget - 1);
-                const double mu = __shfl(tab_mu, lead, 64), y = __shfl(tab_y, lead, 64);
+                // one lane per bin EDGE: even lane = upper edge, odd lane = lower edge of bin e >> 1, so
+                // the erf / exp chain of a target is one edge deep (it was 2 B / 4 edges deep with four
+                // lanes per target); the pair is combined with one shuffle.  Same formulas, same bits as
+                // write_phi_entry.
+                if (active) {
+                    hand[2][threadIdx.x] = tab_mu;
+                    hand[3][threadIdx.x] = tab_y;
+                }
+                __syncthreads();
+                const int grp = threadIdx.x / kLanesPerTarget;
+                t = (blockIdx.x * blockDim.x + threadIdx.x) / kLanesPerTarget;  // group map from here on
+                const double mu = hand[2][grp], y = hand[3][grp];
                 const int j = threadIdx.x & (kLanesPerTarget - 1);
-                if (t < c.T)
-                    for (int b = j; b < c.B; b += kLanesPerTarget) write_phi_entry(c, t, b, mu, y);
+                const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
+                const double dsig_dy = c.family == kNormal ? 0.5 * sigma : sigma;
+                const double inv = 1.0 / sigma;
+                for (int e0 = 0; e0 < 2 * c.B; e0 += kLanesPerTarget) {
+                    const int e = e0 + j, b = e >> 1;
+                    const bool upper = (e & 1) == 0, live = t < c.T && b < c.B;
+                    const double z = live ? (upper ? c.z_hi[b] : c.z_lo[b]) : 0.0;
+                    double cdf = upper ? 1.0 : 0.0, pdf = 0.0, upd = 0.0;
+                    if (live && !isinf(z)) {
+                        const double u = (z - mu) * inv;
+                        cdf = norm_cdf(u);
+                        pdf = norm_pdf(u);
+                        upd = u * pdf;
+                    }
+                    const double cl = __shfl_xor(cdf, 1, 64), fl = __shfl_xor(pdf, 1, 64), ufl = __shfl_xor(upd, 1, 64);
+                    if (live && upper) {
+                        const long o = (long)b * c.T + t;
+                        c.tabP[o] = cdf - cl;
+                        c.tabPmu[o] = -(pdf - fl) * inv;
+                        c.tabPy[o] = -(upd - ufl) * inv * dsig_dy;
+                    }
+                }
             }
         }
     } else if (c.family == kMultiMixture) {
@@ -891,7 +979,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
             lgamma_digamma(ia, lg_a, dg_a);
             const double Rf = (double)c.R;
             // d/d ia of log q: direct term R (psi(tot) - psi(ia)) + sum_r log x, and the pathwise term
-            double grad = Rf * (dg_tot - dg_a) + c.part[(long)kPQ0 * c.G + g];
+            double grad = Rf * (dg_tot - dg_a) + part_row(c, kPQ0, g);
             for (int r = 0; r < c.R; ++r) {
                 const double gm = c.gam[(long)r * c.G + g];
                 const double x = c.x0_in ? gm
@@ -930,7 +1018,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         float q0u = in ? c.p[7][g] : 0.f;
         if (FINISH && in) {
             const double q0 = (double)expf(q0u);
-            emit_grad<ADAM>(c, 7, g, c.part[(long)kPQ0 * c.G + g] * q0, ak);
+            emit_grad<ADAM>(c, 7, g, part_row(c, kPQ0, g) * q0, ak);
             if (ADAM) q0u = c.p[7][g];
             // - log p(mu_negctrl): Normal(m0, s0) built from Python floats => float32 tensors
             const float s0f = (float)c.neg_scale;
@@ -973,6 +1061,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         StepCtr nxt;
         nxt.step = s_prep;
         nxt.slot = slot_prep;
+        nxt.step_size = 0.f;
+        nxt.pad_ = 0.f;
         *c.ctrB = nxt;
     }
 }
@@ -1360,7 +1450,7 @@ void k_guide_wave(DevArgs c) {
     const double tot = wave_sum(loss);
     if (lane == 0) {
         loss_add(c, ctr.slot, tot);
-        if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = ctr;
+        if (blockIdx.x == 0 && blockIdx.y == 0) publish_ctr(c, ctr);
     }
     BEAN_STAMP_AT(7);
 }
@@ -1604,7 +1694,7 @@ void k_lik(DevArgs c) {
     BEAN_STAMP_AT(7);
     if (threadIdx.x == 0) {
         loss_add(c, c.ctrB->slot, tot);
-        if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = *c.ctrB;
+        if (blockIdx.x == 0 && blockIdx.y == 0) publish_ctr(c, *c.ctrB);
     }
 }
 
@@ -1985,7 +2075,7 @@ void k_guide_survival(DevArgs c) {
     const double tot = block_sum(loss, scratch);
     if (threadIdx.x == 0) {
         loss_add(c, ctr.slot, tot);
-        if (blockIdx.x == 0) *c.ctrA = ctr;
+        if (blockIdx.x == 0) publish_ctr(c, ctr);
     }
 }
 
@@ -2372,7 +2462,7 @@ void k_guide_tiling(DevArgs c) {
     const double tot = block_sum(loss, scratch);
     if (threadIdx.x == 0) {
         loss_add(c, ctr.slot, tot);
-        if (blockIdx.x == 0) *c.ctrA = ctr;
+        if (blockIdx.x == 0) publish_ctr(c, ctr);
     }
 }
 
@@ -2672,7 +2762,7 @@ void k_guide_tiling_wave(DevArgs c) {
     const double tot = wave_sum(loss);
     if (lane == 0) {
         loss_add(c, ctr.slot, tot);
-        if (blockIdx.x == 0 && blockIdx.y == 0) *c.ctrA = ctr;
+        if (blockIdx.x == 0 && blockIdx.y == 0) publish_ctr(c, ctr);
     }
 }
 
@@ -2775,6 +2865,8 @@ __global__ void k_set_step(StepCtr* a, StepCtr* b, unsigned long long step, unsi
     StepCtr s;
     s.step = step;
     s.slot = slot;
+    s.step_size = 0.f;  // set by the guide kernel before any update uses it
+    s.pad_ = 0.f;
     *a = s;
     *b = s;
 }
@@ -2826,3 +2918,4 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
 }  // namespace bean
 
 #include "bean_guide_v2.hpp"
+#include "bean_survival_v2.hpp"

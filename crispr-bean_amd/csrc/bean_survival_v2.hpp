@@ -1,0 +1,324 @@
+// k_guide_survival_wave: the per-(replicate, guide) kernel of the survival variant families in the
+// wave form of k_guide_wave2 (bean_guide_v2.hpp): one single-wave workgroup per (64-guide tile,
+// replicate), rolled loops over the timepoints with thread-private LDS columns, per-replicate rows
+// (summed over replicates by k_param), XCD-aware 1-D grid.  It replaces the block form
+// k_guide_survival<B, ...> (R waves per block, per-thread arrays e[B], ge[B], P0[B], P1[B]: 216 VGPRs
+// at six timepoints, two waves per SIMD), which stays selectable (BEAN_HIP_SURVIVAL=block) as the A/B
+// reference.
+//
+// Reference semantics: bean/model/survival_model.py - NormalModel 15-130 (+ guide 629-648),
+// ControlNormalModel 133-212, MixtureNormalModel 215-424 (+ guide 651-739): component "bin
+// probabilities" are exp(mu_a t_b) with mu = [u_g, u_g + mu_t]; control_allele_count ~
+// Multinomial(pi exp(mu t_ctrl)); the Dirichlet-over-all-guides site is handled per (rep, guide).
+//
+// Likelihood algebra (same as k_guide_wave2, with the total term first so that no per-timepoint
+// value has to be kept): with alpha_b = max((e_b sf_b + eps/B) k m_b, eps), k = a0 / (S + eps):
+//   pre-pass   S = sum e_b sf_b;  A0 = sum alpha_b;  d0 = lgamma/digamma difference of (A0, n)
+//   main loop  ga_b = d0.dp - dpsi_b (0 on the floor);  S_Q += ga_b k m_b sf_b Q_b;  t_Q += sf_b Q_b;
+//              Wa += ga_b alpha_b                         for Q in {P0, P1, t P1}
+//   close      d nll / d(weight of Q) = S_Q - Wa inv t_Q
+#pragma once
+
+namespace bean {
+
+constexpr int kSvMisc = 4;  // per-guide values staged in LDS: a0, a0_bc, c_p (2)
+
+__host__ __device__ inline size_t guide_survival_wave_lds(int B) {
+    return ((size_t)4 * B + (size_t)2 * B * 64 + (size_t)kSvMisc * 64) * sizeof(double) +
+           (size_t)2 * B * 64 * sizeof(float);
+}
+
+template <int FAM, bool ACC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void k_guide_survival_wave(DevArgs c) {
+    constexpr bool MIX = FAM == kMixture;
+    extern __shared__ double sls[];
+    const int lane = threadIdx.x;
+    const int G = c.G, B = c.B, R = c.R;
+    const int wg = blockIdx.x;
+    const int kk = wg >> 3;
+    const int r = kk % R;
+    const int tile = (kk / R) * 8 + (wg & 7);  // the R waves of a tile share an XCD (blockIdx % 8)
+    if (tile * 64 >= G) return;
+    const int g = tile * 64 + lane;
+    const bool valid = g < G;
+    const StepCtr ctr = *c.ctrB;
+    double loss = 0.0;
+
+    // LDS: [4][B] sf, sf_bc, sample mask, time | [B][64] P0 | [B][64] P1 | [kSvMisc][64] | [2][B][64] counts
+    double* cst = sls;
+    double* p0s = cst + 4 * B + lane;              // exp(u t_b)          at p0s[b * 64]
+    double* p1s = cst + 4 * B + B * 64 + lane;     // exp((u + mu_t) t_b) at p1s[b * 64]
+    double* ms = cst + 4 * B + 2 * B * 64 + lane;  // ms[q * 64]
+    float* xs = (float*)(cst + 4 * B + 2 * B * 64 + kSvMisc * 64);
+    const bool use_bc = (c.flags & kUseBc) != 0;
+    const bool q0lik = !MIX && c.surv_q0lik;
+    bool rgm = false, negc = false;
+    float api0 = 0.f, api1 = 0.f, p7 = 0.f;
+    double pa0 = 0.0, mu_t = 0.0, u = 0.0, gam = 0.0, lobs = 0.0;
+    {
+        const int gc = valid ? g : G - 1;
+        const long rgc = (long)r * G + gc;
+        float xv[2][kBMax];
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) {
+            const long xo = ((long)r * B + (b < B ? b : B - 1)) * G + gc;
+            xv[0][b] = c.X[xo];
+            xv[1][b] = use_bc ? c.Xbc[xo] : 0.f;
+        }
+        double cv = 0.0;
+        {
+            const int kq = lane >> 3, bq = lane & 7;
+            const double* src = kq == 0 ? c.sf + r * B : (kq == 1 ? (use_bc ? c.sf_bc : c.sf) + r * B
+                                                                  : (kq == 2 ? c.smask + r * B : c.time));
+            if (kq < 4 && bq < B) cv = src[bq];
+        }
+        rgm = c.rg[rgc] != 0;
+        // survival NormalModel: mu of negative-control guides is forced to 0 (survival_model.py:59-60)
+        negc = q0lik && c.negctrl && c.negctrl[gc] != 0;
+        mu_t = c.mu_t[c.g2t[gc]];
+        const double a00 = c.a0[gc], a01 = use_bc ? c.a0_bc[gc] : 0.0;
+        if (MIX) {
+            api0 = c.p[4][2 * gc];
+            api1 = c.p[4][2 * gc + 1];
+            pa0 = c.pi_a0[gc];
+            u = c.u_g[gc];
+            lobs = c.log_obs0[rgc];
+        }
+        if (MIX || q0lik) {
+            p7 = c.p[7][gc];
+            gam = c.gam[rgc];
+        }
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) {
+            const int bb = b < B ? b : B - 1;
+            xs[(0 * B + bb) * 64 + lane] = xv[0][b];
+            xs[(1 * B + bb) * 64 + lane] = xv[1][b];
+        }
+        {
+            const int kq = lane >> 3, bq = lane & 7;
+            if (kq < 4 && bq < B) cst[kq * B + bq] = cv;
+            if (B > 8) {  // the 16-condition build: timepoints 8 .. B - 1
+                const int b2 = 8 + bq;
+                if (kq < 4 && b2 < B) {
+                    const double* src = kq == 0 ? c.sf + r * B : (kq == 1 ? (use_bc ? c.sf_bc : c.sf) + r * B
+                                                                          : (kq == 2 ? c.smask + r * B : c.time));
+                    cst[kq * B + b2] = src[b2];
+                }
+            }
+        }
+        ms[0 * 64] = a00;
+        ms[1 * 64] = a01;
+    }
+    __syncthreads();
+
+    if (valid) {
+        const long rgi = (long)r * G + g;
+        const long RG = (long)R * G;
+        const double* c_sf = cst;
+        const double* c_sm = cst + 2 * B;
+        const double* c_tm = cst + 3 * B;
+        if (negc) mu_t = 0.0;
+        const double mu1 = u + mu_t;
+        // growth of the two components over the timepoints: thread-private LDS columns
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            const double tb = c_tm[b];
+            p1s[b * 64] = exp(mu1 * tb);
+            if (MIX) p0s[b * 64] = exp(u * tb);
+        }
+        double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0, dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
+        if (MIX) {
+            const double al0 = (double)expf(api0), al1 = (double)expf(api1);
+            const double rs = frcp(al0 + al1) * pa0;
+            const double cp0 = al0 * rs, cp1 = al1 * rs;
+            ms[2 * 64] = cp0;
+            ms[3 * 64] = cp1;
+            const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
+            if (c.pi_in) {
+                pi0 = c.pi_in[rgi * 2];
+                pi1 = c.pi_in[rgi * 2 + 1];
+            } else {
+                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+                const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng);
+                const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
+                const double rs2 = frcp(gm0 + gm1);
+                pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
+                pi1 = fmin(fmax(gm1 * rs2, kDblMin), kOneMinus);
+            }
+            if (c.flags & kDumpPi) {
+                c.pi_out[rgi * 2] = pi0;
+                c.pi_out[rgi * 2 + 1] = pi1;
+            }
+            pe1 = pi1;
+            if (ACC) {
+                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double s1 = pi1 * kacc;
+                const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+                const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+                const double l = flog(p1c * frcp(1.0 - p1c)) + c.lpn[g];
+                const double el = exp(l);
+                const double pn = el * frcp(1.0 + el);
+                const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+                pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+                dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
+                dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+            }
+        }
+        // the draw of the Dirichlet-over-all-guides site, float32 semantics of torch's sampler:
+        // normalise, clamp to [FLT_MIN, 1 - 2^-24]
+        double x0 = 1.0;
+        if (MIX || q0lik) {
+            x0 = c.x0_in ? gam
+                         : (double)fminf(fmaxf((float)(gam * frcp(c.gsum[r])), 1.17549435e-38f), 0.99999994f);
+            if (c.x0_out) c.x0_out[rgi] = x0;
+        }
+        // weights of the two growth columns in e_b = w0 P0_b + w1 P1_b
+        const double w0 = MIX ? (ACC ? 1.0 - pe1 : pi0) : 0.0;
+        const double w1 = MIX ? (ACC ? pe1 : pi1) : (q0lik ? x0 : 1.0);
+        const double epsB = kEps / (double)B;
+        double g0 = 0.0, g1 = 0.0, dmu = 0.0, nll = 0.0;
+        double S_x = 0.0, S_bc = 0.0, n_x = 0.0, n_bc = 0.0;
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            const double e = fma(w0, MIX ? p0s[b * 64] : 0.0, w1 * p1s[b * 64]);
+            S_x += e * c_sf[b];
+            S_bc += e * c_sf[B + b];
+            n_x += (double)xs[b * 64 + lane];
+            n_bc += (double)xs[(B + b) * 64 + lane];
+        }
+#pragma unroll 1
+        for (int lik = 0; lik < 2; ++lik) {
+            if (lik == 1 && !use_bc) break;
+            const double nn = lik ? n_bc : n_x;
+            if (!(rgm && nn > (double)c.mask_thres)) continue;
+            const float* xp = xs + lik * B * 64 + lane;
+            const double* sf = c_sf + lik * B;
+            const double S = lik ? S_bc : S_x;
+            const double a0 = ms[lik * 64];
+            const double inv = frcp(S + kEps);
+            const double ai = a0 * inv;
+            double A0 = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const double araw = alpha_raw(w0, MIX ? p0s[b * 64] : 0.0, w1, p1s[b * 64], sf[b], epsB, ai * c_sm[b]);
+                A0 += araw < kEps ? kEps : araw;
+            }
+            const DD d0 = lgamma_digamma_diff_inl(A0, nn);
+            double lsum = 0.0, Wa = 0.0;
+            double S_0 = 0.0, S_1 = 0.0, S_t = 0.0, t_0 = 0.0, t_1 = 0.0, t_t = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const double p0 = MIX ? p0s[b * 64] : 0.0, p1 = p1s[b * 64];
+                const double sfb = sf[b], tb = c_tm[b];
+                const double km = ai * c_sm[b];
+                const double araw = alpha_raw(w0, p0, w1, p1, sfb, epsB, km);
+                const bool floored = araw < kEps;
+                const DD db = lgamma_digamma_diff_inl(floored ? kEps : araw, (double)xp[b * 64]);
+                lsum += db.d;
+                const double ga = floored ? 0.0 : d0.dp - db.dp;
+                Wa += ga * araw;
+                const double cb = ga * km * sfb;
+                const double tp1 = tb * p1;
+                S_1 += cb * p1;
+                t_1 += sfb * p1;
+                S_t += cb * tp1;
+                t_t += sfb * tp1;
+                if (MIX) {
+                    S_0 += cb * p0;
+                    t_0 += sfb * p0;
+                }
+            }
+            nll += d0.d - lsum;
+            const double W = Wa * inv;
+            g0 += S_0 - W * t_0;
+            g1 += S_1 - W * t_1;
+            dmu += S_t - W * t_t;
+        }
+        double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
+        // d nll / d mu_t: through the edited column, whose weight is w1
+        double gmu = negc ? 0.0 : w1 * dmu;
+        if (q0lik) {
+            // survival NormalModel: - log p(q_0) + log q(q_0) = (ia - 1/G) log x per guide (normalisers
+            // in k_param); d loss / d q_0 for the pathwise gradient of the G-dimensional Dirichlet
+            const double ia = (double)expf(p7);
+            const double dconc = ia - (double)(1.0f / (float)c.G_tot);
+            const double lx = flog(x0);
+            nll += dconc * lx;
+            c.gq[rgi] = g1 + dconc * frcp(x0);
+            row[kPQ0 * RG] = lx;
+        }
+        if (MIX) {
+            const double cp0 = ms[2 * 64], cp1 = ms[3 * 64];
+            const bool cl0 = cp0 < 1e-5, cl1 = cp1 < 1e-5;
+            const double cq0 = cl0 ? 1e-5 : cp0, cq1 = cl1 ? 1e-5 : cp1;
+            double gpi0 = g0, gpi1 = g1;
+            if (ACC) {
+                gpi0 = 0.0;
+                gpi1 = (g1 - g0) * dpe1_dpi1;
+                row[kW2Gnoise * RG] = (g1 - g0) * dpe1_dl;
+            }
+            const double lpi0 = flog(pi0), lpi1 = flog(pi1);
+            const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
+            if (rgm) {
+                // control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)) (survival_model.py:326-346)
+                for (int cc = 0; cc < c.C; ++cc) {
+                    const double tc = c.ctrl_time[cc];
+                    const double gr0 = exp(u * tc), gr1 = exp(mu1 * tc);
+                    const double wv0 = pi0 * gr0, wv1 = pi1 * gr1;
+                    const double rW = frcp(wv0 + wv1);
+                    const float* al = c.allele + (((long)r * c.C + cc) * G + g) * 2;
+                    const double cnt0 = (double)al[0], cnt1 = (double)al[1];
+                    const double pr0 = wv0 * rW, pr1 = wv1 * rW;
+                    const bool in0 = pr0 > kProbEps && pr0 < 1.0 - kProbEps;
+                    const bool in1 = pr1 > kProbEps && pr1 < 1.0 - kProbEps;
+                    nll -= cnt0 * flog(fmin(fmax(pr0, kProbEps), 1.0 - kProbEps));
+                    nll -= cnt1 * flog(fmin(fmax(pr1, kProbEps), 1.0 - kProbEps));
+                    const double n_in = (in0 ? cnt0 : 0.0) + (in1 ? cnt1 : 0.0);
+                    gpi0 += ((in0 ? -cnt0 * frcp(wv0) : 0.0) + n_in * rW) * gr0;
+                    gpi1 += ((in1 ? -cnt1 * frcp(wv1) : 0.0) + n_in * rW) * gr1;
+                    gmu += ((in1 ? -cnt1 : 0.0) + n_in * wv1 * rW) * tc;
+                }
+                gpi0 -= (cp0 - 1.0) * rpi0;
+                gpi1 -= (cp1 - 1.0) * rpi1;
+                nll -= (cp0 - 1.0) * lpi0 + (cp1 - 1.0) * lpi1;
+            }
+            gpi0 += (cq0 - 1.0) * rpi0;
+            gpi1 += (cq1 - 1.0) * rpi1;
+            nll += (cq0 - 1.0) * lpi0 + (cq1 - 1.0) * lpi1;
+            const double proj = pi0 * gpi0 + pi1 * gpi1;
+            const double total = cq0 + cq1;
+            double path0 = 0.0, path1 = 0.0;
+#pragma unroll 1
+            for (int a = 0; a < 2; ++a) {
+                if (a ? cl1 : cl0) continue;
+                const double v = dirichlet_grad_one(a ? pi1 : pi0, a ? cq1 : cq0, total) *
+                                 ((a ? gpi1 : gpi0) - proj);
+                path0 = a ? path0 : v;
+                path1 = a ? v : path1;
+            }
+            row[kW2GA0 * RG] = (cl0 ? 0.0 : lpi0 + path0) - (rgm ? lpi0 : 0.0);
+            row[kW2GA1 * RG] = (cl1 ? 0.0 : lpi1 + path1) - (rgm ? lpi1 : 0.0);
+            // ---- Dirichlet(q0) site: + log q(x) of the guide's draw, - log p(obs) of the model
+            // (observed in the model, sampled in the guide: survival_model.py:306-311, 665-669)
+            {
+                const double q0 = (double)expf(p7);
+                const double lx = flog(x0);
+                const double tot0 = c.gsum[R];
+                nll += (q0 - 1.0) * (lx - lobs);
+                const double gout = (q0 - 1.0) * frcp(x0);
+                const double Sx = tot0 - (double)c.G_tot;  // sum_g x_g * gout_g
+                row[kPQ0 * RG] = lx - lobs + dirichlet_grad_one(x0, q0, tot0) * (gout - Sx);
+            }
+        }
+        row[kPGmu * RG] = gmu;
+        loss = nll;
+    }
+    const double tot = wave_sum(loss);
+    if (lane == 0) {
+        loss_add(c, ctr.slot, tot);
+        if (wg == 0) publish_ctr(c, ctr);
+    }
+}
+
+}  // namespace bean

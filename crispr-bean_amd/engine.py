@@ -485,8 +485,9 @@ class HipSVI:
         torch.cuda.synchronize(self.device)
         return self.loss_hist[: self.steps_done].cpu().tolist()
 
-    def set_profile(self, enable: bool):
-        self._check(self.lib.bean_hip_set_profile(self._h, int(bool(enable))), "set_profile")
+    def set_profile(self, enable):
+        """0 off; 1 time the dominant (guide) kernel; 2 time the fused k_param launches instead."""
+        self._check(self.lib.bean_hip_set_profile(self._h, int(enable)), "set_profile")
 
     def get_profile(self):
         avg, n = ctypes.c_double(0.0), ctypes.c_uint64(0)

@@ -49,8 +49,14 @@ def child(guides, family, steps):
         ms, n = prof.get_profile()
         name = prof.dominant_kernel
         prof.close()
-        out[str(G)] = {"kernel": name, "kernel_us": round(ms * 1e3, 2), "step_us": round(dt / steps * 1e6, 2),
-                       "loss_last": losses[-1]}
+        prof = engine.HipSVI(fam, data, num_steps=100)
+        prof.set_profile(2)
+        prof.run(30, graph_chunk=0)
+        torch.cuda.synchronize()
+        pms, _ = prof.get_profile()
+        prof.close()
+        out[str(G)] = {"kernel": name, "kernel_us": round(ms * 1e3, 2), "param_us": round(pms * 1e3, 2),
+                       "step_us": round(dt / steps * 1e6, 2), "loss_last": losses[-1]}
     print("AB_RESULT " + json.dumps(out), flush=True)
 
 
