@@ -52,6 +52,8 @@ class bean_hip_shape(ctypes.Structure):
         ("clip_norm", c_double),
         ("negctrl_loc", c_double),
         ("negctrl_scale", c_double),
+        ("n_sample_covariates", c_int32),
+        ("reserved_", c_int32),
     ]
 
 
@@ -66,7 +68,7 @@ BUF = {
     "PRIOR_MU_LOC": 15, "PRIOR_MU_SCALE": 16, "PRIOR_SD_LOC": 17, "PRIOR_SD_SCALE": 18,
     "A2E_PTR": 19, "A2E_IDX": 20, "E2A_PTR": 21, "E2A_IDX": 22, "ALLELE_MASK": 23,
     "TIMEPOINTS": 24, "CONTROL_TIME": 25, "LOG_OBS0": 26, "NEGCTRL_MASK": 27,
-    "XCHG_GSUM": 28, "XCHG_TGRAD": 29, "XCHG_SQ": 30,
+    "XCHG_GSUM": 28, "XCHG_TGRAD": 29, "XCHG_SQ": 30, "REP_BY_COV": 31,
     "P": 32, "G": 48, "M": 64, "V": 80,
     "EPS_MU_IN": 96, "EPS_SD_IN": 97, "PI_IN": 98, "EPS_NOISE_IN": 99,
     "EPS_MU_OUT": 100, "EPS_SD_OUT": 101, "PI_OUT": 102, "EPS_NOISE_OUT": 103,

@@ -177,7 +177,7 @@ def main(args, return_data=False):
         adjust_confidence_by_negative_control=args.adjust_confidence_by_negative_control,
         adjust_confidence_negatives=adj_negctrl_idx,
         sd_is_fitted=(args.selection == "sorting"),
-        sample_covariates=None,
+        sample_covariates=getattr(ndata, "sample_covariates", None),
         is_survival_screen=(args.selection == "survival"),
     )
     info("Done!")

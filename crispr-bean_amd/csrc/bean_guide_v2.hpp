@@ -41,6 +41,23 @@ __device__ __forceinline__ double alpha_raw(double w0, double p0, double w1, dou
     return fma(e, sfb, epsB) * km;
 }
 
+// Diagnostic builds only (wrong results): -DBEAN_GW_DIAG=n removes one piece of the kernel so that A/B
+// timings give that piece's cost in place: 1 sampler, 2 implicit-gradient calls, 3 lgamma/digamma
+// differences (replaced by two multiplies), 4 second bin loop.
+#ifndef BEAN_GW_DIAG
+#define BEAN_GW_DIAG 0
+#endif
+__device__ __forceinline__ DD gw_lgamma_diff(double a, double x) {
+#if BEAN_GW_DIAG == 3
+    DD d;
+    d.d = a * x;
+    d.dp = x;
+    return d;
+#else
+    return lgamma_digamma_diff_inl(a, x);
+#endif
+}
+
 template <int FAM, bool ACC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BEAN_WAVE_EU)))
 void k_guide_wave2(DevArgs c) {
@@ -99,6 +116,7 @@ void k_guide_wave2(DevArgs c) {
         const int j = lane & ((1 << lg2) - 1), sub = lane >> lg2;
         const int n_rows = 3 * B;
         constexpr int kTabLoads = 6;
+        const long covoff = c.n_cov ? (long)r * B * T : 0;  // sample covariates: tables per replicate
         double tv[kTabLoads];
         int wbv[kTabLoads];
 #pragma unroll
@@ -108,7 +126,7 @@ void k_guide_wave2(DevArgs c) {
             const int wbc = ok ? wb : 0;
             const int which = (wbc >= B) + (wbc >= 2 * B), bb = wbc - which * B;
             const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
-            tv[q] = tab[(long)bb * T + t0 + (ok ? j : 0)];
+            tv[q] = tab[covoff + (long)bb * T + t0 + (ok ? j : 0)];
             wbv[q] = ok ? wb : -1;
         }
         // wave-uniform per-bin constants of this replicate: lane k * 8 + b loads constant k of bin b
@@ -148,7 +166,7 @@ void k_guide_wave2(DevArgs c) {
             if (wb < n_rows && j < nt) {
                 const int which = (wb >= B) + (wb >= 2 * B), bb = wb - which * B;
                 const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
-                tabs[wb * ntm + j] = tab[(long)bb * T + t0 + j];
+                tabs[wb * ntm + j] = tab[covoff + (long)bb * T + t0 + j];
             }
         }
         {
@@ -186,10 +204,17 @@ void k_guide_wave2(DevArgs c) {
             ms[4 * 64] = cp0;  // needed again after the likelihoods
             ms[5 * 64] = cp1;
             const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
+#if BEAN_GW_DIAG == 1
+            if (true) {
+                pi0 = 0.3 + 1e-3 * cq0;
+                pi1 = 0.7 - 1e-3 * cq1;
+            } else {
+#else
             if (c.pi_in) {
                 pi0 = c.pi_in[rgi * 2];
                 pi1 = c.pi_in[rgi * 2 + 1];
             } else {
+#endif
                 BEAN_STAMP_AT(1);
                 Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
                 const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng);
@@ -256,12 +281,12 @@ void k_guide_wave2(DevArgs c) {
                 const double araw = alpha_raw(w0, MIX ? c_p0[b] : 0.0, w1, tp[b * ntm], sf[b], epsB, ai * c_sm[b]);
                 const double alpha = araw < kEps ? kEps : araw;
                 A0 += alpha;
-                const DD db = lgamma_digamma_diff_inl(alpha, x);
+                const DD db = gw_lgamma_diff(alpha, x);
                 lsum += db.d;
                 dps[b * 64] = db.dp;
             }
             if (lik == 0) BEAN_STAMP_AT(3);
-            const DD d0 = lgamma_digamma_diff_inl(A0, nn);
+            const DD d0 = gw_lgamma_diff(A0, nn);
             nll += d0.d - lsum;
             // loop 2: with ga_b = d0.dp - dpsi_b (0 where alpha_b sits on its floor) and
             // k_b = a0 m_b inv sf_b:  S_Q = sum ga_b k_b Q_b,  t_Q = sum sf_b Q_b,
@@ -270,7 +295,7 @@ void k_guide_wave2(DevArgs c) {
             double S_mu = 0.0, S_y = 0.0, S_0 = 0.0, S_1 = 0.0;
             double t_mu = 0.0, t_y = 0.0, t_0 = 0.0, t_1 = 0.0;
 #pragma unroll 1
-            for (int b = 0; b < B; ++b) {
+            for (int b = 0; b < (BEAN_GW_DIAG == 4 ? 1 : B); ++b) {
                 const double p0 = MIX ? c_p0[b] : 0.0;
                 const double p1 = tp[b * ntm], pmu = tp[(B + b) * ntm], py = tp[(2 * B + b) * ntm];
                 const double sfb = sf[b];
@@ -313,6 +338,9 @@ void k_guide_wave2(DevArgs c) {
                 gpi1 = (g1 - g0) * dpe1_dpi1;
                 row[kW2Gnoise * RG] = (g1 - g0) * dpe1_dl;
             }
+            // digamma of the concentrations, tabulated by k_param (DevArgs::dgq): issued here, used
+            // by the implicit-gradient calls below
+            const double dgS = c.dgq[3 * (long)G + g], dg0 = c.dgq[4 * (long)G + g], dg1 = c.dgq[5 * (long)G + g];
             const double lpi0 = flog(pi0), lpi1 = flog(pi1);
             const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
             if (rgm) {
@@ -344,11 +372,21 @@ void k_guide_wave2(DevArgs c) {
             const double proj = pi0 * gpi0 + pi1 * gpi1;
             const double total = cq0 + cq1;
             double path0 = 0.0, path1 = 0.0;
+            // torch's approximation switches formula on x <= 0.5 / x >= 0.5: a lane takes its SMALLER
+            // component in the first pass and the larger one in the second, so that a pass runs one side's
+            // formulas for the whole wave (in component order every pass ran both sides': 13 % of
+            // the kernel).  Same calls, same arguments, same bits.
+            const int first = pi0 <= pi1 ? 0 : 1;
 #pragma unroll 1
-            for (int a = 0; a < 2; ++a) {
+            for (int pass = 0; pass < 2; ++pass) {
+                const int a = pass ^ first;
                 if (a ? cl1 : cl0) continue;
-                const double v = dirichlet_grad_one(a ? pi1 : pi0, a ? cq1 : cq0, total) *
+#if BEAN_GW_DIAG == 2
+                const double v = (a ? pi1 : pi0) * ((a ? gpi1 : gpi0) - proj);
+#else
+                const double v = dirichlet_grad_one_pre(a ? pi1 : pi0, a ? cq1 : cq0, total, a ? dg1 : dg0, dgS) *
                                  ((a ? gpi1 : gpi0) - proj);
+#endif
                 path0 = a ? path0 : v;
                 path1 = a ? v : path1;
             }
@@ -361,7 +399,7 @@ void k_guide_wave2(DevArgs c) {
     }
     const double tot = wave_sum(loss);
     if (lane == 0) {
-        loss_add(c, ctr.slot, tot);
+        wave_loss_out(c, ctr.slot, wg, tot);
         if (wg == 0) publish_ctr(c, ctr);
     }
     BEAN_STAMP_AT(7);

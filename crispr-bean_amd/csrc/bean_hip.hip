@@ -79,7 +79,9 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
             case 2: case 3: return is_survival(s) ? 0 : T;  // survival models have no sd latent
             case 7: return ((is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) || is_surv_normal(s)) ? G : 0;
             case 4: return is_mixture(s) ? G * A : 0;
-            case 5: case 6: return (is_mixture(s) && (s.flags & BEAN_FLAG_SCALE_BY_ACC) && (s.flags & BEAN_FLAG_FIT_NOISE)) ? G : 0;
+            case 5: case 6:
+                if (s.n_sample_covariates > 0) return (uint64_t)s.n_sample_covariates;  // mu_cov_loc / mu_cov_scale
+                return (is_mixture(s) && (s.flags & BEAN_FLAG_SCALE_BY_ACC) && (s.flags & BEAN_FLAG_FIT_NOISE)) ? G : 0;
         }
         return 0;
     };
@@ -123,7 +125,9 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_EPS_SD_IN: case BEAN_BUF_EPS_SD_OUT: return is_survival(s) ? 0 : 8 * T;
         case BEAN_BUF_PI_IN: case BEAN_BUF_PI_OUT: return is_mixture(s) ? 8 * R * G * A : 0;
         case BEAN_BUF_EPS_NOISE_IN: case BEAN_BUF_EPS_NOISE_OUT:
+            if (s.n_sample_covariates > 0) return 8 * (uint64_t)s.n_sample_covariates;  // eps of mu_cov
             return (s.flags & BEAN_FLAG_SCALE_BY_ACC) ? 8 * G : 0;
+        case BEAN_BUF_REP_BY_COV: return 8 * R * (uint64_t)(s.n_sample_covariates > 0 ? s.n_sample_covariates : 0);
         case BEAN_BUF_LOSS_HIST: return 8;  // minimum; any multiple of 8 accepted
     }
     return 0;
@@ -174,6 +178,7 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.loss_acc = c->loss_acc;
     d.time = (const double*)P(BEAN_BUF_TIMEPOINTS);
     d.negctrl = (const uint8_t*)P(BEAN_BUF_NEGCTRL_MASK);
+    d.rbc = (const double*)P(BEAN_BUF_REP_BY_COV);
     if (P(BEAN_BUF_XCHG_GSUM)) d.gsum = (double*)P(BEAN_BUF_XCHG_GSUM);
     else d.gsum = c->gsum_ws;
     if (P(BEAN_BUF_XCHG_SQ)) d.sq = (double*)P(BEAN_BUF_XCHG_SQ);
@@ -220,6 +225,10 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (s->family == BEAN_FAMILY_CONTROL_NORMAL && s->n_targets != 1)
         return fail("bean_hip_create: ControlNormal requires n_targets == 1");
     if (!(s->lrd > 0.0) || !(s->initial_lr > 0.0)) return fail("bean_hip_create: lr and lrd must be > 0");
+    if (s->n_sample_covariates < 0 || s->n_sample_covariates > 64)
+        return fail("bean_hip_create: n_sample_covariates must be in [0, 64]");
+    if (s->n_sample_covariates > 0 && !(s->family == BEAN_FAMILY_NORMAL && s->selection == BEAN_SELECTION_SORTING))
+        return fail("bean_hip_create: sample covariates belong to the sorting NormalModel only (bean/model/model.py:73-91)");
     if (s->guide_offset < 0 || s->target_offset < 0 ||
         (s->n_guides_total > 0 && s->guide_offset + s->n_guides > s->n_guides_total))
         return fail("bean_hip_create: shard offsets outside the whole screen");
@@ -264,7 +273,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
 
     const uint64_t B = d.B, T = d.T, G = d.G;
     const uint64_t A1 = is_tiling(*s) ? (uint64_t)(d.A - 1) : 0;
-    const uint64_t n_tab = is_tiling(*s) ? A1 * G : T;  // table columns: allele slots or targets
+    const uint64_t n_cov = (uint64_t)s->n_sample_covariates;
+    // table columns: allele slots or targets (per replicate with sample covariates)
+    const uint64_t n_tab = is_tiling(*s) ? A1 * G : T * (n_cov ? (uint64_t)s->n_reps : 1);
     const uint64_t n_part = is_tiling(*s) ? (uint64_t)kTNumPart : (uint64_t)kNumPart;
     const bool surv_mix = is_survival(*s) && s->family == BEAN_FAMILY_MIXTURE_NORMAL;
     const bool surv_tiling = is_survival(*s) && is_tiling(*s);
@@ -283,6 +294,12 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const bool use_split = split_ok && !c->fused_guide;
     c->wave_guide = c->wave_guide && split_ok;
     c->wave2 = c->wave2 && c->wave_guide;
+    if (s->n_sample_covariates > 0 && (!c->wave2 || s->n_guides_total > s->n_guides)) {
+        delete c;
+        return fail("bean_hip_create: sample covariates need the default guide kernel (k_guide_wave2) and an unsharded "
+                    "screen: mu_cov is shared by every guide");
+    }
+    d.n_cov = s->n_sample_covariates;
     c->surv_wave = c->surv_wave && is_survival(*s) && !is_tiling(*s);
     d.rows_v2 = (c->wave2 || c->surv_wave) ? 1 : 0;
     c->tiling_wave = c->tiling_wave && is_tiling(*s);
@@ -295,8 +312,12 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
 #else
     const uint64_t n_dbg = 0;
 #endif
+    // per-wave loss parts of the wave-form guide kernels (1-D grid of padded tiles x replicates)
+    const uint64_t n_lpart = (c->wave2 || c->surv_wave) ? ((G + 63) / 64 + 7) / 8 * 8 * Rr : 0;
+    const uint64_t n_dgq = ((c->wave2 || c->surv_wave) && s->family == BEAN_FAMILY_MIXTURE_NORMAL) ? 6 * G : 0;
+    const uint64_t n_dgq_t = c->tiling_wave ? (uint64_t)(kAMax + 1) * G : 0;
     const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
-                           n_split + n_dbg + n_trow;
+                           n_split + n_dbg + n_trow + 3 * n_lpart + n_dgq + n_dgq_t + 2 * n_cov + 2 * Rr;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
     if (e != hipSuccess) {
@@ -369,8 +390,25 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         d.sq = w; w += Rr;
         c->sq_ws = d.sq;
     }
-    d.ctrA = (StepCtr*)w; w += 2;
-    d.ctrB = (StepCtr*)w; w += 2;
+    if (n_cov) {
+        d.cov_mu = w; w += n_cov;
+        d.cov_eps = w; w += n_cov;
+        d.cov_shift = w; w += Rr;
+        d.cov_sum = w; w += Rr;
+    }
+    if (n_dgq) {
+        d.dgq = w; w += n_dgq;
+    }
+    if (n_dgq_t) {
+        d.dgq_t = w; w += n_dgq_t;
+    }
+    if (n_lpart) {
+        d.lpart = (long long*)w; w += 3 * n_lpart;
+        d.n_lpart = (int)n_lpart;
+    }
+    static_assert(sizeof(StepCtr) == 24, "two StepCtr take 6 of the 8 spare workspace doubles");
+    d.ctrA = (StepCtr*)w; w += 3;
+    d.ctrB = (StepCtr*)w; w += 3;
     *out = c;
     return 0;
 }
@@ -442,6 +480,7 @@ static int check_bound(bean_hip_ctx* c, bool need_grads, bool need_moments) {
     if (s.flags & BEAN_FLAG_USE_BCMATCH) { REQ(BEAN_BUF_X_BC); REQ(BEAN_BUF_SIZE_FACTOR_BC); REQ(BEAN_BUF_A0_BC); }
     if (is_mixture(s)) { REQ(BEAN_BUF_ALLELE_CTRL); REQ(BEAN_BUF_PI_A0); }
     if (s.flags & BEAN_FLAG_SCALE_BY_ACC) REQ(BEAN_BUF_ACCESSIBILITY);
+    if (s.n_sample_covariates > 0) REQ(BEAN_BUF_REP_BY_COV);
     for (int i = 0; i < 8; ++i) {
         if (expected_bytes(s, BEAN_BUF_P_MU_LOC + i) == 0) continue;
         REQ(BEAN_BUF_P_MU_LOC + i);
@@ -494,6 +533,10 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
     grid_param(c, ntb, nb);
     DevArgs d = c->d;
     d.tgrad = tgrad;
+    if (d.n_cov) {  // sample covariates: their own small step runs first (it owns the replicates' shifts)
+        if (FINISH) hipLaunchKernelGGL(k_cov_sum, dim3(d.R), dim3(1024), 0, stream, d);
+        hipLaunchKernelGGL((k_cov_step<FINISH, ADAM, PREP>), dim3(1), dim3(64), 0, stream, d);
+    }
     if (c->profile && c->profile_param && FINISH && PREP && c->ev.size() < 8192) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         (void)hipEventCreate(&e0);

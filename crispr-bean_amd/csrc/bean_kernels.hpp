@@ -93,6 +93,22 @@ struct DevArgs {
     // order-independent loss accumulators (loss_add): kLossSub lines of kLossWords int64 words per
     // loss_hist slot, and one line for the data-only constant
     long long *loss_acc, *const_acc;
+    // (6, G): lgamma / digamma of the guide-side Dirichlet concentrations c_q of the CURRENT alpha_pi:
+    // rows lgamma(c_q0 + c_q1), lgamma(c_q0), lgamma(c_q1), then the three digammas.  Written by k_param
+    // PREP (after the update), read by the next guide kernel (implicit-gradient calls) and by the next
+    // k_param FINISH instead of being recomputed there.  Null: every user computes its own.
+    // sorting NormalModel with sample covariates (model.py:73-91, 771-783): mu_cov ~ N(0, 1) per covariate,
+    // guide N(mu_cov_loc, mu_cov_scale) in parameter slots 5 / 6; replicate r's means are shifted by
+    // rep_by_cov[r, 0] * mu_cov[0] (only the first column enters the likelihood there), so the Phi tables
+    // are per (replicate, target): (R, B, T)
+    int n_cov;
+    const double* rbc;                 // (R, n_cov) design matrix
+    double *cov_mu, *cov_eps;          // (n_cov) current draw
+    double *cov_shift, *cov_sum;       // (R) shift of replicate r; sum_g of its d nll / d mu rows
+    double* dgq;
+    double* dgq_t;                     // tiling: (kAMax + 1, G) digamma(c_q[a]) rows and digamma(sum c_q), same contract
+    long long* lpart;                  // (n_lpart, 3) per-wave loss parts of the wave-form guide kernels, or null
+    int n_lpart;
     int rows_v2;                       // wrow holds the five rows of k_guide_wave2 (bean_guide_v2.hpp)
     // workspace
     double *tabP, *tabPmu, *tabPy;     // (B, T)
@@ -205,7 +221,35 @@ __device__ __forceinline__ void loss_add(const DevArgs& c, unsigned long long sl
     fixed_add(c.loss_acc + ((long)slot * kLossSub + sub) * kLossWords, v);
 }
 
+// A wave-form guide kernel leaves its part of the loss as three int64 words (the split of fixed_add)
+// in lpart[wave]; the k_param launch that follows adds them up (integers: any grouping gives the same
+// sum) and issues two atomics per BLOCK instead of two per wave - the ~4000 device-scope atomics of a
+// guide launch cost 3.6 us of its 48.
+__device__ __forceinline__ void wave_loss_out(const DevArgs& c, unsigned long long slot, long wave, double v) {
+    if (!c.lpart) {
+        loss_add(c, slot, v);
+        return;
+    }
+    long long* o = c.lpart + 3 * wave;
+    if (!(fabs(v) < 4.0e15)) {
+        o[0] = 0;
+        o[1] = 0;
+        o[2] = 1;
+        return;
+    }
+    const double hi = rint(v * 1024.0);
+    o[0] = (long long)hi;
+    o[1] = (long long)rint((v - hi * (1.0 / 1024.0)) * 1099511627776.0);
+    o[2] = 0;
+}
+
 // ---------------------------------------------------------------- reductions
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -414,11 +458,25 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_targe
         c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
         if (c.eps_noise_out) c.eps_noise_out[g] = eps;
     }
+    if (PREP && c.dgq_t) {
+        // digamma of the guide-side concentrations of the (updated) alpha_pi for the next guide kernel's
+        // A implicit-gradient calls per (replicate, guide), which otherwise each evaluate two digammas
+        const bool live = in && a < A;
+        const bool am = live && c.amask[(long)g * A + a] != 0;
+        const double alpha = live ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
+        const double S = allele_group_sum(alpha);
+        const double pa0 = in ? c.pi_a0[g] : 1.0;
+        double cq = alpha * frcp(in ? S : 1.0) * pa0;
+        if (c.survival && live && cq < 1e-5) cq = 1e-5;
+        const double tot = allele_group_sum(live ? cq : 0.0);
+        if (live) c.dgq_t[(long)a * c.G + g] = digamma(cq);
+        if (lead) c.dgq_t[(long)kAMax * c.G + g] = digamma(tot);
+    }
 }
 
 // One entry of the per-target Phi tables (a2): P[b, t] = Phi(u_hi) - Phi(u_lo) and its
 // derivatives in mu_t and y_t = log sd_t, for the draw (mu, y) of target t.
-__device__ __forceinline__ void write_phi_entry(const DevArgs& c, int t, int b, double mu, double y) {
+__device__ __forceinline__ void write_phi_entry(const DevArgs& c, int t, int b, double mu, double y, long off = 0) {
     // NormalModel uses sqrt(sd) as the scale (model.py:92-98)
     const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
     const double dsig_dy = c.family == kNormal ? 0.5 * sigma : sigma;
@@ -437,7 +495,7 @@ __device__ __forceinline__ void write_phi_entry(const DevArgs& c, int t, int b, 
         fl = norm_pdf(u);
         ufl = u * fl;
     }
-    const long o = (long)b * c.T + t;
+    const long o = off + (long)b * c.T + t;
     c.tabP[o] = ch - cl;
     c.tabPmu[o] = -(fh - fl) * inv;
     c.tabPy[o] = -(ufh - ufl) * inv * dsig_dy;
@@ -766,7 +824,13 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                     scratch[1] = tab_y;
                 }
                 __syncthreads();
-                if ((int)threadIdx.x < c.B) write_phi_entry(c, t, threadIdx.x, scratch[0], scratch[1]);
+                if ((int)threadIdx.x < c.B) {
+                    if (c.n_cov)
+                        for (int r = 0; r < c.R; ++r)
+                            write_phi_entry(c, t, threadIdx.x, scratch[0] + c.cov_shift[r], scratch[1], (long)r * c.B * c.T);
+                    else
+                        write_phi_entry(c, t, threadIdx.x, scratch[0], scratch[1]);
+                }
                 __syncthreads();
             } else {
                 // one lane per bin EDGE: even lane = upper edge, odd lane = lower edge of bin e >> 1, so
@@ -785,23 +849,29 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
                 const double dsig_dy = c.family == kNormal ? 0.5 * sigma : sigma;
                 const double inv = 1.0 / sigma;
-                for (int e0 = 0; e0 < 2 * c.B; e0 += kLanesPerTarget) {
-                    const int e = e0 + j, b = e >> 1;
-                    const bool upper = (e & 1) == 0, live = t < c.T && b < c.B;
-                    const double z = live ? (upper ? c.z_hi[b] : c.z_lo[b]) : 0.0;
-                    double cdf = upper ? 1.0 : 0.0, pdf = 0.0, upd = 0.0;
-                    if (live && !isinf(z)) {
-                        const double u = (z - mu) * inv;
-                        cdf = norm_cdf(u);
-                        pdf = norm_pdf(u);
-                        upd = u * pdf;
-                    }
-                    const double cl = __shfl_xor(cdf, 1, 64), fl = __shfl_xor(pdf, 1, 64), ufl = __shfl_xor(upd, 1, 64);
-                    if (live && upper) {
-                        const long o = (long)b * c.T + t;
-                        c.tabP[o] = cdf - cl;
-                        c.tabPmu[o] = -(pdf - fl) * inv;
-                        c.tabPy[o] = -(upd - ufl) * inv * dsig_dy;
+                const int n_tab = c.n_cov ? c.R : 1;  // sample covariates: one table per replicate
+                for (int rt = 0; rt < n_tab; ++rt) {
+                    const double mu_r = c.n_cov ? mu + c.cov_shift[rt] : mu;
+                    const long off = (long)rt * c.B * c.T;
+                    for (int e0 = 0; e0 < 2 * c.B; e0 += kLanesPerTarget) {
+                        const int e = e0 + j, b = e >> 1;
+                        const bool upper = (e & 1) == 0, live = t < c.T && b < c.B;
+                        const double z = live ? (upper ? c.z_hi[b] : c.z_lo[b]) : 0.0;
+                        double cdf = upper ? 1.0 : 0.0, pdf = 0.0, upd = 0.0;
+                        if (live && !isinf(z)) {
+                            const double u = (z - mu_r) * inv;
+                            cdf = norm_cdf(u);
+                            pdf = norm_pdf(u);
+                            upd = u * pdf;
+                        }
+                        const double cl = __shfl_xor(cdf, 1, 64), fl = __shfl_xor(pdf, 1, 64),
+                                     ufl = __shfl_xor(upd, 1, 64);
+                        if (live && upper) {
+                            const long o = off + (long)b * c.T + t;
+                            c.tabP[o] = cdf - cl;
+                            c.tabPmu[o] = -(pdf - fl) * inv;
+                            c.tabPy[o] = -(upd - ufl) * inv * dsig_dy;
+                        }
                     }
                 }
             }
@@ -854,14 +924,32 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 const bool cl[2] = {cp[0] < 1e-5, cp[1] < 1e-5};
                 const double cq[2] = {cl[0] ? 1e-5 : cp[0], cl[1] ? 1e-5 : cp[1]};
                 double lgS_p, dgS_p, lg_p[2], dg_p[2];
-                lgamma_digamma(cp[0] + cp[1], lgS_p, dgS_p);
-                lgamma_digamma(cp[0], lg_p[0], dg_p[0]);
-                lgamma_digamma(cp[1], lg_p[1], dg_p[1]);
-                double lgS_q = lgS_p, dgS_q = dgS_p, lg_q[2] = {lg_p[0], lg_p[1]}, dg_q[2] = {dg_p[0], dg_p[1]};
-                if (cl[0] || cl[1]) {
-                    lgamma_digamma(cq[0] + cq[1], lgS_q, dgS_q);
-                    lgamma_digamma(cq[0], lg_q[0], dg_q[0]);
-                    lgamma_digamma(cq[1], lg_q[1], dg_q[1]);
+                double lgS_q, dgS_q, lg_q[2], dg_q[2];
+                if (c.dgq) {
+                    // the guide side (c_q) was tabulated by the previous PREP for this alpha_pi
+                    const long Gl = c.G;
+                    lgS_q = c.dgq[g];
+                    lg_q[0] = c.dgq[Gl + g];
+                    lg_q[1] = c.dgq[2 * Gl + g];
+                    dgS_q = c.dgq[3 * Gl + g];
+                    dg_q[0] = c.dgq[4 * Gl + g];
+                    dg_q[1] = c.dgq[5 * Gl + g];
+                    lgS_p = lgS_q, dgS_p = dgS_q, lg_p[0] = lg_q[0], lg_p[1] = lg_q[1], dg_p[0] = dg_q[0], dg_p[1] = dg_q[1];
+                    if (cl[0] || cl[1]) {  // model side (c_p, unclamped) differs
+                        lgamma_digamma(cp[0] + cp[1], lgS_p, dgS_p);
+                        lgamma_digamma(cp[0], lg_p[0], dg_p[0]);
+                        lgamma_digamma(cp[1], lg_p[1], dg_p[1]);
+                    }
+                } else {
+                    lgamma_digamma(cp[0] + cp[1], lgS_p, dgS_p);
+                    lgamma_digamma(cp[0], lg_p[0], dg_p[0]);
+                    lgamma_digamma(cp[1], lg_p[1], dg_p[1]);
+                    lgS_q = lgS_p, dgS_q = dgS_p, lg_q[0] = lg_p[0], lg_q[1] = lg_p[1], dg_q[0] = dg_p[0], dg_q[1] = dg_p[1];
+                    if (cl[0] || cl[1]) {
+                        lgamma_digamma(cq[0] + cq[1], lgS_q, dgS_q);
+                        lgamma_digamma(cq[0], lg_q[0], dg_q[0]);
+                        lgamma_digamma(cq[1], lg_q[1], dg_q[1]);
+                    }
                 }
                 // per-replicate rows of the wave form: independent loads, four replicates in flight
                 double Lp_[2] = {0.0, 0.0}, Lq_[2] = {0.0, 0.0}, path_[2] = {0.0, 0.0}, nrg = 0.0;
@@ -961,6 +1049,25 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
                 if (c.eps_noise_out) c.eps_noise_out[g] = eps;
             }
+            if (PREP && c.dgq) {
+                // lgamma / digamma of the guide-side concentrations of the (updated) alpha_pi, for
+                // the next guide kernel and the next FINISH
+                const double al0 = (double)expf(c.p[4][2 * g]), al1 = (double)expf(c.p[4][2 * g + 1]);
+                const double s = al0 + al1, pa0 = c.pi_a0[g];
+                const double c0 = al0 / s * pa0, c1 = al1 / s * pa0;  // as FINISH forms c_p
+                const double q0 = c0 < 1e-5 ? 1e-5 : c0, q1 = c1 < 1e-5 ? 1e-5 : c1;
+                double lgS, dgS, lg0, dg0, lg1, dg1;
+                lgamma_digamma(q0 + q1, lgS, dgS);
+                lgamma_digamma(q0, lg0, dg0);
+                lgamma_digamma(q1, lg1, dg1);
+                const long Gl = c.G;
+                c.dgq[g] = lgS;
+                c.dgq[Gl + g] = lg0;
+                c.dgq[2 * Gl + g] = lg1;
+                c.dgq[3 * Gl + g] = dgS;
+                c.dgq[4 * Gl + g] = dg0;
+                c.dgq[5 * Gl + g] = dg1;
+            }
         }
     }
     if (c.surv_q0lik && (int)blockIdx.x >= n_target_blocks) {
@@ -1054,6 +1161,38 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         const double tot = block_sum(loss_fin, scratch);
         if (threadIdx.x == 0) {
             loss_add(c, ctr.slot, tot);
+        }
+        // the guide kernel's per-wave loss parts (wave_loss_out): the first blocks take 256 each
+        if (c.lpart && (long)blockIdx.x * blockDim.x < c.n_lpart) {
+            __shared__ long long isum[3][16];
+            long long ph = 0, pl = 0, pb = 0;
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < c.n_lpart; i += (long)gridDim.x * blockDim.x) {
+                ph += c.lpart[3 * i];
+                pl += c.lpart[3 * i + 1];
+                pb += c.lpart[3 * i + 2];
+            }
+            ph = wave_sum_i64(ph);
+            pl = wave_sum_i64(pl);
+            pb = wave_sum_i64(pb);
+            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+            if (lane == 0) {
+                isum[0][w] = ph;
+                isum[1][w] = pl;
+                isum[2][w] = pb;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                long long a = 0, b = 0, d = 0;
+                for (int i = 0; i < nw; ++i) {
+                    a += isum[0][i];
+                    b += isum[1][i];
+                    d += isum[2][i];
+                }
+                long long* acc = c.loss_acc + ((long)ctr.slot * kLossSub + (blockIdx.x & (kLossSub - 1))) * kLossWords;
+                atomicAdd((unsigned long long*)acc, (unsigned long long)a);
+                atomicAdd((unsigned long long*)acc + 1, (unsigned long long)b);
+                if (d) atomicAdd((unsigned long long*)acc + 2, (unsigned long long)d);
+            }
         }
     }
     (void)loss_prep;
@@ -2736,6 +2875,7 @@ void k_guide_tiling_wave(DevArgs c) {
                         }
                 }
             }
+            const double dgS_t = c.dgq_t[(long)kAMax * G + g];  // digamma(sum c_q), tabulated by k_param
             // model-side floored concentration c_p (model.py:640-651) for - d log p / d pi
             const double rSe = frcp(Ssum + kEps) * pa0;
             double proj = 0.0;
@@ -2753,7 +2893,9 @@ void k_guide_tiling_wave(DevArgs c) {
             }
 #pragma unroll
             for (int a = 0; a < kAMax; ++a)
-                if (a < A) row[(long)(kTPath + a) * RG] = dirichlet_grad_one(pi[a], cq[a], total) * (gpi[a] - proj);
+                if (a < A)
+                    row[(long)(kTPath + a) * RG] =
+                        dirichlet_grad_one_pre(pi[a], cq[a], total, c.dgq_t[(long)a * G + g], dgS_t) * (gpi[a] - proj);
             row[(long)kTGnoise * RG] = gnoise;
             row[(long)kTNrg * RG] = 1.0;
             loss = nll;
@@ -2859,6 +3001,68 @@ __global__ __launch_bounds__(256) void k_loss_finalize(DevArgs c, unsigned long 
         return;
     }
     c.loss_hist[i] = fixed_value(c.loss_acc + (long)i * kLossSub * kLossWords, kLossSub) + fixed_value(c.const_acc, 1);
+}
+
+// ---- sample covariates of the sorting NormalModel
+// cov_sum[r] = sum_g d nll / d mu of replicate r's rows (fixed order: strided partials, block tree)
+__global__ __launch_bounds__(1024) void k_cov_sum(DevArgs c) {
+    __shared__ double scratch[16];
+    const int r = blockIdx.x;
+    double v = 0.0;
+    for (int g = threadIdx.x; g < c.G; g += blockDim.x) v += c.wrow[((long)kPGmu * c.R + r) * c.G + g];
+    const double tot = block_sum(v, scratch);
+    if (threadIdx.x == 0) c.cov_sum[r] = tot;
+}
+
+// One block: prior / entropy terms, gradients and ClippedAdam of mu_cov_loc / mu_cov_scale (FINISH),
+// the draw of the next step and the replicates' shifts (PREP).  Runs before the k_param launch with
+// the same template arguments; reads the step counter the same way.
+template <bool FINISH, bool ADAM, bool PREP>
+__global__ __launch_bounds__(64) void k_cov_step(DevArgs c) {
+    const StepCtr ctr = *c.ctrA;
+    const unsigned long long s_prep = FINISH ? ctr.step + 1 : ctr.step;
+    AdamCoef ak;
+    ak.step_size = ctr.step_size;
+    ak.clip = (float)c.clip;
+    double loss = 0.0;
+    for (int i = threadIdx.x; i < c.n_cov; i += blockDim.x) {
+        float loc = c.p[5][i], su = c.p[6][i];
+        if (FINISH) {
+            const double m = c.cov_mu[i], eps = c.cov_eps[i], sc = exp((double)su);
+            double G = 0.0;
+            if (i == 0)  // `(data.rep_by_cov * mu_cov)[:, 0]`: only the first covariate shifts the means
+                for (int r = 0; r < c.R; ++r) G += c.rbc[(long)r * c.n_cov] * c.cov_sum[r];
+            // - log p (Normal(0, 1)) + log q (Normal(loc, scale))
+            loss += 0.5 * m * m + kHalfLog2PiC + (-0.5 * eps * eps - (double)su - kHalfLog2PiC);
+            const double Gm = G + m;
+            emit_grad<ADAM>(c, 5, i, Gm, ak);
+            emit_grad<ADAM>(c, 6, i, Gm * eps * sc - 1.0, ak);
+            if (ADAM) {
+                loc = c.p[5][i];
+                su = c.p[6][i];
+            }
+        }
+        if (PREP) {
+            double eps;
+            if (c.eps_noise_in) {
+                eps = c.eps_noise_in[i];
+            } else {
+                rocrand_state_philox4x32_10 st;
+                rocrand_init(c.seed, ((unsigned long long)kSiteCov << 48) + (unsigned long long)i, s_prep * 4ull, &st);
+                eps = (double)rocrand_normal(&st);
+            }
+            const double m = (double)loc + eps * exp((double)su);
+            c.cov_eps[i] = eps;
+            c.cov_mu[i] = m;
+            if (c.eps_noise_out) c.eps_noise_out[i] = eps;
+            if (i == 0)
+                for (int r = 0; r < c.R; ++r) c.cov_shift[r] = c.rbc[(long)r * c.n_cov] * m;
+        }
+    }
+    if (FINISH) {
+        const double tot = wave_sum(loss);
+        if (threadIdx.x == 0) loss_add(c, ctr.slot, tot);
+    }
 }
 
 __global__ void k_set_step(StepCtr* a, StepCtr* b, unsigned long long step, unsigned long long slot) {

@@ -204,8 +204,13 @@ __device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
 // x^y for x > 0 through exp(y log x) (used only on rarely taken paths)
 __device__ __forceinline__ double fpow(double x, double y) { return exp(y * flog(x)); }
 
-__device__ inline double beta_grad_alpha_small(double x, double alpha, double beta) {
-    const double factor = digamma(alpha) - digamma(alpha + beta) - flog(x);
+// PRE: digamma(alpha) and digamma(alpha + beta) are supplied by the caller (they depend on the
+// concentrations only, which k_param has already evaluated for the guide: see DevArgs::dgq) instead
+// of being evaluated here - two of them per call were ~11 % of k_guide_wave2's instructions.
+template <bool PRE>
+__device__ __forceinline__ double beta_grad_alpha_small_t(double x, double alpha, double beta, double dg_a,
+                                                          double dg_ab) {
+    const double factor = (PRE ? dg_a - dg_ab : digamma(alpha) - digamma(alpha + beta)) - flog(x);
     const double ra = frcp(alpha);
     double numer = 1.0;
     double series = numer * ra * (factor + ra);
@@ -219,8 +224,10 @@ __device__ inline double beta_grad_alpha_small(double x, double alpha, double be
     return isnan(result) ? 0.0 : result;
 }
 
-__device__ inline double beta_grad_beta_small(double x, double alpha, double beta) {
-    const double factor = digamma(alpha + beta) - digamma(beta);
+template <bool PRE>
+__device__ __forceinline__ double beta_grad_beta_small_t(double x, double alpha, double beta, double dg_ab,
+                                                         double dg_b) {
+    const double factor = PRE ? dg_ab - dg_b : digamma(alpha + beta) - digamma(beta);
     double numer = 1.0, betas = 1.0, dbetas = 0.0, series = factor * frcp(alpha);
     for (int i = 1; i <= 8; ++i) {
         const double ci = (double)i;
@@ -293,11 +300,13 @@ __device__ __constant__ const double kDirGradC[2][3][3][4] = {
       {-0.0003477407336, 6.959756487e-05, 1.097287507e-05, -1.650964693e-06}}},
 };
 
-__device__ __forceinline__ double dirichlet_grad_one_inl(double x, double alpha, double total) {
+template <bool PRE>
+__device__ __forceinline__ double dirichlet_grad_one_t(double x, double alpha, double total, double dg_alpha,
+                                                       double dg_total) {
     const double beta = total - alpha;
     const double boundary = total * x * (1.0 - x);
-    if (x <= 0.5 && boundary < 2.5) return beta_grad_alpha_small(x, alpha, beta);
-    if (x >= 0.5 && boundary < 0.75) return -beta_grad_beta_small(1.0 - x, beta, alpha);
+    if (x <= 0.5 && boundary < 2.5) return beta_grad_alpha_small_t<PRE>(x, alpha, beta, dg_alpha, dg_total);
+    if (x >= 0.5 && boundary < 0.75) return -beta_grad_beta_small_t<PRE>(1.0 - x, beta, alpha, dg_total, dg_alpha);
     if (alpha > 6.0 && beta > 6.0) return beta_grad_alpha_mid(x, alpha, beta);
     // rational correction to an analytic approximation (kDirGradC below)
     const auto& c = kDirGradC;
@@ -316,12 +325,21 @@ __device__ __forceinline__ double dirichlet_grad_one_inl(double x, double alpha,
             q += ua * (c[1][i][j][0] + b * (c[1][i][j][1] + b * (c[1][i][j][2] + b * c[1][i][j][3])));
         }
     }
-    const double approx = x * (digamma(total) - digamma(alpha)) * frcp(beta);
+    const double dd = PRE ? dg_total - dg_alpha : digamma(total) - digamma(alpha);
+    const double approx = x * dd * frcp(beta);
     return p * approx * frcp(q);
 }
-// out-of-line copy for the kernels that call it from several sites
+__device__ __forceinline__ double dirichlet_grad_one_inl(double x, double alpha, double total) {
+    return dirichlet_grad_one_t<false>(x, alpha, total, 0.0, 0.0);
+}
+// out-of-line copies for the kernels that call them from several sites
 __device__ BEAN_NOINLINE double dirichlet_grad_one(double x, double alpha, double total) {
     return dirichlet_grad_one_inl(x, alpha, total);
+}
+// with digamma(alpha) and digamma(total) supplied by the caller
+__device__ BEAN_NOINLINE double dirichlet_grad_one_pre(double x, double alpha, double total, double dg_alpha,
+                                                       double dg_total) {
+    return dirichlet_grad_one_t<true>(x, alpha, total, dg_alpha, dg_total);
 }
 
 // ---------------------------------------------------------------------------
@@ -329,7 +347,7 @@ __device__ BEAN_NOINLINE double dirichlet_grad_one(double x, double alpha, doubl
 // (seed, site, element) through the subsequence and by the SVI step through the
 // offset, so draws do not depend on grid shape or on the number of GPUs.
 // ---------------------------------------------------------------------------
-enum RngSite : unsigned long long { kSiteTarget = 1, kSitePi = 2, kSiteNoise = 3, kSiteAux = 4, kSiteQ0 = 5 };
+enum RngSite : unsigned long long { kSiteTarget = 1, kSitePi = 2, kSiteNoise = 3, kSiteAux = 4, kSiteQ0 = 5, kSiteCov = 6 };
 
 // Stateless view of one Philox subsequence: draw k is counter (offset/4 + k), so
 // the generator lives in 7 registers and never touches memory.

@@ -258,6 +258,9 @@ void k_guide_survival_wave(DevArgs c) {
                 gpi1 = (g1 - g0) * dpe1_dpi1;
                 row[kW2Gnoise * RG] = (g1 - g0) * dpe1_dl;
             }
+            // digamma of the concentrations, tabulated by k_param (DevArgs::dgq): issued here, used
+            // by the implicit-gradient calls below
+            const double dgS = c.dgq[3 * (long)G + g], dg0 = c.dgq[4 * (long)G + g], dg1 = c.dgq[5 * (long)G + g];
             const double lpi0 = flog(pi0), lpi1 = flog(pi1);
             const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
             if (rgm) {
@@ -289,10 +292,12 @@ void k_guide_survival_wave(DevArgs c) {
             const double proj = pi0 * gpi0 + pi1 * gpi1;
             const double total = cq0 + cq1;
             double path0 = 0.0, path1 = 0.0;
+            const int first = pi0 <= pi1 ? 0 : 1;  // smaller component first: see k_guide_wave2
 #pragma unroll 1
-            for (int a = 0; a < 2; ++a) {
+            for (int pass = 0; pass < 2; ++pass) {
+                const int a = pass ^ first;
                 if (a ? cl1 : cl0) continue;
-                const double v = dirichlet_grad_one(a ? pi1 : pi0, a ? cq1 : cq0, total) *
+                const double v = dirichlet_grad_one_pre(a ? pi1 : pi0, a ? cq1 : cq0, total, a ? dg1 : dg0, dgS) *
                                  ((a ? gpi1 : gpi0) - proj);
                 path0 = a ? path0 : v;
                 path1 = a ? v : path1;
@@ -316,7 +321,7 @@ void k_guide_survival_wave(DevArgs c) {
     }
     const double tot = wave_sum(loss);
     if (lane == 0) {
-        loss_add(c, ctr.slot, tot);
+        wave_loss_out(c, ctr.slot, wg, tot);
         if (wg == 0) publish_ctr(c, ctr);
     }
 }

@@ -20,7 +20,7 @@ import torch
 from . import _lib
 
 PI_NOISE_SD = 0.655  # bean/model/utils.py:133
-POSITIVE = ("mu_scale", "sd_scale", "alpha_pi", "noise_scale", "q0", "initial_abundance")
+POSITIVE = ("mu_scale", "sd_scale", "alpha_pi", "noise_scale", "q0", "initial_abundance", "mu_cov_scale")
 
 
 def _quantile_edges(upper: torch.Tensor, lower: torch.Tensor):
@@ -133,6 +133,20 @@ class HipSVI:
             flags |= _lib.FLAG_DUMP_PI
         if not loss_owner:
             flags |= _lib.FLAG_NOT_LOSS_OWNER
+        # sample covariates (uns["sample_covariates"], data_class.py:75-92): only the sorting NormalModel
+        # has the mu_cov site (model.py:73-91, 771-783); with any other family the reference fits with
+        # the regrouped replicates and then fails in write_result_table (readwrite.py:88-90)
+        covs = getattr(data, "sample_covariates", None)
+        self.n_cov = 0
+        if covs is not None:
+            if not (family == "Normal" and not survival):
+                raise ValueError(
+                    "this screen carries uns['sample_covariates']: only the sorting Normal model (--uniform-edit) "
+                    f"models them (bean/model/model.py:73-91); the {family} family cannot write its result table "
+                    "in the reference (readwrite.py:88-90) and is refused here")
+            if n_guides_total and int(n_guides_total) != G:
+                raise NotImplementedError("sample covariates (mu_cov is shared by all guides) with a guide-sharded fit")
+            self.n_cov = int(data.n_sample_covariates)
         self.prior_params = prior_params
         if prior_params is not None and ("mu_loc" in prior_params or "mu_scale" in prior_params):
             flags |= _lib.FLAG_PRIOR_NORMAL_MU
@@ -151,6 +165,7 @@ class HipSVI:
             sd_prior_scale=1.0 if family == "ControlNormal" else float(np.float32(sd_scale)),
             initial_lr=self.initial_lr, lrd=self.lrd, clip_norm=10.0,
             negctrl_loc=float(mu_negctrl[0]), negctrl_scale=float(mu_negctrl[1]),
+            n_sample_covariates=self.n_cov,
         )
         self._shape = shape
         handle = ctypes.c_void_p()
@@ -216,6 +231,8 @@ class HipSVI:
         if mixture:
             self._bind("ALLELE_CTRL", f32(data.allele_counts_control))
             self._bind("PI_A0", f64(data.pi_a0))
+        if self.n_cov:
+            self._bind("REP_BY_COV", f64(torch.as_tensor(data.rep_by_cov).reshape(R, self.n_cov)))
         if acc:
             if data.guide_accessibility is None:
                 raise ValueError("scale_by_accessibility needs data.guide_accessibility")
@@ -262,6 +279,9 @@ class HipSVI:
         if self.fit_noise:
             init["noise_loc"] = torch.zeros(G)
             init["noise_scale"] = torch.full((G,), float(np.log(PI_NOISE_SD)))
+        if self.n_cov:  # mu_cov_loc = 0, mu_cov_scale = 1 (model.py:773-780)
+            init["mu_cov_loc"] = torch.zeros(self.n_cov)
+            init["mu_cov_scale"] = torch.zeros(self.n_cov)
         self.unconstrained: Dict[str, torch.Tensor] = {}
         self.grads: Dict[str, torch.Tensor] = {}
         self._m: Dict[str, torch.Tensor] = {}
@@ -269,6 +289,9 @@ class HipSVI:
         order = list(_lib.PARAM_ORDER)
         if surv_normal:
             order[order.index("q0")] = "initial_abundance"  # same slot: a positive (G,) Dirichlet concentration
+        if self.n_cov:  # the noise slots are free in the Normal family (include/bean_hip.h)
+            order[order.index("noise_loc")] = "mu_cov_loc"
+            order[order.index("noise_scale")] = "mu_cov_scale"
         for i, name in enumerate(order):
             if name not in init:
                 continue
@@ -306,6 +329,9 @@ class HipSVI:
             if acc:
                 self._noise_out["eps_noise"] = torch.zeros(G, dtype=torch.float64, device=dev)
                 self._bind("EPS_NOISE_OUT", self._noise_out["eps_noise"])
+            if self.n_cov:
+                self._noise_out["eps_cov"] = torch.zeros(self.n_cov, dtype=torch.float64, device=dev)
+                self._bind("EPS_NOISE_OUT", self._noise_out["eps_cov"])
         self.steps_done = 0
         with self._on_stream():
             self._check(self.lib.bean_hip_prepare(self._h, self._sptr()), "prepare")
@@ -417,6 +443,9 @@ class HipSVI:
         # the draw of the Dirichlet-over-guides site: `initial_abundance` in the survival MixtureNormal
         # guide, `q_0` (site initial_guide_abundance) in the survival NormalModel
         names["q_0" if self.surv_normal else "initial_abundance"] = "X0_IN"
+        if self.n_cov:
+            names.pop("eps_noise")
+            names["eps_cov"] = "EPS_NOISE_IN"
         if noise is not None and "mu_negctrl" in noise and "eps_u" not in noise:
             m0, s0 = float(np.float32(self._shape.negctrl_loc)), float(np.float32(self._shape.negctrl_scale))
             noise = dict(noise)

@@ -74,6 +74,17 @@ def build_variant_screen_data(
     screen = screen.copy()
     samples = screen.samples
     samples["size_factor"] = _size_factor(screen.X)
+    # ScreenData.__init__ (data_class.py:75-92): with uns["sample_covariates"] a "replicate" is a
+    # (replicate, covariates) combination, keyed by the joined string `_rc`
+    sample_covariates = None
+    if "sample_covariates" in screen.uns:
+        sample_covariates = [str(c) for c in np.asarray(screen.uns["sample_covariates"]).reshape(-1)]
+        missing = [c for c in sample_covariates if c not in samples.columns]
+        if missing:
+            raise ValueError(f"uns['sample_covariates'] names {missing}, which are not columns of screen.samples")
+        samples["_rc"] = [".".join(str(v) for v in row)
+                          for row in samples[[replicate_column] + sample_covariates].values.tolist()]
+        replicate_column = "_rc"
     if reporter or use_bcmatch:
         if "X_bcmatch" not in screen.layers:
             raise ValueError("the screen has no X_bcmatch layer")
@@ -194,6 +205,14 @@ def build_variant_screen_data(
     else:
         data.target_lengths = None
     data.negctrl_guide_idx = negctrl_guide_idx
+    if sample_covariates is not None:
+        # (R, n_cov) integer design, rows in replicate-id order (data_class.py:972-979)
+        data.sample_covariates = sample_covariates
+        data.n_sample_covariates = len(sample_covariates)
+        design = samples[["_rc"] + sample_covariates].drop_duplicates().set_index("_rc")
+        data.rep_by_cov = torch.as_tensor(design.values.astype(int))
+        if data.rep_by_cov.shape[0] != R:
+            raise ValueError("sample covariates are not constant within a replicate")
     data.guide_accessibility = None
     if accessibility_col is not None:
         acc = screen.guides[accessibility_col].values.astype(np.float64)

@@ -95,6 +95,12 @@ typedef struct bean_hip_shape {
      * (survival_model.py:225,271-274); fed from the neg-ctrl fit by bean run */
     double negctrl_loc;    /* 0.0 */
     double negctrl_scale;  /* 0.1 */
+    /* sorting NormalModel with sample covariates (bean/model/model.py:73-91, 771-783): number of
+     * covariates (0 = none).  The mu_cov_loc / mu_cov_scale parameters (n_sample_covariates each) use
+     * the NOISE_LOC / NOISE_SCALE parameter slots and the eps draws the EPS_NOISE_IN / _OUT slots,
+     * which this family does not otherwise use. */
+    int32_t n_sample_covariates;
+    int32_t reserved_;
 } bean_hip_shape;
 
 /* Buffer slots.  dtype / shape in brackets; "opt" = only for some families. */
@@ -138,6 +144,8 @@ enum bean_hip_buf {
     BEAN_BUF_XCHG_TGRAD,      /* f64 (2,T) ControlNormal / tiling: per-target likelihood gradient opt  */
     BEAN_BUF_XCHG_SQ,         /* f64 (R)   survival NormalModel: sum_g q_0[r,g] * d loss / d q_0[r,g], the
                                  projection term of the Dirichlet-over-guides pathwise gradient opt  */
+    /* ---- sorting NormalModel with sample covariates */
+    BEAN_BUF_REP_BY_COV = 31, /* f64 (R, n_sample_covariates) design matrix rep_by_cov (data_class.py:83-90) opt */
     /* ---- parameters: unconstrained values as Pyro's param store keeps them */
     BEAN_BUF_P_MU_LOC = 32,   /* f32 (T)                                              */
     BEAN_BUF_P_MU_SCALE,      /* f32 (T)   log mu_scale                               */

@@ -202,6 +202,9 @@ def init_params(family: str, data, fit_noise: bool = True, scale_by_acc: bool = 
     else:
         T = data.n_targets
         p = {k: torch.zeros((T, 1), dtype=f) for k in ("mu_loc", "mu_scale", "sd_loc", "sd_scale")}
+    if family == "Normal" and getattr(data, "sample_covariates", None) is not None:
+        p["mu_cov_loc"] = torch.zeros(data.n_sample_covariates, dtype=f)
+        p["mu_cov_scale"] = torch.zeros(data.n_sample_covariates, dtype=f)  # log(1)
     if family in ("MixtureNormal", "MultiMixtureNormal"):
         A = data.n_max_alleles
         a0 = torch.ones((data.n_guides, A), dtype=f)
@@ -238,6 +241,14 @@ def normal_loss(data, params, noise=None, use_bcmatch=True, sd_scale=0.01,
     mu = torch.repeat_interleave(mu_t, data.target_lengths, dim=0)
     sd = torch.repeat_interleave(sd_t, data.target_lengths, dim=0)
     mu = mu[None, None].expand(R, B, -1, -1)
+    if getattr(data, "sample_covariates", None) is not None:
+        # sample covariates (model.py:73-76, 88-91; guide 771-782): one Normal site per covariate,
+        # but only the FIRST column of rep_by_cov * mu_cov shifts the replicates' means
+        # (`(data.rep_by_cov * mu_cov)[:, 0]`)
+        mu_cov = normal_rsample(P["mu_cov_loc"], P["mu_cov_scale"], _noise(noise, "eps_cov"))
+        guide_lp["mu_cov"] = tdist.Normal(P["mu_cov_loc"], P["mu_cov_scale"]).log_prob(mu_cov).sum()
+        model_lp["mu_cov"] = tdist.Normal(0.0, 1.0).log_prob(mu_cov).sum()
+        mu = mu + (data.rep_by_cov * mu_cov)[:, 0][:, None, None, None].expand(-1, B, G, 1)
     sd = torch.sqrt(sd[None, None].expand(R, B, -1, -1))
     uq = data.upper_bounds[None, :, None, None].expand(R, -1, G, 1)
     lq = data.lower_bounds[None, :, None, None].expand(R, -1, G, 1)
