@@ -1,5 +1,5 @@
-"""``bean`` command dispatcher (``bean/cli/execute.py:30-84``): the ``run`` sub-command and its
-companion ``build-prior`` are in scope of this implementation."""
+"""``bean`` command dispatcher (``bean/cli/execute.py:30-84``): the ``run`` sub-command, its companion
+``build-prior`` and the mask-producing part of ``qc`` are in scope of this implementation."""
 from __future__ import annotations
 
 import argparse
@@ -16,6 +16,9 @@ def get_parser():
     from .build_prior import attach_args as attach_prior_args
 
     attach_prior_args(sub.add_parser("build-prior", help="obtain prior_params.pkl for batched runs"))
+    from .qc import attach_args as attach_qc_args
+
+    attach_qc_args(sub.add_parser("qc", help="QC of the screen: mask low-quality samples and outlier guides"))
     return parser
 
 
@@ -26,6 +29,11 @@ def main(argv=None):
         from .build_prior import main as build_prior_main
 
         build_prior_main(args)
+        return 0
+    if args.subcommand == "qc":
+        from .qc import main as qc_main
+
+        qc_main(args)
         return 0
     if args.subcommand != "run":
         parser.print_help()

@@ -124,6 +124,14 @@ class ReporterScreen:
         return pd.DataFrame(out, index=self.guides.index)
 
 
+def _write(self, out_path: str) -> None:
+    """Write ``.h5ad`` (``ReporterScreen.write``, reference ``ReporterScreen.py:896-915``)."""
+    h5ad_io.write_screen(self, out_path)
+
+
+ReporterScreen.write = _write
+
+
 def read_h5ad(path: str) -> ReporterScreen:
     """``be.read_h5ad`` (``bean/framework/ReporterScreen.py:1009-1011``)."""
     tree = h5ad_io.read_tree(path)

@@ -146,6 +146,141 @@ def read_tree(path: str) -> dict:
             return pickle.load(fh)
 
 
-if __name__ == "__main__":  # helper-interpreter entry: h5ad_io.py <in.h5ad> <out.pkl>
-    with open(sys.argv[2], "wb") as fh:
-        pickle.dump(decode_file(sys.argv[1]), fh, protocol=4)
+# ------------------------------------------------------------------- writing
+def _enc_frame(df) -> dict:
+    """pandas DataFrame -> encode tree (the mirror image of ``_decode``'s dataframe node)."""
+    import pandas as pd
+
+    cols = {}
+    for c in df.columns:
+        v = df[c]
+        if isinstance(v.dtype, pd.CategoricalDtype):
+            cols[str(c)] = {"__categorical__": True, "categories": np.asarray(v.cat.categories.astype(str), dtype=object),
+                            "codes": np.asarray(v.cat.codes), "ordered": bool(v.cat.ordered)}
+        elif v.dtype.kind in "biuf":
+            cols[str(c)] = v.to_numpy()
+        else:
+            cols[str(c)] = np.asarray(["" if x is None or (isinstance(x, float) and np.isnan(x)) else str(x)
+                                       for x in v.tolist()], dtype=object)
+    return {"__dataframe__": True, "index_name": "_index" if df.index.name is None else str(df.index.name),
+            "index": np.asarray(df.index.astype(str), dtype=object), "columns": [str(c) for c in df.columns], "data": cols}
+
+
+def _enc_value(v):
+    import pandas as pd
+
+    if isinstance(v, pd.DataFrame):
+        return _enc_frame(v)
+    if isinstance(v, dict):
+        return {str(k): _enc_value(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        arr = np.asarray(v)
+        return np.asarray([str(x) for x in v], dtype=object) if arr.dtype.kind in "OUS" else arr
+    if isinstance(v, np.ndarray) and v.dtype.kind in "OUS":
+        return np.asarray([str(x) for x in v.reshape(-1)], dtype=object).reshape(v.shape)
+    return v
+
+
+def encode_screen(screen) -> dict:
+    """ReporterScreen -> encode tree of numpy arrays / builtins (picklable)."""
+    return {"X": np.asarray(screen.X, dtype=np.float32),
+            "layers": {k: np.asarray(v, dtype=np.float32) for k, v in screen.layers.items()},
+            "obs": _enc_frame(screen.guides), "var": _enc_frame(screen.samples),
+            "uns": {str(k): _enc_value(v) for k, v in screen.uns.items()}}
+
+
+def _write_node(parent, name, v):
+    import h5py
+
+    str_dt = h5py.string_dtype(encoding="utf-8")
+
+    def tag(obj, enc, ver):
+        obj.attrs["encoding-type"] = enc
+        obj.attrs["encoding-version"] = ver
+
+    if isinstance(v, dict) and v.get("__dataframe__"):
+        g = parent.create_group(name)
+        tag(g, "dataframe", "0.2.0")
+        g.attrs["_index"] = v["index_name"]
+        g.attrs["column-order"] = np.asarray(v["columns"], dtype=str_dt) if v["columns"] else np.empty(0, dtype=str_dt)
+        _write_node(g, v["index_name"], v["index"])
+        for c in v["columns"]:
+            _write_node(g, c, v["data"][c])  # a "/" in the name nests groups, as anndata writes it
+        return
+    if isinstance(v, dict) and v.get("__categorical__"):
+        g = parent.create_group(name)
+        tag(g, "categorical", "0.2.0")
+        g.attrs["ordered"] = bool(v["ordered"])
+        _write_node(g, "categories", v["categories"])
+        _write_node(g, "codes", np.asarray(v["codes"]))
+        return
+    if isinstance(v, dict):
+        g = parent.create_group(name)
+        tag(g, "dict", "0.1.0")
+        for k, x in v.items():
+            _write_node(g, k, x)
+        return
+    if isinstance(v, str):
+        d = parent.create_dataset(name, data=v, dtype=str_dt)
+        tag(d, "string", "0.2.0")
+        return
+    if isinstance(v, (bool, int, float, np.bool_, np.integer, np.floating)):
+        d = parent.create_dataset(name, data=v)
+        tag(d, "numeric-scalar", "0.2.0")
+        return
+    arr = np.asarray(v)
+    if arr.dtype.kind in "OUS":
+        d = parent.create_dataset(name, data=arr.astype(object), dtype=str_dt)
+        tag(d, "string-array", "0.2.0")
+    else:
+        d = parent.create_dataset(name, data=arr)
+        tag(d, "array", "0.2.0")
+
+
+def write_tree_file(tree: dict, path: str) -> None:
+    """Encode tree -> AnnData ``.h5ad`` (encoding versions of anndata 0.8+); needs h5py."""
+    import h5py
+
+    with h5py.File(path, "w") as f:
+        f.attrs["encoding-type"] = "anndata"
+        f.attrs["encoding-version"] = "0.1.0"
+        _write_node(f, "X", tree["X"])
+        _write_node(f, "layers", tree["layers"])
+        _write_node(f, "obs", tree["obs"])
+        _write_node(f, "var", tree["var"])
+        _write_node(f, "uns", tree["uns"])
+        for k in ("obsm", "varm", "obsp", "varp"):
+            _write_node(f, k, {})
+
+
+def write_screen(screen, path: str) -> None:
+    """Write a ReporterScreen as ``.h5ad`` (``ReporterScreen.write``, reference
+    ``bean/framework/ReporterScreen.py:896-915``), in-process with h5py or through the helper."""
+    tree = encode_screen(screen)
+    try:
+        import h5py  # noqa: F401
+
+        write_tree_file(tree, path)
+        return
+    except ImportError:
+        pass
+    if not os.path.exists(HELPER_PYTHON):
+        raise ImportError("writing .h5ad needs h5py: install it, or point BEAN_H5PY_PYTHON at an interpreter that "
+                          f"has it (tried {HELPER_PYTHON})")
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "tree.pkl")
+        with open(src, "wb") as fh:
+            pickle.dump(tree, fh, protocol=4)
+        res = subprocess.run([HELPER_PYTHON, os.path.abspath(__file__), "--write", src, path],
+                             capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"h5ad helper failed:\n{res.stderr}")
+
+
+if __name__ == "__main__":  # helper-interpreter entry: h5ad_io.py <in.h5ad> <out.pkl> | --write <tree.pkl> <out.h5ad>
+    if sys.argv[1] == "--write":
+        with open(sys.argv[2], "rb") as fh:
+            write_tree_file(pickle.load(fh), sys.argv[3])
+    else:
+        with open(sys.argv[2], "wb") as fh:
+            pickle.dump(decode_file(sys.argv[1]), fh, protocol=4)

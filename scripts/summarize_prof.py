@@ -1,8 +1,8 @@
 """Condense rocprofv3 CSV output (scripts/profile.sh) into profiles/<tag>_*.
 
-    python scripts/summarize_prof.py gpurun_out/prof_<tag> <tag>
+    python scripts/summarize_prof.py gpurun_out/prof_<tag>[_<config>] <tag> [config]
 
-Writes profiles/<tag>_kernel_stats.csv (the --stats table restricted to this
+Writes (with suffix _<config> for the tiling / survival configurations) profiles/<tag>_kernel_stats.csv (the --stats table restricted to this
 library's kernels), profiles/<tag>_counters.txt (mean per dispatch of every PMC
 counter collected, per kernel) and profiles/<tag>_traffic.json (HBM bytes per
 launch of the dominant kernel: FETCH_SIZE is doubled as
@@ -17,13 +17,16 @@ import sys
 from collections import defaultdict
 
 root, tag = sys.argv[1], sys.argv[2]
+config = sys.argv[3] if len(sys.argv) > 3 else "metric"
+suf = "" if config == "metric" else "_" + config
 os.makedirs("profiles", exist_ok=True)
 for f in glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if "bean::" in r[0]]
-    with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as out:
+    with open(f"profiles/{tag}_kernel_stats{suf}.csv", "w", newline="") as out:
         csv.writer(out).writerows(keep)
-lines, traffic = [], {}
+lines, traffic, calib = [], {}, {}
+dominant = None
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         agg = defaultdict(lambda: defaultdict(list))
@@ -43,12 +46,21 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
                 lines.append(f"    {c:24s} n={len(v):5d} mean={sum(v) / len(v):.6g}")
                 if "k_guide" in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
                     traffic[c] = sum(v) / len(v)
-open(f"profiles/{tag}_counters.txt", "w").write("\n".join(lines) + "\n")
+                    dominant = k
+                if "k_prepare" in k and c == "FETCH_SIZE":
+                    calib[c] = sum(v) / len(v)
+open(f"profiles/{tag}_counters{suf}.txt", "w").write("\n".join(lines) + "\n")
 if traffic:
     fetch = traffic.get("FETCH_SIZE", 0.0) * 1024 * 2  # KiB; gfx950 reports half of a coalesced stream
     write = traffic.get("WRITE_SIZE", 0.0) * 1024
-    json.dump({"kernel": "k_guide_wave", "fetch_bytes_corrected": fetch, "write_bytes": write,
-               "hbm_bytes_per_launch": fetch + write,
-               "note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as read; separate --pmc passes"},
-              open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+    out = {"kernel": dominant, "fetch_bytes_corrected": fetch, "write_bytes": write,
+           "hbm_bytes_per_launch": fetch + write,
+           "note": "FETCH_SIZE x2 (gfx950 correction of MI355X_MICROARCH.md, calibrated there for 16-B/lane streams; "
+                   "these kernels load 4-8 B per lane, so the corrected figure is an upper bound), WRITE_SIZE as read; "
+                   "separate --pmc passes"}
+    if calib:
+        # k_prepare reads every count / mask tensor exactly once with the same 4-B/lane loads: its raw
+        # FETCH_SIZE against that known byte count calibrates the correction for this access width
+        out["k_prepare_fetch_size_raw_bytes"] = calib["FETCH_SIZE"] * 1024
+    json.dump(out, open(f"profiles/{tag}_traffic{suf}.json", "w"), indent=1)
 print("\n".join(lines))

@@ -207,6 +207,7 @@ def test_two_rank_cli_writes_the_single_process_tables(tmp_path):
     are sharded over the ranks, rank 0 writes the tables; for the variant sorting family the result
     is the single-process result bit for bit (also with per-target `--prior-params`, which every rank
     cuts to its own targets), for tiling up to the regrouping of float64 sums."""
+    import pickle
     import subprocess
     import sys
 
@@ -243,3 +244,17 @@ def test_two_rank_cli_writes_the_single_process_tables(tmp_path):
             pd.testing.assert_frame_equal(a, b)
         else:
             np.testing.assert_allclose(a[num].values, b[num].values, rtol=1e-5, atol=1e-7)
+
+
+def test_qc_then_run_with_default_mask_columns(tmp_path):
+    """`bean qc` writes samples["mask"] / uns["repguide_mask"]; `bean run` then works
+    with its DEFAULT --sample-mask-col / --repguide-mask (no `--sample-mask-col ""` escape)."""
+    masked = str(tmp_path / "var_masked.h5ad")
+    assert bean_main(["qc", VAR, "-o", masked, "-r", str(tmp_path / "qc"), "--count-correlation-thres", "0.5"]) == 0
+    out = str(tmp_path / "run")
+    assert bean_main(["run", "sorting", "variant", masked, "-o", out, "--n-iter", "20"]) == 0
+    (d,) = [os.path.join(out, p) for p in os.listdir(out) if p.startswith("bean_run_result.")]
+    el = pd.read_csv(f"{d}/bean_element_result.MixtureNormal.csv")
+    assert len(el) == 6 and np.isfinite(el[["mu", "mu_sd", "mu_z", "sd"]].values).all()
+    sg = pd.read_csv(f"{d}/bean_sgRNA_result.MixtureNormal.csv")
+    assert "edit_rate" in sg.columns and len(sg) == 30
