@@ -40,7 +40,14 @@ def main(argv=None):
         return 2
     from .run import main as run_main
 
-    run_main(args)
+    try:
+        run_main(args)
+    finally:
+        # `torchrun ... bean run`: leave the process group cleanly (RCCL communicators, store)
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
     return 0
 
 

@@ -65,12 +65,13 @@ def main(args, return_data=False):
     args, bdata = check_args(args, bdata)
     prefix = args.outdir + "/bean_run_result." + os.path.basename(args.bdata_path).rsplit(".h5ad", 1)[0]
     os.makedirs(prefix, exist_ok=True)
-    handler = logging.FileHandler(f"{prefix}/bean_run.log")
-    handler.setLevel(logging.INFO)
-    logger.addHandler(handler)
+    if rank == 0:  # rank 0 owns the log file and every table; the other ranks only fit their shards
+        handler = logging.FileHandler(f"{prefix}/bean_run.log")
+        handler.setLevel(logging.INFO)
+        logger.addHandler(handler)
     model_label, model, guide = identify_model_guide(args)
     info("Done loading data. Preprocessing...")
-    bdata = prepare_bdata(bdata, args, warn, prefix)
+    bdata = prepare_bdata(bdata, args, warn, prefix, write_files=(rank == 0))
     is_neg = lambda scr: np.where(scr.guides[args.negctrl_col].map(lambda v: str(v).lower())  # noqa: E731
                                   == args.negctrl_col_value.lower())[0]
     negctrl_idx = is_neg(bdata) if args.negctrl_col in bdata.guides.columns else np.zeros(0, dtype=int)

@@ -41,6 +41,7 @@ struct bean_hip_ctx {
     long long* loss_acc;  // library-owned fixed-point loss accumulators, kLossWords per loss_hist slot
     int* tile_targets_dev;
     bool tiling_wave;  // tiling families, default: k_guide_tiling_wave (BEAN_HIP_TILING=block: k_guide_tiling)
+    bool tiling_wide;  // more alleles per guide than this build's kAMax: bean_tiling_wide.hpp
     double* gsum_ws;  // library-owned normaliser buffer (replaced by BEAN_BUF_XCHG_GSUM when bound)
     double* sq_ws;    // library-owned projection sums (replaced by BEAN_BUF_XCHG_SQ when bound)
     // graph cache: graphs[k] replays 2^k {k_param, guide} pairs
@@ -214,9 +215,10 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (s->family == BEAN_FAMILY_MIXTURE_NORMAL && s->n_max_alleles != 2)
         return fail("bean_hip_create: MixtureNormal requires n_max_alleles == 2");
     if (is_tiling(*s)) {
-        if (s->n_max_alleles < 2 || s->n_max_alleles > kAMax)
-            return fail("bean_hip_create: MultiMixtureNormal requires n_max_alleles in [2, " + std::to_string(kAMax) +
-                        "] (libbean_hip.so holds 8 alleles per guide, libbean_hip_a16.so 16)");
+        if (s->n_max_alleles < 2 || s->n_max_alleles > kWideMaxA)
+            return fail("bean_hip_create: MultiMixtureNormal requires n_max_alleles in [2, " + std::to_string(kWideMaxA) +
+                        "] (up to " + std::to_string(kAMax) + " alleles per guide run in the register-resident kernels "
+                        "of this build, more in the allele-parallel ones)");
         if (s->n_edits < 1 || s->n_targets != s->n_edits)
             return fail("bean_hip_create: MultiMixtureNormal requires n_targets == n_edits >= 1");
         if (s->n_a2e_nnz < 0) return fail("bean_hip_create: n_a2e_nnz must be >= 0");
@@ -276,7 +278,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const uint64_t n_cov = (uint64_t)s->n_sample_covariates;
     // table columns: allele slots or targets (per replicate with sample covariates)
     const uint64_t n_tab = is_tiling(*s) ? A1 * G : T * (n_cov ? (uint64_t)s->n_reps : 1);
-    const uint64_t n_part = is_tiling(*s) ? (uint64_t)kTNumPart : (uint64_t)kNumPart;
+    const uint64_t n_part = is_tiling(*s) ? (uint64_t)(s->n_max_alleles > kAMax ? tq_num(s->n_max_alleles) : kTNumPart)
+                                          : (uint64_t)kNumPart;
     const bool surv_mix = is_survival(*s) && s->family == BEAN_FAMILY_MIXTURE_NORMAL;
     const bool surv_tiling = is_survival(*s) && is_tiling(*s);
     const bool surv_norm = is_surv_normal(*s);
@@ -302,8 +305,11 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.n_cov = s->n_sample_covariates;
     c->surv_wave = c->surv_wave && is_survival(*s) && !is_tiling(*s);
     d.rows_v2 = (c->wave2 || c->surv_wave) ? 1 : 0;
-    c->tiling_wave = c->tiling_wave && is_tiling(*s);
-    const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G : 0;
+    c->tiling_wide = is_tiling(*s) && s->n_max_alleles > kAMax;
+    c->tiling_wave = c->tiling_wave && is_tiling(*s) && !c->tiling_wide;
+    d.wide_alleles = c->tiling_wide ? 1 : 0;
+    const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G
+                                           : (c->tiling_wide ? (uint64_t)tq_num(d.A) * Rr * G : 0);
     const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G
                                        : (c->wave_guide ? (uint64_t)(c->wave2 ? kW2Rows : kNumPart + 2) * Rr * G
                                                         : (c->surv_wave ? (uint64_t)kW2Rows * Rr * G : 0));
@@ -351,7 +357,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (n_dbg) {
         d.dbg = (unsigned long long*)w; w += n_dbg;
     }
-    if (c->tiling_wave) {
+    if (c->tiling_wave || c->tiling_wide) {
         d.trow = w; w += n_trow;
     }
     if (c->wave_guide && c->wave2) {
@@ -522,7 +528,8 @@ static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_block
     const DevArgs& d = c->d;
     n_target_blocks = d.wide_targets ? d.T : (int)(((long)d.T * kLanesPerTarget + kParamBlock - 1) / kParamBlock);
     int guide_blocks = 0;
-    if (d.family == kMultiMixture) guide_blocks = (int)(((long)d.G * kAMax + kParamBlock - 1) / kParamBlock);  // kAMax lanes per guide
+    if (d.family == kMultiMixture)  // kAMax lanes per guide, or one wave per guide on the wide path
+        guide_blocks = (int)(((long)d.G * (d.wide_alleles ? 64 : kAMax) + kParamBlock - 1) / kParamBlock);
     else if (d.family == kMixture || d.surv_q0lik) guide_blocks = (d.G + kParamBlock - 1) / kParamBlock;
     n_blocks = n_target_blocks + guide_blocks;
 }
@@ -703,7 +710,7 @@ static void launch_sums(bean_hip_ctx* c, hipStream_t stream) {
 static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     const bool acc = (d.flags & kAcc) != 0;
-    const dim3 grid((d.G + 63) / 64, d.R), block(64);
+    const dim3 grid((unsigned)(((d.G + 63) / 64 + 7) / 8 * 8) * (unsigned)d.R), block(64);
     const size_t lds = (size_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * 64 * sizeof(double) +
                        (size_t)2 * d.B * 64 * sizeof(float);
     const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
@@ -727,7 +734,6 @@ static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
         if (acc) hipLaunchKernelGGL((k_guide_tiling_wave<true, false>), grid, block, lds, stream, d);
         else hipLaunchKernelGGL((k_guide_tiling_wave<false, false>), grid, block, lds, stream, d);
     }
-    hipLaunchKernelGGL(k_sum_trow, dim3((d.G + 255) / 256, kTNumPart), dim3(256), 0, stream, d);
 }
 
 // survival variant families, one wave per (guide tile, replicate) (bean_survival_v2.hpp)
@@ -786,6 +792,30 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
     }
     if (c->tiling_wave) {
         launch_guide_tiling_wave(c, stream);
+        return;
+    }
+    if (c->tiling_wide) {
+        const bool acc = (d.flags & kAcc) != 0;
+        const dim3 gridw((unsigned)((long)d.R * d.G)), blockw(64);
+        const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof) {
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, stream);
+        }
+        if (d.survival) {
+            if (acc) hipLaunchKernelGGL((k_guide_tiling_wide<true, true>), gridw, blockw, 0, stream, d);
+            else hipLaunchKernelGGL((k_guide_tiling_wide<false, true>), gridw, blockw, 0, stream, d);
+        } else {
+            if (acc) hipLaunchKernelGGL((k_guide_tiling_wide<true, false>), gridw, blockw, 0, stream, d);
+            else hipLaunchKernelGGL((k_guide_tiling_wide<false, false>), gridw, blockw, 0, stream, d);
+        }
+        if (prof) {
+            (void)hipEventRecord(e1, stream);
+            c->ev.push_back(e0);
+            c->ev.push_back(e1);
+        }
         return;
     }
     const dim3 grid((d.G + 63) / 64), block(64 * nw);
@@ -1038,7 +1068,8 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
 }
 
 extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
-    if (c && c->d.family == kMultiMixture) return c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling";
+    if (c && c->d.family == kMultiMixture)
+        return c->tiling_wide ? "k_guide_tiling_wide" : (c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling");
     if (c && c->d.survival) return c->surv_wave ? "k_guide_survival_wave" : "k_guide_survival";
     if (c && c->wave_guide) return c->wave2 ? "k_guide_wave2" : "k_guide_wave";
     return "k_lik";

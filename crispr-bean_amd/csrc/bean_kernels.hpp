@@ -105,6 +105,7 @@ struct DevArgs {
     const double* rbc;                 // (R, n_cov) design matrix
     double *cov_mu, *cov_eps;          // (n_cov) current draw
     double *cov_shift, *cov_sum;       // (R) shift of replicate r; sum_g of its d nll / d mu rows
+    int wide_alleles;                  // tiling with more alleles per guide than kAMax: bean_tiling_wide.hpp
     double* dgq;
     double* dgq_t;                     // tiling: (kAMax + 1, G) digamma(c_q[a]) rows and digamma(sum c_q), same contract
     long long* lpart;                  // (n_lpart, 3) per-wave loss parts of the wave-form guide kernels, or null
@@ -277,6 +278,15 @@ __device__ __forceinline__ double part_row(const DevArgs& c, int q, int g) {
     for (int r = 0; r < c.R; ++r) s += c.wrow[((long)q * c.R + r) * c.G + g];
     return s;
 }
+// tiling: row q of guide g summed over the replicates in fixed order - straight from the wave kernels'
+// per-replicate rows (trow) when they exist (no separate reduction launch and no round trip through
+// `part`), else from `part` (block form)
+__device__ __forceinline__ double trow_sum(const DevArgs& c, int q, long g) {
+    if (!c.trow) return c.part[(long)q * c.G + g];
+    double s = 0.0;
+    for (int r = 0; r < c.R; ++r) s += c.trow[((long)q * c.R + r) * c.G + g];
+    return s;
+}
 __device__ __forceinline__ double lik_row(const DevArgs& c, int q, int g) {
     if (!c.rrow) return part_row(c, q, g);
     double s = 0.0;
@@ -392,7 +402,7 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_targe
         // the survival tiling guide clamps its concentration at 1e-5 (survival_model.py:813-821);
         // the sorting one does not (model.py:942-950)
         const bool clampq = c.survival != 0;
-        const double nrg = in ? c.part[(long)kTNrg * c.G + g] : 0.0;
+        const double nrg = in ? trow_sum(c, kTNrg, g) : 0.0;
         const double cqr = alpha * rS * pa0;
         const bool cqc = clampq && cqr < 1e-5;
         const double cq = cqc ? 1e-5 : cqr;
@@ -408,9 +418,9 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_targe
         if (live) {
             double lg, dg;
             lgamma_digamma(cq, lg, dg);
-            const double L = c.part[(long)(kTL + a) * c.G + g];
+            const double L = trow_sum(c, kTL + a, g);
             const double lq = -nrg * lg + (cq - 1.0) * L;
-            gq = cqc ? 0.0 : L + nrg * (dgS_q - dg) + c.part[(long)(kTPath + a) * c.G + g];
+            gq = cqc ? 0.0 : L + nrg * (dgS_q - dg) + trow_sum(c, kTPath + a, g);
             lgamma_digamma(cp, lg, dg);
             const double lp = -nrg * lg + (cp - 1.0) * L;
             gp = cpc ? 0.0 : -(L + nrg * (dgS_p - dg));
@@ -425,7 +435,7 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_targe
         }
         if (lead && acc_on) {
             const double lpn = c.lpn[g], eps = c.eps_noise[g];
-            const double gl = c.part[(long)kTGnoise * c.G + g];
+            const double gl = trow_sum(c, kTGnoise, g);
             const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
             const float nsf = 0.655f;
             const double nvar = (double)(nsf * nsf);
@@ -554,16 +564,21 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
         // allele_to_edit @ mu_edits and ||allele_to_edit * sd_edits|| (model.py:618-622).  The
         // slots of the edit are spread over its lane group, summed by a fixed shuffle tree.
         const int A1 = c.A - 1;
+        // rows of the per-allele-slot gradients: fixed layout of the register-resident kernels, or the
+        // runtime layout of the wide path (bean_tiling_wide.hpp: 2 + 2 A, 2 + 2 A + (A - 1))
+        const int q_gmu = c.wide_alleles ? 2 + 2 * c.A : (int)kTGmu;
+        const int q_gsig = c.wide_alleles ? 2 + 2 * c.A + A1 : (int)kTGsig;
         const int lg = threadIdx.x & (kLanesPerTarget - 1);
         double a = 0.0, b = 0.0;
         if (t < c.T) {
             const double sd = c.survival ? 0.0 : exp(c.y_t[t]);  // survival: no sd latent
             for (int k = c.e2a_ptr[t] + lg; k < c.e2a_ptr[t + 1]; k += kLanesPerTarget) {
                 const int slot = c.e2a_idx[k];
-                const long o = (long)(slot % A1) * c.G + slot / A1;
-                a += c.part[(long)kTGmu * c.G + o];
+                const int a1 = slot % A1, gs = slot / A1;
+                const long o = (long)a1 * c.G + gs;
+                a += trow_sum(c, q_gmu + a1, gs);
                 // d sigma_a / d y_e = sd_e^2 / sigma_a
-                if (!c.survival) b += c.part[(long)kTGsig * c.G + o] * sd * sd / c.sig_a[o];
+                if (!c.survival) b += trow_sum(c, q_gsig + a1, gs) * sd * sd / c.sig_a[o];
             }
         }
 #pragma unroll
@@ -623,6 +638,10 @@ __global__ __launch_bounds__(kParamBlock) void k_target_reduce(DevArgs c, double
         out[c.T + t] = gy;
     }
 }
+
+}  // namespace bean
+#include "bean_tiling_wide.hpp"  // needs everything above; k_param below dispatches to it
+namespace bean {
 
 // -------------------------------------------------------------------- k_param
 // grid = n_target_blocks + n_guide_blocks, 256 threads.
@@ -877,13 +896,16 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
             }
         }
     } else if (c.family == kMultiMixture) {
-        param_guide_tiling<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
+        if (c.wide_alleles) param_guide_tiling_wide<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
+        else param_guide_tiling<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
         if (c.survival) {
             // per-guide baseline growth mu_negctrl ~ N(m0, s0): sampled in the model only
             // (survival_model.py:479-483), i.e. a fresh prior draw each step
             const int tid = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
-            const int g = tid / kAMax;  // kAMax lanes per guide (param_guide_tiling): lane 0 acts
-            if (g < c.G && tid % kAMax == 0) {
+            // kAMax lanes per guide (param_guide_tiling) or one wave per guide (wide path): lane 0 acts
+            const int lpg = c.wide_alleles ? 64 : kAMax;
+            const int g = tid / lpg;
+            if (g < c.G && tid % lpg == 0) {
                 if (FINISH) {
                     const float s0f = (float)c.neg_scale;
                     const double du = c.u_g[g] - (double)(float)c.neg_loc;
@@ -2613,15 +2635,22 @@ void k_guide_tiling(DevArgs c) {
 // nothing lives in scratch.  Per-allele state is two register arrays (pi, d loss / d pi) walked by
 // fully unrolled loops; everything indexed by the bin b is a thread-private LDS column walked by
 // rolled loops: e[b], d nll / d e[b], the digamma differences of the current likelihood, the counts.
-// The per-replicate rows go to trow[(q, r, g)]; k_sum_trow adds the replicates into `part`.
+// The per-replicate rows go to trow[(q, r, g)]; k_param adds the replicates up where it reads them (trow_sum).
 // dynamic LDS: (3 B [+ 3 kAMax if ACC]) * 64 doubles + 2 B * 64 floats.
 template <bool ACC, bool SURV>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void k_guide_tiling_wave(DevArgs c) {
     extern __shared__ double tls[];
     const int lane = threadIdx.x;
-    const int g = blockIdx.x * 64 + lane;
-    const int r = blockIdx.y;
+    // 1-D grid, XCD-aware decode (as k_guide_wave2): the R waves of a tile have equal blockIdx % 8, i.e.
+    // share an L2, so the tile's allele tables (3 B (A - 1) doubles per guide: 42 MB at config 3) and
+    // per-guide values come from HBM once, not once per replicate (measured 432 -> see profiles/)
+    const int wg = blockIdx.x;
+    const int kk = wg >> 3;
+    const int r = kk % c.R;
+    const int tile = (kk / c.R) * 8 + (wg & 7);
+    if (tile * 64 >= c.G) return;
+    const int g = tile * 64 + lane;
     const bool valid = g < c.G;
     const StepCtr ctr = *c.ctrB;
     const int G = c.G, A = c.A, A1 = c.A - 1, B = c.B;
@@ -2904,25 +2933,8 @@ void k_guide_tiling_wave(DevArgs c) {
     const double tot = wave_sum(loss);
     if (lane == 0) {
         loss_add(c, ctr.slot, tot);
-        if (blockIdx.x == 0 && blockIdx.y == 0) publish_ctr(c, ctr);
+        if (wg == 0) publish_ctr(c, ctr);
     }
-}
-
-// part[q, g] = sum_r trow[q, r, g] for the rows of the alleles that exist (fixed order)
-__global__ __launch_bounds__(256) void k_sum_trow(DevArgs c) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = blockIdx.y;
-    if (g >= c.G) return;
-    const int A = c.A;
-    bool used = q == kTGnoise || q == kTNrg;
-    if (q >= kTPath && q < kTPath + kAMax) used = q - kTPath < A;
-    if (q >= kTL && q < kTL + kAMax) used = q - kTL < A;
-    if (q >= kTGmu && q < kTGmu + kAMax - 1) used = q - kTGmu < A - 1;
-    if (q >= kTGsig) used = q - kTGsig < A - 1;
-    if (!used) return;
-    double s = 0.0;
-    for (int r = 0; r < c.R; ++r) s += c.trow[((long)q * c.R + r) * c.G + g];
-    c.part[(long)q * c.G + g] = s;
 }
 
 // ------------------------------------------------------------------ one-offs

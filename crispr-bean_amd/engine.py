@@ -73,9 +73,12 @@ class HipSVI:
         self.survival = survival
         if not torch.cuda.is_available():
             raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
-        # the tiling kernels hold 8 alleles per guide in the default build, 16 in the second one
+        # the register-resident tiling kernels hold 8 alleles per guide (and 8 conditions) in the default
+        # build, 16 in the second one; more alleles per guide run in the allele-parallel kernels of
+        # either build (csrc/bean_tiling_wide.hpp), so only the condition count decides then
         amax = 8
-        if (family == "MultiMixtureNormal" and int(getattr(data, "n_max_alleles", 2)) > 8) or data.n_condits > 8:
+        n_al = int(getattr(data, "n_max_alleles", 2)) if family == "MultiMixtureNormal" else 2
+        if (8 < n_al <= 16) or data.n_condits > 8:
             amax = 16
         self.lib = _lib.load(amax)
         self.device = torch.device(device if device is not None else "cuda:0")

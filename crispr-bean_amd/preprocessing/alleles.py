@@ -14,15 +14,18 @@ Two deliberate differences, both stated to the user when they apply:
   objects whose hash depends on the process' string-hash seed, so its edit numbering is not
   reproducible run to run; any numbering is equivalent up to a permutation of the rows of the
   result table);
-* the HIP kernels hold at most ``MAX_ALLELES`` = 16 alleles per guide (15 edited + the unedited one;
-  the default library build holds 8, ``libbean_hip_a16.so`` 16).  A table with more alleles per
-  guide - normally one that has not been through ``bean filter`` - is reduced to each guide's 15
-  most abundant alleles; the reads of the dropped alleles fall into
-  the unedited allele exactly as they do for alleles ``bean filter`` removes
-  (``data_class.py:773-777``).
+* alleles per guide: up to 16 (the unedited one included) run in the register-resident kernels
+  (``libbean_hip.so`` holds 8, ``libbean_hip_a16.so`` 16), up to ``MAX_ALLELES`` = 256 in the
+  allele-parallel kernels (``csrc/bean_tiling_wide.hpp``), so unfiltered tables fit as they are (the
+  reference's own ``tests/data/tiling_mini_screen.h5ad`` has 230).  Beyond 256 the build stops with an
+  error that names ``bean filter``; ``BEAN_MAX_ALLELES_PER_GUIDE=N`` opts in to keeping each guide's
+  ``N - 1`` most abundant alleles instead (the reads of the dropped ones fall into the unedited allele
+  exactly as they do for alleles ``bean filter`` removes, ``data_class.py:773-777``) - a different model
+  from the reference's, hence never the default.
 """
 from __future__ import annotations
 
+import os
 import re
 import warnings
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -31,7 +34,7 @@ import numpy as np
 import pandas as pd
 import torch
 
-MAX_ALLELES = 16
+MAX_ALLELES = 256  # csrc/bean_tiling_wide.hpp: kWideMaxA
 _REV = {"A": "T", "C": "G", "T": "A", "G": "C", "-": "-"}
 _NT_EDIT = re.compile(r"(((chr)?\w+|nan):)?-?\d+:-?\d+:[+-]:[A-Z*-]>[A-Z*-]")
 
@@ -129,15 +132,24 @@ def build_allele_tensors(allele_df: pd.DataFrame, guide_index: Sequence[str], al
     # allele_id_for_guide = 1, 2, ... in table order within each guide (reindex_allele_df, 701-734)
     df["allele_id_for_guide"] = df.groupby("guide", sort=False).cumcount() + 1
     n_max = int(df["allele_id_for_guide"].max()) + 1 if len(df) else 1
+    opt_in = os.environ.get("BEAN_MAX_ALLELES_PER_GUIDE")
+    if opt_in is not None:
+        max_alleles = min(max_alleles, max(int(opt_in), 2))
     if n_max > max_alleles:
+        if opt_in is None:
+            raise ValueError(
+                f"the allele table has up to {n_max - 1} edited alleles per guide; the kernels hold {max_alleles - 1}. "
+                "Filter the table first (`bean filter` writes filtered `allele_counts_*` tables; pass one with "
+                "--allele-df-key), or set BEAN_MAX_ALLELES_PER_GUIDE=N to keep each guide's N - 1 most abundant "
+                "alleles (the rest are counted as unedited: this changes the fitted model).")
         total = df[sample_cols].sum(axis=1)
         rank = total.groupby(df["guide"], sort=False).rank(method="first", ascending=False)
         keep = rank <= (max_alleles - 1)
         out.n_dropped = int((~keep).sum())
         warnings.warn(
-            f"allele table has up to {n_max - 1} edited alleles per guide; the MI355X kernels hold "
-            f"{max_alleles - 1}: keeping each guide's {max_alleles - 1} most abundant alleles "
-            f"({out.n_dropped} rows folded into the unedited allele). Run `bean filter` for a principled filter.")
+            f"BEAN_MAX_ALLELES_PER_GUIDE={max_alleles}: the allele table has up to {n_max - 1} edited alleles per "
+            f"guide; keeping each guide's {max_alleles - 1} most abundant alleles ({out.n_dropped} rows folded into "
+            "the unedited allele).")
         df = df.loc[keep].reset_index(drop=True)
         df["allele_id_for_guide"] = df.groupby("guide", sort=False).cumcount() + 1
         n_max = int(df["allele_id_for_guide"].max()) + 1 if len(df) else 1

@@ -17,7 +17,7 @@ def filter_no_info_target(bdata, condit_col: str, control_condition: str, target
     return len(empty), bdata[keep, :].copy()
 
 
-def prepare_bdata(bdata, args, warn, prefix: str):
+def prepare_bdata(bdata, args, warn, prefix: str, write_files: bool = True):
     """Format a screen for the fit: category replicate column, drop zero-count guides,
     sort guides by target, drop targets without counts."""
     bdata = bdata.copy()
@@ -45,7 +45,7 @@ def prepare_bdata(bdata, args, warn, prefix: str):
         bdata = bdata[np.argsort(bdata.guides[args.target_col].astype(str).values, kind="stable"), :]
         n_bad, bdata = filter_no_info_target(
             bdata, condit_col=args.condition_col, control_condition=args.control_condition,
-            target_col=args.target_col, write_no_support_targets=True,
+            target_col=args.target_col, write_no_support_targets=write_files,
             no_support_target_write_path=f"{prefix}/no_support_targets.csv")
         if n_bad > 0:
             warn(f"Ignoring {n_bad} targets with 0 gRNA counts across all non-control samples. "

@@ -65,10 +65,17 @@ def test_numbering_csr_and_mask_on_a_small_table():
     assert cnt[1, 0].tolist() == [[0, 9, 4, 1], [27, 3, 0, 0], [8, 0, 0, 0]]
 
 
-def test_cap_keeps_the_most_abundant_alleles():
+def test_too_many_alleles_is_an_error_and_truncation_is_opt_in(monkeypatch):
+    """The reference has no bound on alleles per guide; beyond what the kernels hold the build stops
+    (naming `bean filter`) rather than silently fitting a different model; BEAN_MAX_ALLELES_PER_GUIDE
+    opts in to keeping the most abundant alleles."""
     df = _small_table()
+    monkeypatch.delenv("BEAN_MAX_ALLELES_PER_GUIDE", raising=False)
+    with pytest.raises(ValueError, match="bean filter"):
+        alleles.build_allele_tensors(df, ["g1", "g2"], max_alleles=3)
+    monkeypatch.setenv("BEAN_MAX_ALLELES_PER_GUIDE", "3")
     with pytest.warns(UserWarning, match="most abundant alleles"):
-        at = alleles.build_allele_tensors(df, ["g1", "g2"], max_alleles=3)
+        at = alleles.build_allele_tensors(df, ["g1", "g2"])
     assert at.n_max_alleles == 3 and at.n_dropped == 1  # g1's rarest allele (total 1) is folded away
     assert "50:A>G" in at.edit_index and len(at.reindexed) == 4
 
@@ -77,25 +84,24 @@ def test_cap_keeps_the_most_abundant_alleles():
 def test_tiling_mini_screen_builds_consistent_tensors():
     s = read_h5ad(TILING)
     s.samples["replicate"] = s.samples["replicate"].astype(str)
-    with pytest.warns(UserWarning, match="most abundant alleles"):
-        d = DATACLASS_DICT["sorting"]["MultiMixtureNormal"](
-            s, sample_mask_column=None, allele_df_key="allele_counts", control_condition="bulk")
-    assert (d.n_reps, d.n_condits, d.n_guides, d.n_max_alleles) == (2, 5, 30, 16)
+    d = DATACLASS_DICT["sorting"]["MultiMixtureNormal"](
+        s, sample_mask_column=None, allele_df_key="allele_counts", control_condition="bulk")
+    # the unfiltered table: up to 230 edited alleles per guide, kept as they are
+    assert (d.n_reps, d.n_condits, d.n_guides, d.n_max_alleles) == (2, 5, 30, 231) and d.n_alleles_dropped == 0
     assert d.n_edits == len(d.edit_index) == d.n_targets and d.n_edits > 20
     d.validate()
     # alleles partition the barcode-matched reads
     assert torch.equal(d.allele_counts.sum(-1), d.X_bcmatch)
     assert torch.equal(d.allele_counts_control.sum(-1), d.X_bcmatch_control)
-    assert d.allele_counts_control.shape == (2, 1, 30, 16) and d.pi_a0.shape == (30,)
+    assert d.allele_counts_control.shape == (2, 1, 30, 231) and d.pi_a0.shape == (30,)
     # the dense view agrees with a direct parse of the kept rows
     dense = d.allele_to_edit_dense()
-    assert dense.shape == (30, 15, d.n_edits) and set(np.unique(dense.numpy())) <= {0.0, 1.0}
+    assert dense.shape == (30, 230, d.n_edits) and set(np.unique(dense.numpy())) <= {0.0, 1.0}
     tbl = s.uns["allele_counts"]
     tot = tbl[[c for c in tbl.columns if c.startswith("rep")]].sum(axis=1)
     g0 = s.guides.index[0]
-    top = tbl.loc[tbl.guide == g0].assign(t=tot[tbl.guide == g0]).sort_values("t", ascending=False, kind="stable")
     kept = set()
-    for a in top["allele"].head(15):
+    for a in tbl.loc[tbl.guide == g0, "allele"]:
         kept.update(alleles.allele_edits(a))
     got = {e for e, j in d.edit_index.items() if dense[0, :, j].sum() > 0}
     assert got == kept

@@ -78,7 +78,9 @@ def _shape(**kw):
 @pytest.mark.parametrize("kw,msg", [
     (dict(family=7), "family"),
     (dict(selection=2), "selection"),
-    (dict(family=3, n_max_alleles=9, n_edits=2, n_targets=2), "n_max_alleles"),
+    (dict(family=3, n_max_alleles=300, n_edits=2, n_targets=2), "n_max_alleles"),
+    (dict(n_sample_covariates=2), "sample covariates"),
+    (dict(family=0, n_sample_covariates=100), "n_sample_covariates"),
     (dict(family=3, n_max_alleles=4, n_edits=3, n_targets=2), "n_targets == n_edits"),
     (dict(n_condits=9), "n_condits"),
     (dict(n_guides=0), ">= 1"),

@@ -424,16 +424,61 @@ def test_tiling_screen_built_from_h5ad_matches_oracle(engine):
     from bean_amd.framework import h5ad_io, read_h5ad
     from bean_amd.preprocessing.screen_data import DATACLASS_DICT
 
-    if not os.path.exists(h5ad_io.HELPER_PYTHON):
-        pytest.skip("no h5py interpreter")
+    assert os.path.exists(h5ad_io.HELPER_PYTHON), "no h5py helper interpreter: .h5ad screens cannot be read here"
     s = read_h5ad(os.path.join(os.path.dirname(__file__), "golden", "tiling_mini_screen.h5ad"))
     s.samples["replicate"] = s.samples["replicate"].astype(str)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         data = DATACLASS_DICT["sorting"]["MultiMixtureNormal"](
             s, sample_mask_column=None, allele_df_key="allele_counts", control_condition="bulk")
-    assert data.n_max_alleles == 16 and data.n_guides == 30  # fitted by libbean_hip_a16.so
+    # the unfiltered table: up to 230 edited alleles per guide, kept as they are and fitted by the
+    # allele-parallel kernels (csrc/bean_tiling_wide.hpp)
+    assert data.n_max_alleles == 231 and data.n_guides == 30 and data.n_alleles_dropped == 0
     _compare_tiling(engine, data, {})
+
+
+@pytest.mark.parametrize("gen_kw,kw", [
+    (dict(n_guides=150, n_reps=3, n_max_alleles=20, mask_fraction=0.05), {}),
+    (dict(n_guides=70, n_reps=2, n_max_alleles=40, with_accessibility=True), dict(scale_by_accessibility=True)),
+    (dict(n_guides=40, n_reps=2, n_max_alleles=100), {}),  # two alleles per lane
+    (dict(n_guides=65, n_reps=1, n_max_alleles=17, bins=tuple((i / 10, (i + 1) / 10) for i in range(10))), {}),
+])
+def test_wide_tiling_matches_oracle(engine, gen_kw, kw):
+    """More alleles per guide than the register-resident kernels hold (16): the allele-parallel path
+    (one wave per (replicate, guide), lanes over alleles), against the same oracle."""
+    data = make_sorting_tiling_screen(seed=14, **gen_kw)
+    assert data.n_max_alleles == gen_kw["n_max_alleles"]
+    _compare_tiling(engine, data, kw)
+
+
+def test_wide_tiling_trajectory_fused_loop_and_shards(engine):
+    data = make_sorting_tiling_screen(120, 2, seed=15, n_max_alleles=24)
+    n = 12
+    eng = engine.HipSVI("MultiMixtureNormal", data.to(DEV), dump_noise=True, num_steps=2000)
+    assert eng.dominant_kernel == "k_guide_tiling_wide"
+    params = elbo.init_params("MultiMixtureNormal", data)
+    optim = svi.ClippedAdam(params, lr=0.01, lrd=0.1 ** (1 / 2000))
+    for t in range(n):
+        loss, _ = eng.elbo_grad(step=t, seed=5, loss_index=t)
+        draws = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+        eng.adam(t + 1)
+        ref = svi.svi_step(elbo.multi_mixture_normal_loss, data, params, optim, noise=draws)
+        assert abs(loss - ref) <= 2e-6 * abs(ref), (t, loss, ref)
+    torch.cuda.synchronize()
+    for k, v in eng.unconstrained.items():
+        ref = params[k].detach()
+        err = (v.cpu() - ref).abs().max().item()
+        assert err <= 1e-4 * max(1.0, ref.abs().max().item()), (k, err)
+    fused = engine.HipSVI("MultiMixtureNormal", data.to(DEV), num_steps=2000)
+    fused.run(n, seed=5, graph_chunk=4)
+    for k in eng.unconstrained:
+        assert torch.equal(eng.unconstrained[k], fused.unconstrained[k]), k
+    longer = engine.HipSVI("MultiMixtureNormal", data.to(DEV), num_steps=300)
+    longer.run(300)
+    ls = longer.losses()
+    assert np.isfinite(ls).all() and ls[-1] < ls[0]
+    for e in (eng, fused, longer):
+        e.close()
 
 
 def test_tiling_trajectory_and_fused_loop(engine):
@@ -663,6 +708,7 @@ def _compare_survival_tiling(engine, data, kw, seed=7, step=2):
     (dict(n_guides=300, n_reps=2, with_accessibility=True, n_max_alleles=5), dict(scale_by_accessibility=True)),
     (dict(n_guides=130, n_reps=4, n_max_alleles=3, times=(0.0, 3.0, 6.0, 9.0, 12.0)), {}),
     (dict(n_guides=200, n_reps=2, n_max_alleles=8), dict(mu_negctrl=(0.05, 0.2))),
+    (dict(n_guides=90, n_reps=2, n_max_alleles=30), {}),  # allele-parallel path
 ])
 def test_survival_tiling_matches_oracle(engine, gen_kw, kw):
     data = make_survival_tiling_screen(seed=11, **gen_kw)
