@@ -113,6 +113,7 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_XCHG_SQ: return is_surv_normal(s) ? 8 * R : 0;
         case BEAN_BUF_XCHG_TGRAD: return 8 * 2 * T;
         case BEAN_BUF_EPS_U_IN: case BEAN_BUF_EPS_U_OUT: return (is_survival(s) && is_mixture(s)) ? 8 * G : 0;
+        case BEAN_BUF_PRIOR_IA: return (is_surv_normal(s) && s.prior_ia_total > 0.0) ? 8 * G : 0;
         case BEAN_BUF_TARGET_OFFSETS: return is_tiling(s) ? 0 : 4 * (T + 1);
         case BEAN_BUF_GUIDE_TO_TARGET: return is_tiling(s) ? 0 : 4 * G;
         case BEAN_BUF_A2E_PTR: return is_tiling(s) ? 4 * (G * (A - 1) + 1) : 0;
@@ -180,6 +181,8 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.time = (const double*)P(BEAN_BUF_TIMEPOINTS);
     d.negctrl = (const uint8_t*)P(BEAN_BUF_NEGCTRL_MASK);
     d.rbc = (const double*)P(BEAN_BUF_REP_BY_COV);
+    d.prior_ia = (const double*)P(BEAN_BUF_PRIOR_IA);
+    d.prior_ia_total = c->shape.prior_ia_total;
     if (P(BEAN_BUF_XCHG_GSUM)) d.gsum = (double*)P(BEAN_BUF_XCHG_GSUM);
     else d.gsum = c->gsum_ws;
     if (P(BEAN_BUF_XCHG_SQ)) d.sq = (double*)P(BEAN_BUF_XCHG_SQ);
@@ -308,6 +311,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->tiling_wide = is_tiling(*s) && s->n_max_alleles > kAMax;
     c->tiling_wave = c->tiling_wave && is_tiling(*s) && !c->tiling_wide;
     d.wide_alleles = c->tiling_wide ? 1 : 0;
+    d.trow_summed = c->tiling_wave ? 1 : 0;
     const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G
                                            : (c->tiling_wide ? (uint64_t)tq_num(d.A) * Rr * G : 0);
     const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G
@@ -487,6 +491,7 @@ static int check_bound(bean_hip_ctx* c, bool need_grads, bool need_moments) {
     if (is_mixture(s)) { REQ(BEAN_BUF_ALLELE_CTRL); REQ(BEAN_BUF_PI_A0); }
     if (s.flags & BEAN_FLAG_SCALE_BY_ACC) REQ(BEAN_BUF_ACCESSIBILITY);
     if (s.n_sample_covariates > 0) REQ(BEAN_BUF_REP_BY_COV);
+    if (is_surv_normal(s) && s.prior_ia_total > 0.0) REQ(BEAN_BUF_PRIOR_IA);
     for (int i = 0; i < 8; ++i) {
         if (expected_bytes(s, BEAN_BUF_P_MU_LOC + i) == 0) continue;
         REQ(BEAN_BUF_P_MU_LOC + i);
@@ -734,6 +739,7 @@ static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
         if (acc) hipLaunchKernelGGL((k_guide_tiling_wave<true, false>), grid, block, lds, stream, d);
         else hipLaunchKernelGGL((k_guide_tiling_wave<false, false>), grid, block, lds, stream, d);
     }
+    hipLaunchKernelGGL(k_sum_trow, dim3((d.G + 255) / 256, kTNumPart), dim3(256), 0, stream, d);
 }
 
 // survival variant families, one wave per (guide tile, replicate) (bean_survival_v2.hpp)

@@ -105,6 +105,11 @@ struct DevArgs {
     const double* rbc;                 // (R, n_cov) design matrix
     double *cov_mu, *cov_eps;          // (n_cov) current draw
     double *cov_shift, *cov_sum;       // (R) shift of replicate r; sum_g of its d nll / d mu rows
+    // survival NormalModel: prior_params["initial_abundance"] (survival_model.py:38-49): per-guide prior
+    // concentration of the Dirichlet-over-guides site and its sum over the WHOLE screen; null: ones / G
+    const double* prior_ia;
+    double prior_ia_total;
+    int trow_summed;                   // k_sum_trow has reduced trow into part
     int wide_alleles;                  // tiling with more alleles per guide than kAMax: bean_tiling_wide.hpp
     double* dgq;
     double* dgq_t;                     // tiling: (kAMax + 1, G) digamma(c_q[a]) rows and digamma(sum c_q), same contract
@@ -278,11 +283,11 @@ __device__ __forceinline__ double part_row(const DevArgs& c, int q, int g) {
     for (int r = 0; r < c.R; ++r) s += c.wrow[((long)q * c.R + r) * c.G + g];
     return s;
 }
-// tiling: row q of guide g summed over the replicates in fixed order - straight from the wave kernels'
-// per-replicate rows (trow) when they exist (no separate reduction launch and no round trip through
-// `part`), else from `part` (block form)
+// tiling: row q of guide g summed over the replicates in fixed order: from `part` (block form, or the
+// wave form after k_sum_trow - measured faster than R strided reads per row inside k_param), or straight
+// from the per-replicate rows (the allele-parallel path, which has no separate reduction launch)
 __device__ __forceinline__ double trow_sum(const DevArgs& c, int q, long g) {
-    if (!c.trow) return c.part[(long)q * c.G + g];
+    if (!c.trow || c.trow_summed) return c.part[(long)q * c.G + g];
     double s = 0.0;
     for (int r = 0; r < c.R; ++r) s += c.trow[((long)q * c.R + r) * c.G + g];
     return s;
@@ -1120,13 +1125,13 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
             if (ADAM) iau = c.p[7][g];
             // normalisers: + log q: R (lgamma(tot) - sum lgamma(ia)); - log p: the prior
             // concentration is the float32 value of 1 / G on every guide (torch.ones(G) / G)
-            const double pr = (double)(1.0f / (float)c.G_tot);
+            const double pr = c.prior_ia ? c.prior_ia[g] : (double)(1.0f / (float)c.G_tot);
             double lg_p, dg_p;
             lgamma_digamma(pr, lg_p, dg_p);
             loss_fin += Rf * (lg_p - lg_a);
             if (c.g_off + g == 0) {  // once per screen (guide 0 of the whole screen)
                 double lg_ps, dg_ps;
-                lgamma_digamma(pr * (double)c.G_tot, lg_ps, dg_ps);
+                lgamma_digamma(c.prior_ia ? c.prior_ia_total : pr * (double)c.G_tot, lg_ps, dg_ps);
                 loss_fin += Rf * (lg_tot - lg_ps);
             }
         }
@@ -2130,7 +2135,7 @@ void k_guide_survival(DevArgs c) {
             if (q0lik) {
                 gmu = negc ? 0.0 : dmu * x0;
                 // - log p(q_0) + log q(q_0): (ia - 1/G) log x per guide; normalisers in k_param
-                const double dconc = ia - (double)(1.0f / (float)c.G_tot);
+                const double dconc = ia - (c.prior_ia ? c.prior_ia[g] : (double)(1.0f / (float)c.G_tot));
                 const double lx = flog(x0);
                 nll += dconc * lx;
                 c.gq[(long)r * G + g] = g1 + dconc * frcp(x0);
@@ -2635,7 +2640,7 @@ void k_guide_tiling(DevArgs c) {
 // nothing lives in scratch.  Per-allele state is two register arrays (pi, d loss / d pi) walked by
 // fully unrolled loops; everything indexed by the bin b is a thread-private LDS column walked by
 // rolled loops: e[b], d nll / d e[b], the digamma differences of the current likelihood, the counts.
-// The per-replicate rows go to trow[(q, r, g)]; k_param adds the replicates up where it reads them (trow_sum).
+// The per-replicate rows go to trow[(q, r, g)]; k_sum_trow adds the replicates into `part`.
 // dynamic LDS: (3 B [+ 3 kAMax if ACC]) * 64 doubles + 2 B * 64 floats.
 template <bool ACC, bool SURV>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
@@ -2935,6 +2940,23 @@ void k_guide_tiling_wave(DevArgs c) {
         loss_add(c, ctr.slot, tot);
         if (wg == 0) publish_ctr(c, ctr);
     }
+}
+
+// part[q, g] = sum_r trow[q, r, g] for the rows of the alleles that exist (fixed order)
+__global__ __launch_bounds__(256) void k_sum_trow(DevArgs c) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;
+    if (g >= c.G) return;
+    const int A = c.A;
+    bool used = q == kTGnoise || q == kTNrg;
+    if (q >= kTPath && q < kTPath + kAMax) used = q - kTPath < A;
+    if (q >= kTL && q < kTL + kAMax) used = q - kTL < A;
+    if (q >= kTGmu && q < kTGmu + kAMax - 1) used = q - kTGmu < A - 1;
+    if (q >= kTGsig) used = q - kTGsig < A - 1;
+    if (!used) return;
+    double s = 0.0;
+    for (int r = 0; r < c.R; ++r) s += c.trow[((long)q * c.R + r) * c.G + g];
+    c.part[(long)q * c.G + g] = s;
 }
 
 // ------------------------------------------------------------------ one-offs

@@ -242,7 +242,7 @@ void k_guide_survival_wave(DevArgs c) {
             // survival NormalModel: - log p(q_0) + log q(q_0) = (ia - 1/G) log x per guide (normalisers
             // in k_param); d loss / d q_0 for the pathwise gradient of the G-dimensional Dirichlet
             const double ia = (double)expf(p7);
-            const double dconc = ia - (double)(1.0f / (float)c.G_tot);
+            const double dconc = ia - (c.prior_ia ? c.prior_ia[g] : (double)(1.0f / (float)c.G_tot));
             const double lx = flog(x0);
             nll += dconc * lx;
             c.gq[rgi] = g1 + dconc * frcp(x0);

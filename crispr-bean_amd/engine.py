@@ -68,8 +68,6 @@ class HipSVI:
         survival = getattr(data, "selection", "sorting") == "survival"
         surv_normal = survival and family == "Normal"
         self.surv_normal = surv_normal
-        if surv_normal and prior_params is not None and "initial_abundance" in prior_params:
-            raise NotImplementedError("prior_params['initial_abundance'] is not supported by the HIP engine")
         self.survival = survival
         if not torch.cuda.is_available():
             raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
@@ -153,6 +151,18 @@ class HipSVI:
         self.prior_params = prior_params
         if prior_params is not None and ("mu_loc" in prior_params or "mu_scale" in prior_params):
             flags |= _lib.FLAG_PRIOR_NORMAL_MU
+        # survival NormalModel: prior_params["initial_abundance"] replaces the ones / G prior concentration of
+        # the Dirichlet-over-guides site (survival_model.py:38-49); float32 values as the reference holds them
+        prior_ia, prior_ia_total = None, 0.0
+        if surv_normal and prior_params is not None and "initial_abundance" in prior_params:
+            full = torch.as_tensor(prior_params["initial_abundance"]).detach().cpu().to(torch.float32).double().reshape(-1)
+            g_all = int(n_guides_total) if n_guides_total else G
+            if full.numel() != g_all:
+                raise ValueError(f"prior_params['initial_abundance'] has {full.numel()} entries for {g_all} guides")
+            if not bool((full > 0).all()):
+                raise ValueError("prior_params['initial_abundance'] must be positive")
+            prior_ia = full[int(guide_offset): int(guide_offset) + G]
+            prior_ia_total = float(full.sum())
         self.num_steps = int(num_steps)
         self.lrd = float(gamma) ** (1.0 / self.num_steps)
         self.initial_lr = float(initial_lr)
@@ -169,6 +179,7 @@ class HipSVI:
             initial_lr=self.initial_lr, lrd=self.lrd, clip_norm=10.0,
             negctrl_loc=float(mu_negctrl[0]), negctrl_scale=float(mu_negctrl[1]),
             n_sample_covariates=self.n_cov,
+            prior_ia_total=prior_ia_total,
         )
         self._shape = shape
         handle = ctypes.c_void_p()
@@ -234,6 +245,8 @@ class HipSVI:
         if mixture:
             self._bind("ALLELE_CTRL", f32(data.allele_counts_control))
             self._bind("PI_A0", f64(data.pi_a0))
+        if prior_ia is not None:
+            self._bind("PRIOR_IA", f64(prior_ia))
         if self.n_cov:
             self._bind("REP_BY_COV", f64(torch.as_tensor(data.rep_by_cov).reshape(R, self.n_cov)))
         if acc:

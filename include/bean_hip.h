@@ -101,6 +101,10 @@ typedef struct bean_hip_shape {
      * which this family does not otherwise use. */
     int32_t n_sample_covariates;
     int32_t reserved_;
+    /* survival NormalModel with prior_params["initial_abundance"] (survival_model.py:38-49): sum of that
+     * per-guide prior concentration over the WHOLE screen (0 = the default prior ones / G); the per-guide
+     * values of this shard go in BEAN_BUF_PRIOR_IA */
+    double prior_ia_total;
 } bean_hip_shape;
 
 /* Buffer slots.  dtype / shape in brackets; "opt" = only for some families. */
@@ -194,6 +198,8 @@ enum bean_hip_buf {
     BEAN_BUF_EPS_U_IN,        /* f64 (G)   survival: mu_negctrl standard normals opt  */
     BEAN_BUF_X0_OUT,          /* f64 (R,G)                                       opt  */
     BEAN_BUF_EPS_U_OUT,       /* f64 (G)                                         opt  */
+    BEAN_BUF_PRIOR_IA,        /* f64 (G)   survival NormalModel: prior concentration of the Dirichlet-over-guides
+                                 site, prior_params["initial_abundance"]                      opt  */
     /* ---- loss */
     BEAN_BUF_LOSS_HIST = 112, /* f64 (capacity) one entry per SVI step                */
     BEAN_BUF_COUNT = 128

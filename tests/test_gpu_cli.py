@@ -71,10 +71,9 @@ def test_sorting_variant_with_accessibility_track(tmp_path, extra, label):
 
 def test_sorting_tiling_with_accessibility_track(tmp_path):
     """tests/test_run.py:85,124: tiling with `--scale-by-acc --acc-bw-path`."""
-    with pytest.warns(UserWarning, match="most abundant alleles"):
-        d = _run(tmp_path, "sorting", "tiling", TILING, "--n-iter", "10", "--repguide-mask", "None",
-                 "--allele-df-key", "allele_counts", "--control-guide-tag", "None", "--scale-by-acc",
-                 "--acc-bw-path", os.path.join(GOLD, "accessibility_signal.bw"))
+    d = _run(tmp_path, "sorting", "tiling", TILING, "--n-iter", "10", "--repguide-mask", "None",
+             "--allele-df-key", "allele_counts", "--control-guide-tag", "None", "--scale-by-acc",
+             "--acc-bw-path", os.path.join(GOLD, "accessibility_signal.bw"))
     el = pd.read_csv(f"{d}/bean_element_result.MultiMixtureNormal+Acc.csv")
     assert len(el) > 20 and np.isfinite(el[["mu", "mu_sd", "mu_z", "sd"]].values).all()
 
@@ -125,13 +124,12 @@ def test_survival_variant_runs(tmp_path, extra):
 def test_sorting_tiling_runs(tmp_path, extra, label):
     """The reference's `bean run sorting tiling` invocations (tests/test_run.py:85-150, 218) on its
     tiling mini-screen with the unfiltered allele table (`--allele-df-key allele_counts`): up to 230
-    alleles per guide there, reduced to the 7 most abundant per guide with a warning."""
+    alleles per guide there, all kept (allele-parallel kernels)."""
     argv = ["sorting", "tiling", TILING, "--n-iter", "10", "--repguide-mask", "None",
             "--allele-df-key", "allele_counts"]
     if "--control-guide-tag" not in extra:
         argv += ["--control-guide-tag", "None"]
-    with pytest.warns(UserWarning, match="most abundant alleles"):
-        d = _run(tmp_path, *argv, *extra)
+    d = _run(tmp_path, *argv, *extra)
     el = pd.read_csv(f"{d}/bean_element_result.{label}.csv")
     sg = pd.read_csv(f"{d}/bean_sgRNA_result.{label}.csv")
     assert len(sg) == 30
@@ -154,8 +152,7 @@ def test_survival_tiling_runs(tmp_path, extra):
     the data file but no test invocation for it)."""
     argv = ["survival", "tiling", SURV_TILING, "--n-iter", "10", "--repguide-mask", "None",
             "--allele-df-key", "allele_counts", "--control-guide-tag", "None", "--control-condition=D7"]
-    with pytest.warns(UserWarning, match="most abundant alleles"):
-        d = _run(tmp_path, *argv, *extra)
+    d = _run(tmp_path, *argv, *extra)
     el = pd.read_csv(f"{d}/bean_element_result.MultiMixtureNormal.csv")
     sg = pd.read_csv(f"{d}/bean_sgRNA_result.MultiMixtureNormal.csv")
     assert len(sg) == 30 and len(el) > 20 and "sd" not in el.columns

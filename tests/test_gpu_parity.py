@@ -596,6 +596,17 @@ def test_survival_normal_matches_oracle(engine, gen_kw, drop_idx):
     _compare_survival(engine, "Normal", data, {})
 
 
+def test_survival_normal_with_initial_abundance_prior(engine):
+    """prior_params["initial_abundance"] (survival_model.py:38-49): a per-guide prior concentration of the
+    Dirichlet-over-guides site instead of ones / G."""
+    data = make_survival_variant_screen(400, 3, seed=10)
+    g = torch.Generator().manual_seed(2)
+    prior = {"initial_abundance": (torch.rand(400, generator=g) + 0.2) / 400,
+             "mu_loc": torch.randn((data.n_targets, 1), generator=g) * 0.1,
+             "mu_scale": torch.rand((data.n_targets, 1), generator=g) + 0.5}
+    _compare_survival(engine, "Normal", data, dict(prior_params=prior))
+
+
 def test_survival_normal_trajectory_and_fused_loop(engine):
     data = make_survival_variant_screen(600, 3, seed=9, frac_effect=0.5)
     n = 12
