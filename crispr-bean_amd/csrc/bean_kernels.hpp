@@ -2285,22 +2285,37 @@ __global__ __launch_bounds__(256) void k_allele(DevArgs c) {
     c.sig_a[idx] = sigma;
     const bool live = valid && var > 0.0;  // masked alleles: probability 0, no gradient (utils.py:56-59,73-74)
     const double inv = live ? 1.0 / sigma : 0.0;
+    // bins are sorted by their bounds (data_class.py:948-964), so a bin's lower edge is very often the
+    // previous bin's upper edge: its Phi / phi are reused instead of evaluated twice (same values)
+    double pz = 0.0, pch = 0.0, pfh = 0.0, pufh = 0.0;
+    bool have_prev = false;
     for (int b = 0; b < c.B; ++b) {
         double P = 0.0, dmu = 0.0, dsig = 0.0;
         if (live) {
             const double zh = c.z_hi[b], zl = c.z_lo[b];
             double ch = 1.0, cl = 0.0, fh = 0.0, fl = 0.0, ufh = 0.0, ufl = 0.0;
+            if (!isinf(zl)) {
+                if (have_prev && zl == pz) {
+                    cl = pch;
+                    fl = pfh;
+                    ufl = pufh;
+                } else {
+                    const double u = (zl - mu) * inv;
+                    cl = norm_cdf(u);
+                    fl = norm_pdf(u);
+                    ufl = u * fl;
+                }
+            }
             if (!isinf(zh)) {
                 const double u = (zh - mu) * inv;
                 ch = norm_cdf(u);
                 fh = norm_pdf(u);
                 ufh = u * fh;
-            }
-            if (!isinf(zl)) {
-                const double u = (zl - mu) * inv;
-                cl = norm_cdf(u);
-                fl = norm_pdf(u);
-                ufl = u * fl;
+                pz = zh;
+                pch = ch;
+                pfh = fh;
+                pufh = ufh;
+                have_prev = true;
             }
             P = ch - cl;
             dmu = -(fh - fl) * inv;

@@ -151,6 +151,35 @@ def test_empty_rank_is_an_error():
     assert [s[1] - s[0] for s in shards].count(0) == 2
 
 
+def _empty_shard_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = make_sorting_variant_screen(6, 2, seed=9, guides_per_target=3)  # 2 targets for 3 ranks
+    made = []
+
+    def factory(shard_data, shard, n_total, **extra):
+        made.append(shard)
+        raise AssertionError("no engine may be built when a rank has no guides")
+
+    try:
+        parallel.run_sharded(factory, data, 3)
+        outcome = "returned"
+    except ValueError as exc:
+        outcome = "ValueError" if "no guides" in str(exc) else f"other: {exc}"
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
+        fh.write(f"{outcome} {len(made)}")
+    dist.destroy_process_group()
+
+
+def test_every_rank_raises_when_one_shard_is_empty(tmp_path):
+    """Fewer targets than ranks: ALL ranks raise before any engine or collective exists (a rank that
+    raised alone would leave the others waiting in an all-reduce until the backend's timeout)."""
+    world = 3
+    mp.spawn(_empty_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ValueError 0"
+
+
 # ------------------------------------------------- exchange families (tiling, survival)
 class ExchangeEngine:
     """Minimal stand-in with the interface of a HipSVI whose family needs per-step exchanges: the
