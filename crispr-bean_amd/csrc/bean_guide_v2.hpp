@@ -275,18 +275,33 @@ void k_guide_wave2(DevArgs c) {
             const double ai = a0 * inv;
             // loop 1: the lgamma / digamma differences; digamma differences parked in LDS
             double A0 = 0.0, lsum = 0.0;
+            bool floored = false;
 #pragma unroll 1
             for (int b = 0; b < B; ++b) {
                 const double x = (double)xp[b * 64];
                 const double araw = alpha_raw(w0, MIX ? c_p0[b] : 0.0, w1, tp[b * ntm], sf[b], epsB, ai * c_sm[b]);
                 const double alpha = araw < kEps ? kEps : araw;
+                floored = floored || araw < kEps;
                 A0 += alpha;
                 const DD db = gw_lgamma_diff(alpha, x);
                 lsum += db.d;
                 dps[b * 64] = db.dp;
             }
             if (lik == 0) BEAN_STAMP_AT(3);
-            const DD d0 = gw_lgamma_diff(A0, nn);
+            // total term lgamma(A0 + n) - lgamma(A0): data unless a bin sits on its floor
+            // (DevArgs::tot_const); a lane's arithmetic does not depend on its wave's other lanes
+            DD d0;
+            d0.d = 0.0;
+            d0.dp = 0.0;
+            if (!c.tot_const) {
+                d0 = lgamma_digamma_diff(A0, nn);
+            } else if (__any(floored)) {
+                const DD dt = lgamma_digamma_diff(A0, nn), dc = lgamma_digamma_diff(a0, nn);
+                if (floored) {
+                    d0.d = dt.d - dc.d;
+                    d0.dp = dt.dp;
+                }
+            }
             nll += d0.d - lsum;
             // loop 2: with ga_b = d0.dp - dpsi_b (0 where alpha_b sits on its floor) and
             // k_b = a0 m_b inv sf_b:  S_Q = sum ga_b k_b Q_b,  t_Q = sum sf_b Q_b,

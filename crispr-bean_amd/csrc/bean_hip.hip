@@ -308,10 +308,15 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.n_cov = s->n_sample_covariates;
     c->surv_wave = c->surv_wave && is_survival(*s) && !is_tiling(*s);
     d.rows_v2 = (c->wave2 || c->surv_wave) ? 1 : 0;
+
     c->tiling_wide = is_tiling(*s) && s->n_max_alleles > kAMax;
     c->tiling_wave = c->tiling_wave && is_tiling(*s) && !c->tiling_wide;
     d.wide_alleles = c->tiling_wide ? 1 : 0;
     d.trow_summed = c->tiling_wave ? 1 : 0;
+    {
+        const char* tc = getenv("BEAN_HIP_TOT_CONST");  // =0: the total terms are evaluated every step (A/B)
+        d.tot_const = ((c->wave2 || c->surv_wave || c->tiling_wave || c->tiling_wide) && !(tc && !strcmp(tc, "0"))) ? 1 : 0;
+    }
     const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G
                                            : (c->tiling_wide ? (uint64_t)tq_num(d.A) * Rr * G : 0);
     const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G

@@ -116,6 +116,11 @@ struct DevArgs {
     long long* lpart;                  // (n_lpart, 3) per-wave loss parts of the wave-form guide kernels, or null
     int n_lpart;
     int rows_v2;                       // wrow holds the five rows of k_guide_wave2 (bean_guide_v2.hpp)
+    // 1: the guide kernel leaves the total term lgamma(A0 + n) - lgamma(A0) of a Dirichlet-Multinomial
+    // site to the constant wherever no bin sits on its floor: get_alpha normalises, so there
+    // A0 = sum_b alpha_b = a0[g] is data (k_prepare adds the term once) and its derivative multiplies
+    // sum_b d alpha_b = 0.  A (replicate, guide) with a floored bin adds the difference to that constant.
+    int tot_const;
     // workspace
     double *tabP, *tabPmu, *tabPy;     // (B, T)
     double* P0;                        // (B)
@@ -659,6 +664,29 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
 #elif BEAN_KP_DIAG == 2  // ... or the guide part alone
     if ((int)blockIdx.x < n_target_blocks && blockIdx.x != 0) return;
 #endif
+#ifdef BEAN_STAMP
+    const int lane = threadIdx.x & 63;
+    const long wave_gid = (long)blockIdx.x * (kParamBlock / 64) + (threadIdx.x >> 6);
+#endif
+#ifdef BEAN_KP_SPECIAL  // experiment: what does the code of the other families cost this one?
+    __builtin_assume(c.family == kMixture);
+    __builtin_assume(!c.survival);
+    __builtin_assume(c.tgrad == nullptr);
+    __builtin_assume(!c.wide_targets);
+    __builtin_assume(c.n_cov == 0);
+    __builtin_assume(c.flags == 0);
+    __builtin_assume(c.pr_sd_loc == nullptr);
+    __builtin_assume(c.pr_sd_scale == nullptr);
+    __builtin_assume(c.eps_mu_in == nullptr);
+    __builtin_assume(c.eps_mu_out == nullptr);
+    __builtin_assume(c.dgq != nullptr);
+    __builtin_assume(c.wrow != nullptr);
+    __builtin_assume(c.rows_v2);
+    __builtin_assume(!c.surv_q0lik);
+    __builtin_assume(!c.not_loss_owner);
+    __builtin_assume(c.lpart != nullptr);
+#endif
+    BEAN_STAMP_AT(0);
     const StepCtr ctr = *c.ctrA;
     const unsigned long long s_fin = ctr.step;
     const unsigned long long s_prep = FINISH ? ctr.step + 1 : ctr.step;
@@ -728,6 +756,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 }
             }
         }
+        BEAN_STAMP_AT(1);
         if (active && c.survival) {
             // survival families: mu only (no sd latent), growth tables are computed in k_guide_survival
             float pl = c.p[0][t], psu = c.p[1][t];
@@ -812,6 +841,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 emit_grad_pre<ADAM>(c, 2, t, Gy - 1.0, ak, pf[2], mf[2], vf[2]);
                 emit_grad_pre<ADAM>(c, 3, t, Gy * eps2 * s_sd - 1.0 - eps2 * s_sd, ak, pf[3], mf[3], vf[3]);
             }
+            BEAN_STAMP_AT(2);
             if (PREP) {
                 double eps1, eps2;
                 if (c.eps_mu_in) {
@@ -839,6 +869,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 tab_y = y;
             }
         }
+        BEAN_STAMP_AT(3);
         // ---- Phi tables: the B entries of a target are spread over the lanes of its group
         // (thin mode: kLanesPerTarget consecutive lanes; wide mode: the block's first threads)
         if (PREP && !c.survival && c.family != kMultiMixture) {
@@ -900,6 +931,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 }
             }
         }
+        BEAN_STAMP_AT(4);
     } else if (c.family == kMultiMixture) {
         if (c.wide_alleles) param_guide_tiling_wide<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
         else param_guide_tiling<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
@@ -1037,6 +1069,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                         gc[a] = -nrg * (dgS_p - dg_p[a]) + (cl[a] ? 0.0 : Rf * (dgS_q - dg_q[a])) + GA_[a];
                 }
                 loss_fin = -lp + lq;
+                BEAN_STAMP_AT(1);
                 const double dot = (gc[0] * al0 + gc[1] * al1) / s;
                 emit_grad<ADAM>(c, 4, 2 * g, pa0 / s * (gc[0] - dot) * al0, ak);
                 emit_grad<ADAM>(c, 4, 2 * g + 1, pa0 / s * (gc[1] - dot) * al1, ak);
@@ -1076,6 +1109,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
                 if (c.eps_noise_out) c.eps_noise_out[g] = eps;
             }
+            BEAN_STAMP_AT(2);
             if (PREP && c.dgq) {
                 // lgamma / digamma of the guide-side concentrations of the (updated) alpha_pi, for
                 // the next guide kernel and the next FINISH
@@ -1095,6 +1129,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 c.dgq[4 * Gl + g] = dg0;
                 c.dgq[5 * Gl + g] = dg1;
             }
+            BEAN_STAMP_AT(4);
         }
     }
     if (c.surv_q0lik && (int)blockIdx.x >= n_target_blocks) {
@@ -1223,6 +1258,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         }
     }
     (void)loss_prep;
+    BEAN_STAMP_AT(7);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         StepCtr nxt;
         nxt.step = s_prep;
@@ -2816,10 +2852,12 @@ void k_guide_tiling_wave(DevArgs c) {
                 const double a0 = lik ? c.a0_bc[g] : c.a0[g];
                 const double inv = frcp(S + kEps);
                 double A0 = 0.0, lsum = 0.0, Ua = 0.0, Va = 0.0;
+                bool anyfl = false;
 #pragma unroll 1
                 for (int b = 0; b < B; ++b) {
                     const double araw = (es[b * 64] * uniform_ld(sf, b) + epsB) * inv * a0 * uniform_ld(sm, b);
                     const bool floored = araw < kEps;
+                    anyfl = anyfl || floored;
                     const double al = floored ? kEps : araw;
                     A0 += al;
                     const DD db = lgamma_digamma_diff_inl(al, (double)xp[b * 64]);
@@ -2828,7 +2866,19 @@ void k_guide_tiling_wave(DevArgs c) {
                     Ua += floored ? 0.0 : araw;
                     Va += floored ? 0.0 : db.dp * araw;
                 }
-                const DD d0 = lgamma_digamma_diff_inl(A0, nn);
+                // total term: data unless a bin sits on its floor (DevArgs::tot_const)
+                DD d0;
+                d0.d = 0.0;
+                d0.dp = 0.0;
+                if (!c.tot_const) {
+                    d0 = lgamma_digamma_diff(A0, nn);
+                } else if (__any(anyfl)) {
+                    const DD dt = lgamma_digamma_diff(A0, nn), dc = lgamma_digamma_diff(a0, nn);
+                    if (anyfl) {
+                        d0.d = dt.d - dc.d;
+                        d0.dp = dt.dp;
+                    }
+                }
                 nll += d0.d - lsum;
                 const double W = (d0.dp * Ua - Va) * inv;
 #pragma unroll 1
@@ -2998,6 +3048,10 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
         }
         if (rgm && n > (double)c.mask_thres) v -= lgamma(1.0 + n) - lf;
         if ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) v -= lgamma(1.0 + nb) - lfb;
+        if (c.tot_const) {
+            if (rgm && n > (double)c.mask_thres) v += lgamma_digamma_diff(c.a0[g], n).d;
+            if ((c.flags & kUseBc) && rgm && nb > (double)c.mask_thres) v += lgamma_digamma_diff(c.a0_bc[g], nb).d;
+        }
         if (c.wrow && r == 0) {
             // wave forms: per-guide count of unmasked replicates (the kPNrg row is data)
             double cnt = 0.0;

@@ -199,12 +199,26 @@ void k_guide_survival_wave(DevArgs c) {
             const double inv = frcp(S + kEps);
             const double ai = a0 * inv;
             double A0 = 0.0;
+            bool anyfl = false;
 #pragma unroll 1
             for (int b = 0; b < B; ++b) {
                 const double araw = alpha_raw(w0, MIX ? p0s[b * 64] : 0.0, w1, p1s[b * 64], sf[b], epsB, ai * c_sm[b]);
+                anyfl = anyfl || araw < kEps;
                 A0 += araw < kEps ? kEps : araw;
             }
-            const DD d0 = lgamma_digamma_diff_inl(A0, nn);
+            // total term: data unless a bin sits on its floor (DevArgs::tot_const)
+            DD d0;
+            d0.d = 0.0;
+            d0.dp = 0.0;
+            if (!c.tot_const) {
+                d0 = lgamma_digamma_diff(A0, nn);
+            } else if (__any(anyfl)) {
+                const DD dt = lgamma_digamma_diff(A0, nn), dc = lgamma_digamma_diff(a0, nn);
+                if (anyfl) {
+                    d0.d = dt.d - dc.d;
+                    d0.dp = dt.dp;
+                }
+            }
             double lsum = 0.0, Wa = 0.0;
             double S_0 = 0.0, S_1 = 0.0, S_t = 0.0, t_0 = 0.0, t_1 = 0.0, t_t = 0.0;
 #pragma unroll 1

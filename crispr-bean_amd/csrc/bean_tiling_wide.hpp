@@ -173,7 +173,17 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
             const double lsum = wave_allsum(db.d);
             const double Ua = wave_allsum(binlane && !floored ? araw : 0.0);
             const double Va = wave_allsum(binlane && !floored ? db.dp * araw : 0.0);
-            const DD d0 = lgamma_digamma_diff(A0, nn);
+            // total term: data unless a bin sits on its floor (DevArgs::tot_const)
+            DD d0;
+            d0.d = 0.0;
+            d0.dp = 0.0;
+            if (!c.tot_const) {
+                d0 = lgamma_digamma_diff(A0, nn);
+            } else if (__any(binlane && floored)) {
+                const DD dt = lgamma_digamma_diff(A0, nn), dc = lgamma_digamma_diff(a0, nn);
+                d0.d = dt.d - dc.d;
+                d0.dp = dt.dp;
+            }
             nll_u += d0.d - lsum;
             const double W = (d0.dp * Ua - Va) * inv;
             if (binlane) {

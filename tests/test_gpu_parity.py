@@ -760,3 +760,38 @@ def test_survival_tiling_trajectory_fused_loop_and_store(engine):
     assert set(store.keys()) == {"mu_loc", "mu_scale", "alpha_pi", "initial_abundance"}
     assert torch.allclose(store["initial_abundance"].cpu(), torch.full((250,), 1 / 250))
     assert np.isfinite(out["loss"]).all() and out["loss"][-1] < out["loss"][0]
+
+
+# ------------------------------------------------- total term of the Dirichlet-Multinomial sites
+@pytest.mark.parametrize("which", ["variant", "variant_masked", "survival", "survival_masked", "tiling"])
+def test_total_term_as_constant_equals_evaluating_it(engine, which, monkeypatch):
+    """get_alpha normalises (utils.py:10-31): without a floored bin sum_b alpha_b = a0[g] is data, so the
+    kernels leave lgamma(A0 + n) - lgamma(A0) to the constant (DevArgs::tot_const) and add the difference
+    where a bin sits on its floor (masked samples).  BEAN_HIP_TOT_CONST=0 evaluates it every step."""
+    from bean_amd.preprocessing.synthetic import make_sorting_tiling_screen
+
+    if which.startswith("variant"):
+        data = make_sorting_variant_screen(1500, 3, seed=91, mask_fraction=0.05 if which.endswith("masked") else 0.0)
+        family = "MixtureNormal"
+    elif which.startswith("survival"):
+        data = make_survival_variant_screen(1500, 3, seed=92, mask_fraction=0.05 if which.endswith("masked") else 0.0)
+        family = "MixtureNormal"
+    else:
+        data = make_sorting_tiling_screen(600, 2, seed=93)
+        family = "MultiMixtureNormal"
+    if which.endswith("masked"):
+        assert (data.sample_mask == 0).any()
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BEAN_HIP_TOT_CONST", flag)
+        torch.manual_seed(3)
+        eng = engine.HipSVI(family, data.to(DEV), num_steps=20)
+        for v in eng.unconstrained.values():
+            v.add_(0.3 * torch.randn_like(v))
+        out[flag] = eng.elbo_grad(step=2, seed=11)
+        eng.close()
+    (l1, g1), (l0, g0) = out["1"], out["0"]
+    assert abs(l1 - l0) <= 1e-12 * abs(l0), (l1, l0)
+    for k in g0:
+        scale = g0[k].abs().max().item() + 1e-30
+        assert (g1[k] - g0[k]).abs().max().item() <= 2e-6 * scale, k  # float32 outputs: a few ulp
