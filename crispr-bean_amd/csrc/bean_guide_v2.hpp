@@ -58,9 +58,20 @@ __device__ __forceinline__ DD gw_lgamma_diff(double a, double x) {
 #endif
 }
 
-template <int FAM, bool ACC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BEAN_WAVE_EU)))
-void k_guide_wave2(DevArgs c) {
+// A row of this (replicate, guide) for the launch that follows (k_param), or - fused step kernel, STEP -
+// for the wave of the SAME launch that finishes the tile: then an agent-scope store (global_store ... sc1).
+template <bool STEP>
+__device__ __forceinline__ void w2_row_store(double* p, double v) {
+    if (STEP) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+#define W2_ROW_STORE(ptr, val) w2_row_store<STEP>((ptr), (val))
+
+// The work of one wave = 64 consecutive guides of one replicate.  Returns false for the padded tiles of
+// the XCD-aware grid; otherwise the wave's part of the loss in `tot` (valid in lane 0).
+template <int FAM, bool ACC, bool STEP>
+__device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr& ctr, int& tile_o, int& r_o,
+                                                 int& t0_o, int& nt_o, double& tot_o) {
     constexpr bool MIX = FAM == kMixture;
     extern __shared__ double tabs[];
     const int lane = threadIdx.x;
@@ -71,10 +82,11 @@ void k_guide_wave2(DevArgs c) {
     const int kk = wg >> 3;
     const int r = kk % R;
     const int tile = (kk / R) * 8 + (wg & 7);
-    if (tile * 64 >= G) return;
+    if (tile * 64 >= G) return false;
+    tile_o = tile;
+    r_o = r;
     const int g = tile * 64 + lane;
     const bool valid = g < G;
-    const StepCtr ctr = *c.ctrB;
     double loss = 0.0;
 #ifdef BEAN_STAMP
     const long wave_gid = wg;
@@ -87,6 +99,8 @@ void k_guide_wave2(DevArgs c) {
     const int t0 = __builtin_amdgcn_readfirstlane(c.g2t[g_first]);
     const int nt = __builtin_amdgcn_readfirstlane(c.g2t[g_last]) - t0 + 1;
     const int ntm = c.tile_targets;
+    t0_o = t0;
+    nt_o = nt;
     // LDS: [3][B][ntm] table columns | [4][B] sf, sf_bc, sample mask, P0 of this replicate |
     //      [B][64] digamma differences | [kW2Misc][64] per-guide values | [2][B][64] counts (float)
     double* cst = tabs + 3 * B * ntm;
@@ -340,8 +354,8 @@ void k_guide_wave2(DevArgs c) {
         BEAN_STAMP_AT(6);
         BEAN_SETPRIO(3);
         double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
-        row[kW2Gmu * RG] = a_mu;
-        row[kW2Gy * RG] = a_y;
+        W2_ROW_STORE(row + kW2Gmu * RG, a_mu);
+        W2_ROW_STORE(row + kW2Gy * RG, a_y);
         if (MIX) {
             const double cp0 = ms[4 * 64], cp1 = ms[5 * 64];
             const bool cl0 = cp0 < 1e-5, cl1 = cp1 < 1e-5;
@@ -351,7 +365,7 @@ void k_guide_wave2(DevArgs c) {
             if (ACC) {
                 gpi0 = 0.0;
                 gpi1 = (g1 - g0) * dpe1_dpi1;
-                row[kW2Gnoise * RG] = (g1 - g0) * dpe1_dl;
+                W2_ROW_STORE(row + kW2Gnoise * RG, (g1 - g0) * dpe1_dl);
             }
             // digamma of the concentrations, tabulated by k_param (DevArgs::dgq): issued here, used
             // by the implicit-gradient calls below
@@ -407,17 +421,28 @@ void k_guide_wave2(DevArgs c) {
             }
             // d loss / d c_a of this replicate apart from the per-guide normaliser terms:
             // (c_q unclamped) log pi_a + pathwise term, minus (masked) log pi_a of the model site
-            row[kW2GA0 * RG] = (cl0 ? 0.0 : lpi0 + path0) - (rgm ? lpi0 : 0.0);
-            row[kW2GA1 * RG] = (cl1 ? 0.0 : lpi1 + path1) - (rgm ? lpi1 : 0.0);
+            W2_ROW_STORE(row + kW2GA0 * RG, (cl0 ? 0.0 : lpi0 + path0) - (rgm ? lpi0 : 0.0));
+            W2_ROW_STORE(row + kW2GA1 * RG, (cl1 ? 0.0 : lpi1 + path1) - (rgm ? lpi1 : 0.0));
         }
         loss = nll;
     }
-    const double tot = wave_sum(loss);
-    if (lane == 0) {
-        wave_loss_out(c, ctr.slot, wg, tot);
-        if (wg == 0) publish_ctr(c, ctr);
-    }
+    tot_o = wave_sum(loss);
     BEAN_STAMP_AT(7);
+    return true;
+}
+#undef W2_ROW_STORE
+
+template <int FAM, bool ACC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BEAN_WAVE_EU)))
+void k_guide_wave2(DevArgs c) {
+    const StepCtr ctr = *c.ctrB;
+    int tile, r, t0, nt;
+    double tot;
+    if (!guide_wave2_body<FAM, ACC, false>(c, ctr, tile, r, t0, nt, tot)) return;
+    if (threadIdx.x == 0) {
+        wave_loss_out(c, ctr.slot, blockIdx.x, tot);
+        if (blockIdx.x == 0) publish_ctr(c, ctr);
+    }
 }
 
 }  // namespace bean

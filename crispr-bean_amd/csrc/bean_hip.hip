@@ -38,6 +38,8 @@ struct bean_hip_ctx {
     bool wave_guide;   // sorting variant families, default: one wave per (guide tile, replicate)
     bool wave2;        // ... in its second form, k_guide_wave2 (BEAN_HIP_GUIDE=wave1 selects the first)
     bool surv_wave;    // survival variant families: k_guide_survival_wave (BEAN_HIP_SURVIVAL=block: k_guide_survival)
+    bool fused_step;   // bean_hip_svi_run steps with ONE launch, k_step_wave2 (bean_step_v2.hpp; BEAN_HIP_STEP=pair: two)
+    std::vector<hipGraphExec_t> graphs_fused;  // [k]: 2^(k+1) launches of k_step_wave2
     long long* loss_acc;  // library-owned fixed-point loss accumulators, kLossWords per loss_hist slot
     int* tile_targets_dev;
     bool tiling_wave;  // tiling families, default: k_guide_tiling_wave (BEAN_HIP_TILING=block: k_guide_tiling)
@@ -201,6 +203,9 @@ static void drop_graph(bean_hip_ctx* c) {
     for (hipGraphExec_t g : c->graphs)
         if (g) (void)hipGraphExecDestroy(g);
     c->graphs.clear();
+    for (hipGraphExec_t g : c->graphs_fused)
+        if (g) (void)hipGraphExecDestroy(g);
+    c->graphs_fused.clear();
 }
 
 extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
@@ -317,6 +322,15 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         const char* tc = getenv("BEAN_HIP_TOT_CONST");  // =0: the total terms are evaluated every step (A/B)
         d.tot_const = ((c->wave2 || c->surv_wave || c->tiling_wave || c->tiling_wide) && !(tc && !strcmp(tc, "0"))) ? 1 : 0;
     }
+    {
+        // one launch per step (bean_step_v2.hpp), opt-in (BEAN_HIP_STEP=fused; measured slower than the
+        // two-launch path, see the header): the variant sorting families of k_guide_wave2 whose
+        // parameters are all per target or per guide, no target longer than a tile
+        const char* sm = getenv("BEAN_HIP_STEP");
+        c->fused_step = c->wave2 && !d.wide_targets && s->max_target_len <= 64 && s->n_sample_covariates == 0 &&
+                        (s->family == BEAN_FAMILY_MIXTURE_NORMAL || s->family == BEAN_FAMILY_NORMAL) &&
+                        (sm && !strcmp(sm, "fused"));
+    }
     const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G
                                            : (c->tiling_wide ? (uint64_t)tq_num(d.A) * Rr * G : 0);
     const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G
@@ -331,7 +345,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const uint64_t n_lpart = (c->wave2 || c->surv_wave) ? ((G + 63) / 64 + 7) / 8 * 8 * Rr : 0;
     const uint64_t n_dgq = ((c->wave2 || c->surv_wave) && s->family == BEAN_FAMILY_MIXTURE_NORMAL) ? 6 * G : 0;
     const uint64_t n_dgq_t = c->tiling_wave ? (uint64_t)(kAMax + 1) * G : 0;
-    const uint64_t n_dbl = 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
+    // arrival counters of the fused step kernel: per tile and per tile boundary (ints, zero between launches)
+    const uint64_t n_ctr = c->wave2 ? ((G + 63) / 64 + 7) / 8 * 8 + 2 + 3 * B + 2 : 0;
+    const uint64_t n_dbl = n_ctr + 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
                            n_split + n_dbg + n_trow + 3 * n_lpart + n_dgq + n_dgq_t + 2 * n_cov + 2 * Rr;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
@@ -363,6 +379,13 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.const_acc = (long long*)w; w += kLossWords;
     c->tile_targets_dev = (int*)w; w += 1;
     d.tile_targets = 64;
+    if (n_ctr) {
+        d.tile_ctr = (int*)w;
+        d.bnd_ctr = d.tile_ctr + (n_ctr - 3 * B - 2);
+        w += n_ctr - 3 * B - 2;
+        d.ue_z = w; w += 2 * B;
+        d.ue_idx = (int*)w; w += B + 2;  // 2 B + 1 ints
+    }
     if (n_dbg) {
         d.dbg = (unsigned long long*)w; w += n_dbg;
     }
@@ -748,6 +771,39 @@ static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
 }
 
 // survival variant families, one wave per (guide tile, replicate) (bean_survival_v2.hpp)
+// One SVI step in one launch (bean_step_v2.hpp); `flip` alternates the step-counter buffers.
+static void launch_step_wave2(bean_hip_ctx* c, hipStream_t stream, int flip) {
+    const DevArgs& d = c->d;
+    const int tiles = (d.G + 63) / 64;
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8) * (unsigned)d.R), block(64);
+    const size_t lds = guide_wave2_lds(d.B, d.tile_targets);
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        if (d.family == kMixture) {
+            if (d.flags & kAcc)
+                hipExtLaunchKernelGGL((k_step_wave2<kMixture, true>), grid, block, lds, stream, e0, e1, 0, d, flip);
+            else
+                hipExtLaunchKernelGGL((k_step_wave2<kMixture, false>), grid, block, lds, stream, e0, e1, 0, d, flip);
+        } else {
+            hipExtLaunchKernelGGL((k_step_wave2<kNormal, false>), grid, block, lds, stream, e0, e1, 0, d, flip);
+        }
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+        return;
+    }
+    if (d.family == kMixture) {
+        if (d.flags & kAcc)
+            hipLaunchKernelGGL((k_step_wave2<kMixture, true>), grid, block, lds, stream, d, flip);
+        else
+            hipLaunchKernelGGL((k_step_wave2<kMixture, false>), grid, block, lds, stream, d, flip);
+    } else {
+        hipLaunchKernelGGL((k_step_wave2<kNormal, false>), grid, block, lds, stream, d, flip);
+    }
+}
+
 static void launch_guide_survival_wave(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     const int tiles = (d.G + 63) / 64;
@@ -892,8 +948,8 @@ extern "C" int bean_hip_elbo_grad(bean_hip_ctx* c, uint64_t seed, uint64_t step,
     hipStream_t stream = (hipStream_t)stream_;
     c->d.seed = seed;
     if (clear_loss(c, stream, loss_index, 1)) return -1;
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d.ctrA, c->d.ctrB,
-                       (unsigned long long)step, (unsigned long long)loss_index);
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d, (unsigned long long)step,
+                       (unsigned long long)loss_index);
     launch_param<false, false, true>(c, stream);
     launch_guide(c, stream);
     launch_param<true, false, false>(c, stream);
@@ -927,10 +983,15 @@ static void enqueue_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n) {
 
 // Capture 2^k {k_param, guide} pairs into an executable graph.  On any failure the stream is taken
 // out of capture mode before returning.
-static int capture_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n, hipGraphExec_t* out) {
+static void enqueue_fused(bean_hip_ctx* c, hipStream_t stream, uint64_t n, int flip0 = 0) {
+    for (uint64_t i = 0; i < n; ++i) launch_step_wave2(c, stream, (int)((i + flip0) & 1));
+}
+
+static int capture_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n, hipGraphExec_t* out, bool fused = false) {
     hipGraph_t graph = nullptr;
     HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    enqueue_pairs(c, stream, n);
+    if (fused) enqueue_fused(c, stream, n);
+    else enqueue_pairs(c, stream, n);
     hipError_t e = hipStreamEndCapture(stream, &graph);
     if (e != hipSuccess) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -961,9 +1022,13 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
     if (first_step + n_steps > c->loss_capacity)
         return fail("bean_hip_svi_run: loss_hist too small for first_step + n_steps");
     hipStream_t stream = (hipStream_t)stream_;
-    if (!c->graphs.empty() && (c->graph_seed != seed)) drop_graph(c);
+    if ((!c->graphs.empty() || !c->graphs_fused.empty()) && (c->graph_seed != seed)) drop_graph(c);
     c->d.seed = seed;
     const bool use_graph = graph_chunk > 0 && stream != nullptr && !c->profile;
+    // one launch per step unless per-step noise is injected or dumped, or k_param itself is being timed
+    const DevArgs& dd = c->d;
+    const bool fused = c->fused_step && !c->profile_param && !dd.eps_mu_in && !dd.eps_sd_in && !dd.pi_in &&
+                       !dd.eps_noise_in && !dd.eps_mu_out && !dd.eps_sd_out && !dd.eps_noise_out;
     if (use_graph) {
         // Graphs of 1, 2, 4, ... <= graph_chunk pairs, all instantiated at the first call (nothing is
         // instantiated inside a later, possibly timed, call); any number of pairs is then replayed
@@ -971,7 +1036,22 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
         // depend on the step.
         int kmax = 0;
         while ((2ull << kmax) <= (uint64_t)graph_chunk && kmax < 10) ++kmax;
-        if ((int)c->graphs.size() != kmax + 1) {
+        if (fused) {
+            // graphs of 2, 4, ... <= graph_chunk launches
+            const int n_graphs = kmax > 0 ? kmax : 1;
+            if ((int)c->graphs_fused.size() != n_graphs) {
+                drop_graph(c);
+                for (int k = 0; k < n_graphs; ++k) {
+                    hipGraphExec_t ge = nullptr;
+                    if (capture_pairs(c, stream, 2ull << k, &ge, true)) {
+                        drop_graph(c);
+                        return -1;
+                    }
+                    c->graphs_fused.push_back(ge);
+                }
+                c->graph_seed = seed;
+            }
+        } else if ((int)c->graphs.size() != kmax + 1) {
             drop_graph(c);
             for (int k = 0; k <= kmax; ++k) {
                 hipGraphExec_t ge = nullptr;
@@ -985,20 +1065,34 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
         }
     }
     if (clear_loss(c, stream, first_step, n_steps)) return -1;
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d.ctrA, c->d.ctrB,
-                       (unsigned long long)first_step, (unsigned long long)first_step);
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d, (unsigned long long)first_step,
+                       (unsigned long long)first_step);
     launch_param<false, false, true>(c, stream);
-    launch_guide(c, stream);
-    uint64_t pairs = n_steps - 1;
-    if (use_graph) {
-        for (int k = (int)c->graphs.size() - 1; k >= 0; --k)
-            while (pairs >= (1ull << k)) {
-                HIP_OK(hipGraphLaunch(c->graphs[k], stream));
-                pairs -= 1ull << k;
-            }
+    if (fused) {
+        // n launches of k_step_wave2 = {guide work, FINISH, PREP of the next step}; graphs hold even
+        // numbers of launches (the step counters ping-pong), an odd remainder is launched last
+        uint64_t left = n_steps;
+        if (use_graph) {
+            for (int k = (int)c->graphs_fused.size() - 1; k >= 0; --k)
+                while (left >= (2ull << k)) {
+                    HIP_OK(hipGraphLaunch(c->graphs_fused[k], stream));
+                    left -= 2ull << k;
+                }
+        }
+        enqueue_fused(c, stream, left);
+    } else {
+        launch_guide(c, stream);
+        uint64_t pairs = n_steps - 1;
+        if (use_graph) {
+            for (int k = (int)c->graphs.size() - 1; k >= 0; --k)
+                while (pairs >= (1ull << k)) {
+                    HIP_OK(hipGraphLaunch(c->graphs[k], stream));
+                    pairs -= 1ull << k;
+                }
+        }
+        enqueue_pairs(c, stream, pairs);
+        launch_param<true, true, false>(c, stream);
     }
-    enqueue_pairs(c, stream, pairs);
-    launch_param<true, true, false>(c, stream);
     launch_finalize(c, stream, first_step, n_steps, false);
     HIP_OK(hipGetLastError());
     return 0;
@@ -1022,8 +1116,8 @@ extern "C" int bean_hip_sharded_begin(bean_hip_ctx* c, uint64_t seed, uint64_t f
     hipStream_t stream = (hipStream_t)stream_;
     c->d.seed = seed;
     if (clear_loss(c, stream, first_step, n_steps)) return -1;
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d.ctrA, c->d.ctrB,
-                       (unsigned long long)first_step, (unsigned long long)first_step);
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d, (unsigned long long)first_step,
+                       (unsigned long long)first_step);
     launch_param<false, false, true>(c, stream);
     HIP_OK(hipGetLastError());
     return 0;
@@ -1082,7 +1176,7 @@ extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
     if (c && c->d.family == kMultiMixture)
         return c->tiling_wide ? "k_guide_tiling_wide" : (c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling");
     if (c && c->d.survival) return c->surv_wave ? "k_guide_survival_wave" : "k_guide_survival";
-    if (c && c->wave_guide) return c->wave2 ? "k_guide_wave2" : "k_guide_wave";
+    if (c && c->wave_guide) return c->wave2 ? (c->fused_step ? "k_step_wave2" : "k_guide_wave2") : "k_guide_wave";
     return "k_lik";
 }
 

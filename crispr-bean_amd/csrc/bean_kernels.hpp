@@ -30,16 +30,30 @@
 
 namespace bean {
 
-// In-kernel cycle stamps for diagnostic builds only (-DBEAN_STAMP); the shipped kernels contain none.
+// In-kernel cycle stamps for diagnostic builds only (-DBEAN_STAMP=1: the guide kernels, =2: k_param;
+// they share one buffer); the shipped kernels contain none.
 #ifdef BEAN_STAMP
-#define BEAN_STAMP_AT(slot)                                                                      \
+#define BEAN_STAMP_WRITE(slot)                                                                   \
     do {                                                                                         \
         unsigned long long t_;                                                                   \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
         if (lane == 0) c.dbg[wave_gid * 8 + (slot)] = t_;                                        \
     } while (0)
+#endif
+#if defined(BEAN_STAMP) && BEAN_STAMP == 1
+#define BEAN_STAMP_AT(slot) BEAN_STAMP_WRITE(slot)
 #else
 #define BEAN_STAMP_AT(slot) do {} while (0)
+#endif
+#if defined(BEAN_STAMP) && BEAN_STAMP == 3  // the tail of the fused step kernel (one record per tile)
+#define BEAN_STAMP_TL(slot) BEAN_STAMP_WRITE(slot)
+#else
+#define BEAN_STAMP_TL(slot) do {} while (0)
+#endif
+#if defined(BEAN_STAMP) && BEAN_STAMP == 2
+#define BEAN_STAMP_KP(slot) BEAN_STAMP_WRITE(slot)
+#else
+#define BEAN_STAMP_KP(slot) do {} while (0)
 #endif
 
 constexpr double kEps = 1e-5;         // epsilon of get_alpha (utils.py:11)
@@ -121,6 +135,12 @@ struct DevArgs {
     // A0 = sum_b alpha_b = a0[g] is data (k_prepare adds the term once) and its derivative multiplies
     // sum_b d alpha_b = 0.  A (replicate, guide) with a floored bin adds the difference to that constant.
     int tot_const;
+    int *tile_ctr, *bnd_ctr;           // fused step kernel: arrivals per 64-guide tile / per tile boundary
+    // distinct finite bin edges (k_prepare): ue_z[n] their z values, n in ue_idx[2 B]; ue_idx[b] /
+    // ue_idx[B + b]: the upper / lower edge of bin b in that list, -1 where the edge is infinite.  The
+    // four sort bins + bulk of a standard screen have 10 edges, 4 of them distinct and finite.
+    double* ue_z;
+    int* ue_idx;
     // workspace
     double *tabP, *tabPmu, *tabPy;     // (B, T)
     double* P0;                        // (B)
@@ -372,6 +392,93 @@ __device__ __forceinline__ void emit_grad_pre(const DevArgs& c, int which, long 
     }
 }
 
+// ---- per-target scalar math of the sorting families' FINISH / PREP.  Shared by k_param and by the
+// fused step kernel (bean_step_v2.hpp), whose lanes evaluate one parameter each: every rounding is
+// pinned (no implicit contraction), so both produce the same bits.
+struct TgtPrior {
+    double l0, var0, logs0;
+};
+__device__ __forceinline__ TgtPrior tgt_sd_prior(const DevArgs& c, int t) {
+    TgtPrior pr;
+    pr.l0 = c.pr_sd_loc ? c.pr_sd_loc[t] : 0.0;
+    // LogNormal(sd_loc, sd_scale) prior: the default scale lives in a float32
+    // tensor in the reference (model.py:405-406), so torch forms scale**2 and
+    // log(scale) in float32; user-supplied --prior-params are taken as float64
+    if (c.pr_sd_scale) {
+        const double s0 = c.pr_sd_scale[t];
+        pr.var0 = s0 * s0;
+        pr.logs0 = log(s0);
+    } else {
+        const float s0f = (float)c.sd_prior_scale;
+        pr.var0 = (double)(s0f * s0f);
+        pr.logs0 = (double)logf(s0f);
+    }
+    return pr;
+}
+// d log p / d mu and d log p / d y of the priors (Laplace(0, 1) or Normal on mu, LogNormal on sd), and
+// - log p + log q of the target's two sites for the reported loss (p1, p3: log of the guide scales)
+__device__ __forceinline__ void tgt_prior_terms(const DevArgs& c, int t, const TgtPrior& pr, double mu, double y,
+                                                double eps1, double eps2, float p1, float p3, double& dlogp_mu,
+                                                double& dlogp_dy, double& loss) {
+#pragma clang fp contract(off)
+    double logp_mu;
+    if (c.flags & kPriorNormalMu) {
+        const double pl = c.pr_mu_loc ? c.pr_mu_loc[t] : 0.0;
+        const double ps = c.pr_mu_scale ? c.pr_mu_scale[t] : 1.0;
+        const double zz = (mu - pl) / ps;
+        logp_mu = -0.5 * zz * zz - log(ps) - kHalfLog2PiC;
+        dlogp_mu = -zz / ps;
+    } else {
+        logp_mu = -kLog2 - fabs(mu);
+        dlogp_mu = mu > 0.0 ? -1.0 : (mu < 0.0 ? 1.0 : 0.0);
+    }
+    const double dy0 = y - pr.l0;
+    const double logp_sd = -y - pr.logs0 - kHalfLog2PiC - dy0 * dy0 / (2.0 * pr.var0);
+    dlogp_dy = -1.0 - dy0 / pr.var0;
+    const double logq_mu = -0.5 * eps1 * eps1 - (double)p1 - kHalfLog2PiC;
+    const double logq_sd = -y - 0.5 * eps2 * eps2 - (double)p3 - kHalfLog2PiC;
+    loss = -logp_mu - logp_sd + logq_mu + logq_sd;
+}
+// d loss / d (unconstrained parameter j) of a target: j = 0 mu_loc, 1 mu_scale, 2 sd_loc, 3 sd_scale;
+// G = d loss / d (drawn mu or y), eps the draw's standard normal, s = exp(parameter j) for the scales
+__device__ __forceinline__ double tgt_grad(int j, double G, double eps, double s) {
+#pragma clang fp contract(off)
+    if (j == 0) return G;
+    if (j == 2) return G - 1.0;
+    const double ges = G * eps * s;
+    if (j == 1) return ges - 1.0;
+    return ges - 1.0 - eps * s;
+}
+// the reparameterised draw loc + eps * exp(log scale)
+__device__ __forceinline__ double tgt_draw(float loc, double eps, float log_scale) {
+#pragma clang fp contract(off)
+    return (double)loc + eps * exp((double)log_scale);
+}
+// One bin edge of a target's Phi tables (a2): even e = upper edge, odd e = lower edge of bin e >> 1,
+// on adjacent lanes; the pair is combined with one shuffle.  mu_r: the target's drawn mean (plus the
+// replicate's covariate shift), inv = 1 / sigma.
+__device__ __forceinline__ void phi_edge(const DevArgs& c, int t, bool live_t, int e, double mu_r, double inv,
+                                         double dsig_dy, long off) {
+#pragma clang fp contract(off)
+    const int b = e >> 1;
+    const bool upper = (e & 1) == 0, live = live_t && b < c.B;
+    const double z = live ? (upper ? c.z_hi[b] : c.z_lo[b]) : 0.0;
+    double cdf = upper ? 1.0 : 0.0, pdf = 0.0, upd = 0.0;
+    if (live && !isinf(z)) {
+        const double u = (z - mu_r) * inv;
+        cdf = norm_cdf(u);
+        pdf = norm_pdf(u);
+        upd = u * pdf;
+    }
+    const double cl = __shfl_xor(cdf, 1, 64), fl = __shfl_xor(pdf, 1, 64), ufl = __shfl_xor(upd, 1, 64);
+    if (live && upper) {
+        const long o = off + (long)b * c.T + t;
+        c.tabP[o] = cdf - cl;
+        c.tabPmu[o] = -(pdf - fl) * inv;
+        c.tabPy[o] = -(upd - ufl) * inv * dsig_dy;
+    }
+}
+
 // --------------------------------------------------- tiling: per-guide finish
 // Guide part of k_param for MultiMixtureNormal: Dirichlet normalisers of the
 // A-component pi site, chain to alpha_pi through the two concentration maps the
@@ -617,10 +724,28 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
         if (t < c.T) {
             const int g0 = c.toff[t], ng = c.toff[t + 1] - g0;
             const int n = ng * c.R;
-            for (int i = lg; i < n; i += kLanesPerTarget) {
-                const int r = i / ng, g = g0 + (i - r * ng);
-                a += c.wrow[((long)kPGmu * c.R + r) * c.G + g];
-                b += c.wrow[((long)kPGy * c.R + r) * c.G + g];
+            // four entries' loads in flight per lane before the first add (a loop of load / add pairs is
+            // a chain of memory round trips, and k_param is made of those); i / ng without the integer
+            // division (exact for i < 2^20); the order of the additions is unchanged
+            const float rng = 1.0f / (float)ng;
+            for (int i0 = lg; i0 < n; i0 += 4 * kLanesPerTarget) {
+                double xa[4], xb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * kLanesPerTarget;
+                    xa[u] = xb[u] = 0.0;
+                    if (i < n) {
+                        const int r = (int)(((float)i + 0.5f) * rng), g = g0 + (i - r * ng);
+                        xa[u] = c.wrow[((long)kPGmu * c.R + r) * c.G + g];
+                        xb[u] = c.wrow[((long)kPGy * c.R + r) * c.G + g];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * kLanesPerTarget < n) {
+                        a += xa[u];
+                        b += xb[u];
+                    }
             }
         }
 #pragma unroll
@@ -653,6 +778,219 @@ __global__ __launch_bounds__(kParamBlock) void k_target_reduce(DevArgs c, double
 #include "bean_tiling_wide.hpp"  // needs everything above; k_param below dispatches to it
 namespace bean {
 
+// Coherent read of a row another wave of the SAME launch has written (fused step kernel): agent-scope
+// atomic load (global_load ... sc1); k_param reads the rows of the previous launch with plain loads.
+template <bool COH>
+__device__ __forceinline__ double row_ld(const double* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+__device__ __forceinline__ double noise_row_coherent(const DevArgs& c, int g) {
+    double s = 0.0;
+    for (int r = 0; r < c.R; ++r) s += row_ld<true>(c.wrow + ((long)kPGnoise * c.R + r) * c.G + g);
+    return s;
+}
+
+// Guide part of k_param for the variant MixtureNormal families, one guide per lane: Dirichlet
+// normalisers, chain to alpha_pi, ClippedAdam, (+Acc: the noise site), and the lgamma / digamma table of
+// the updated concentrations.  Shared with the fused step kernel (COH: see row_ld); roundings pinned.
+template <bool FINISH, bool ADAM, bool PREP, bool COH>
+__device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoef ak, unsigned long long s_prep,
+                                                double& loss_fin) {
+#pragma clang fp contract(off)
+    const bool acc_on = (c.flags & kAcc) != 0;
+    const bool fit_noise = acc_on && (c.flags & kFitNoise);
+    float nl = 0.f, ns_u = 0.f;
+    if (fit_noise) {
+        nl = c.p[5][g];
+        ns_u = c.p[6][g];
+    }
+    // alpha_pi: parameters and moments loaded once, with everything else the guide needs (k_param is a
+    // chain of memory round trips); PREP takes the updated values from registers
+    float up[2] = {c.p[4][2 * g], c.p[4][2 * g + 1]}, um[2] = {0.f, 0.f}, uv[2] = {0.f, 0.f};
+    if (FINISH && ADAM) {
+        um[0] = c.m[4][2 * g];
+        um[1] = c.m[4][2 * g + 1];
+        uv[0] = c.v[4][2 * g];
+        uv[1] = c.v[4][2 * g + 1];
+    }
+    if (FINISH) {
+        const float u0 = up[0], u1 = up[1];
+        const double al0 = (double)expf(u0), al1 = (double)expf(u1);
+        const double s = al0 + al1, pa0 = c.pi_a0[g];
+        const double cp[2] = {al0 / s * pa0, al1 / s * pa0};
+        const bool cl[2] = {cp[0] < 1e-5, cp[1] < 1e-5};
+        const double cq[2] = {cl[0] ? 1e-5 : cp[0], cl[1] ? 1e-5 : cp[1]};
+        double lgS_p, dgS_p, lg_p[2], dg_p[2];
+        double lgS_q, dgS_q, lg_q[2], dg_q[2];
+        if (c.dgq) {
+            // the guide side (c_q) was tabulated by the previous PREP for this alpha_pi
+            const long Gl = c.G;
+            lgS_q = c.dgq[g];
+            lg_q[0] = c.dgq[Gl + g];
+            lg_q[1] = c.dgq[2 * Gl + g];
+            dgS_q = c.dgq[3 * Gl + g];
+            dg_q[0] = c.dgq[4 * Gl + g];
+            dg_q[1] = c.dgq[5 * Gl + g];
+            lgS_p = lgS_q, dgS_p = dgS_q, lg_p[0] = lg_q[0], lg_p[1] = lg_q[1], dg_p[0] = dg_q[0], dg_p[1] = dg_q[1];
+            if (cl[0] || cl[1]) {  // model side (c_p, unclamped) differs
+                lgamma_digamma(cp[0] + cp[1], lgS_p, dgS_p);
+                lgamma_digamma(cp[0], lg_p[0], dg_p[0]);
+                lgamma_digamma(cp[1], lg_p[1], dg_p[1]);
+            }
+        } else {
+            lgamma_digamma(cp[0] + cp[1], lgS_p, dgS_p);
+            lgamma_digamma(cp[0], lg_p[0], dg_p[0]);
+            lgamma_digamma(cp[1], lg_p[1], dg_p[1]);
+            lgS_q = lgS_p, dgS_q = dgS_p, lg_q[0] = lg_p[0], lg_q[1] = lg_p[1], dg_q[0] = dg_p[0], dg_q[1] = dg_p[1];
+            if (cl[0] || cl[1]) {
+                lgamma_digamma(cq[0] + cq[1], lgS_q, dgS_q);
+                lgamma_digamma(cq[0], lg_q[0], dg_q[0]);
+                lgamma_digamma(cq[1], lg_q[1], dg_q[1]);
+            }
+        }
+        // per-replicate rows of the wave form: independent loads, four replicates in flight
+        double Lp_[2] = {0.0, 0.0}, Lq_[2] = {0.0, 0.0}, path_[2] = {0.0, 0.0}, nrg = 0.0;
+        double GA_[2] = {0.0, 0.0};
+        if (c.wrow && c.rows_v2) {
+            // k_guide_wave2 rows: GA_a = sum_r of everything d loss / d c_a owes to the draws;
+            // the (c - 1) log pi terms of the loss were added by the guide kernel
+            const long RG = (long)c.R * c.G;
+            const double* w = c.wrow + g;
+            nrg = c.part[(long)kPNrg * c.G + g];  // data only (k_prepare)
+            if (COH) {
+                // atomic loads stay in program order and are waited for where they are used: load
+                // eight replicates' rows first, add afterwards (same order of additions)
+                for (int r0 = 0; r0 < c.R; r0 += 8) {
+                    double x0[8], x1[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        x0[u] = x1[u] = 0.0;
+                        if (r0 + u < c.R) {
+                            const double* wr = w + (long)(r0 + u) * c.G;
+                            x0[u] = row_ld<true>(wr + 3 * RG);
+                            x1[u] = row_ld<true>(wr + 4 * RG);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (r0 + u < c.R) {
+                            GA_[0] += x0[u];
+                            GA_[1] += x1[u];
+                        }
+                }
+            } else {
+#pragma unroll 4
+                for (int r = 0; r < c.R; ++r) {
+                    const double* wr = w + (long)r * c.G;
+                    GA_[0] += wr[3 * RG];
+                    GA_[1] += wr[4 * RG];
+                }
+            }
+        } else if (c.wrow) {
+            const long RG = (long)c.R * c.G;
+            const double* w = c.wrow + g;
+            nrg = c.part[(long)kPNrg * c.G + g];  // data only (k_prepare)
+#pragma unroll 4
+            for (int r = 0; r < c.R; ++r) {
+                const double* wr = w + (long)r * c.G;
+                Lp_[0] += wr[kPLp * RG];
+                Lp_[1] += wr[(kPLp + 1) * RG];
+                Lq_[0] += wr[kPLq * RG];
+                Lq_[1] += wr[(kPLq + 1) * RG];
+                path_[0] += wr[kPPath * RG];
+                path_[1] += wr[(kPPath + 1) * RG];
+            }
+        } else {
+            nrg = c.part[(long)kPNrg * c.G + g];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                Lp_[a] = c.part[(long)(kPLp + a) * c.G + g];
+                Lq_[a] = c.part[(long)(kPLq + a) * c.G + g];
+                path_[a] = c.part[(long)(kPPath + a) * c.G + g];
+            }
+        }
+        const double Rf = (double)c.R;
+        double gc[2];
+        double lp = nrg * (lgS_p - lg_p[0] - lg_p[1]);
+        double lq = Rf * (lgS_q - lg_q[0] - lg_q[1]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const double Lp = Lp_[a], Lq = Lq_[a], gpath = path_[a];
+            lp += (cp[a] - 1.0) * Lp;
+            lq += (cq[a] - 1.0) * Lq;
+            const double g_cp = -(Lp + nrg * (dgS_p - dg_p[a]));
+            const double g_cq = cl[a] ? 0.0 : (Lq + Rf * (dgS_q - dg_q[a]) + gpath);
+            gc[a] = g_cp + g_cq;
+        }
+        if (c.wrow && c.rows_v2) {
+            lp = nrg * (lgS_p - lg_p[0] - lg_p[1]);
+            lq = Rf * (lgS_q - lg_q[0] - lg_q[1]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                gc[a] = -nrg * (dgS_p - dg_p[a]) + (cl[a] ? 0.0 : Rf * (dgS_q - dg_q[a])) + GA_[a];
+        }
+        loss_fin = -lp + lq;
+        const double dot = (gc[0] * al0 + gc[1] * al1) / s;
+        emit_grad_pre<ADAM>(c, 4, 2 * g, pa0 / s * (gc[0] - dot) * al0, ak, up[0], um[0], uv[0]);
+        emit_grad_pre<ADAM>(c, 4, 2 * g + 1, pa0 / s * (gc[1] - dot) * al1, ak, up[1], um[1], uv[1]);
+        if (acc_on) {
+            const double lpn = c.lpn[g], eps = c.eps_noise[g];
+            const double gl = COH ? noise_row_coherent(c, g) : lik_row(c, kPGnoise, g);
+            const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
+            // Normal(0, 0.655) prior held in float32 by the reference (utils.py:158-161)
+            const float nsf = 0.655f;
+            const double nvar = (double)(nsf * nsf);
+            const double logp = -lpn * lpn / (2.0 * nvar) - (double)logf(nsf) - kHalfLog2PiC;
+            const double logq = -0.5 * eps * eps - log(ns) - kHalfLog2PiC;
+            loss_fin += -logp + logq;
+            if (fit_noise) {
+                const double Gl = gl + lpn / nvar;
+                emit_grad<ADAM>(c, 5, g, Gl, ak);
+                emit_grad<ADAM>(c, 6, g, Gl * eps * ns - 1.0, ak);
+                if (ADAM) {
+                    nl = c.p[5][g];
+                    ns_u = c.p[6][g];
+                }
+            }
+        }
+    }
+    if (PREP && acc_on) {
+        double eps;
+        if (c.eps_noise_in) {
+            eps = c.eps_noise_in[g];
+        } else {
+            rocrand_state_philox4x32_10 st;
+            rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)(c.g_off + g),
+                         s_prep * 4ull, &st);
+            eps = (double)rocrand_normal(&st);
+        }
+        const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
+        c.eps_noise[g] = eps;
+        c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
+        if (c.eps_noise_out) c.eps_noise_out[g] = eps;
+    }
+    if (PREP && c.dgq) {
+        // lgamma / digamma of the guide-side concentrations of the (updated) alpha_pi, for
+        // the next guide kernel and the next FINISH
+        const double al0 = (double)expf(up[0]), al1 = (double)expf(up[1]);
+        const double s = al0 + al1, pa0 = c.pi_a0[g];
+        const double c0 = al0 / s * pa0, c1 = al1 / s * pa0;  // as FINISH forms c_p
+        const double q0 = c0 < 1e-5 ? 1e-5 : c0, q1 = c1 < 1e-5 ? 1e-5 : c1;
+        double lgS, dgS, lg0, dg0, lg1, dg1;
+        lgamma_digamma(q0 + q1, lgS, dgS);
+        lgamma_digamma(q0, lg0, dg0);
+        lgamma_digamma(q1, lg1, dg1);
+        const long Gl = c.G;
+        c.dgq[g] = lgS;
+        c.dgq[Gl + g] = lg0;
+        c.dgq[2 * Gl + g] = lg1;
+        c.dgq[3 * Gl + g] = dgS;
+        c.dgq[4 * Gl + g] = dg0;
+        c.dgq[5 * Gl + g] = dg1;
+    }
+}
+
 // -------------------------------------------------------------------- k_param
 // grid = n_target_blocks + n_guide_blocks, 256 threads.
 template <bool FINISH, bool ADAM, bool PREP>
@@ -664,7 +1002,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
 #elif BEAN_KP_DIAG == 2  // ... or the guide part alone
     if ((int)blockIdx.x < n_target_blocks && blockIdx.x != 0) return;
 #endif
-#ifdef BEAN_STAMP
+#if defined(BEAN_STAMP) && BEAN_STAMP == 2
     const int lane = threadIdx.x & 63;
     const long wave_gid = (long)blockIdx.x * (kParamBlock / 64) + (threadIdx.x >> 6);
 #endif
@@ -686,7 +1024,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     __builtin_assume(!c.not_loss_owner);
     __builtin_assume(c.lpart != nullptr);
 #endif
-    BEAN_STAMP_AT(0);
+    BEAN_STAMP_KP(0);
     const StepCtr ctr = *c.ctrA;
     const unsigned long long s_fin = ctr.step;
     const unsigned long long s_prep = FINISH ? ctr.step + 1 : ctr.step;
@@ -756,7 +1094,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 }
             }
         }
-        BEAN_STAMP_AT(1);
+        BEAN_STAMP_KP(1);
         if (active && c.survival) {
             // survival families: mu only (no sd latent), growth tables are computed in k_guide_survival
             float pl = c.p[0][t], psu = c.p[1][t];
@@ -799,49 +1137,20 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 if (c.eps_mu_out) c.eps_mu_out[t] = eps1;
             }
         } else if (active) {
-            const double l0 = c.pr_sd_loc ? c.pr_sd_loc[t] : 0.0;
-            // LogNormal(sd_loc, sd_scale) prior: the default scale lives in a float32
-            // tensor in the reference (model.py:405-406), so torch forms scale**2 and
-            // log(scale) in float32; user-supplied --prior-params are taken as float64
-            double var0, logs0;
-            if (c.pr_sd_scale) {
-                const double s0 = c.pr_sd_scale[t];
-                var0 = s0 * s0;
-                logs0 = log(s0);
-            } else {
-                const float s0f = (float)c.sd_prior_scale;
-                var0 = (double)(s0f * s0f);
-                logs0 = (double)logf(s0f);
-            }
             if (FINISH) {
                 const double eps1 = eps1_f, eps2 = eps2_f;
-                const double mu = mu_f, y = y_f;
                 const double s_mu = exp((double)pf[1]), s_sd = exp((double)pf[3]);
-                double logp_mu, dlogp_mu;
-                if (c.flags & kPriorNormalMu) {
-                    const double pl = c.pr_mu_loc ? c.pr_mu_loc[t] : 0.0;
-                    const double ps = c.pr_mu_scale ? c.pr_mu_scale[t] : 1.0;
-                    const double zz = (mu - pl) / ps;
-                    logp_mu = -0.5 * zz * zz - log(ps) - kHalfLog2PiC;
-                    dlogp_mu = -zz / ps;
-                } else {
-                    logp_mu = -kLog2 - fabs(mu);
-                    dlogp_mu = mu > 0.0 ? -1.0 : (mu < 0.0 ? 1.0 : 0.0);
-                }
-                const double dy0 = y - l0;
-                const double logp_sd = -y - logs0 - kHalfLog2PiC - dy0 * dy0 / (2.0 * var0);
-                const double dlogp_dy = -1.0 - dy0 / var0;
-                const double logq_mu = -0.5 * eps1 * eps1 - (double)pf[1] - kHalfLog2PiC;
-                const double logq_sd = -y - 0.5 * eps2 * eps2 - (double)pf[3] - kHalfLog2PiC;
-                loss_fin = -logp_mu - logp_sd + logq_mu + logq_sd;
+                double dlogp_mu, dlogp_dy;
+                tgt_prior_terms(c, t, tgt_sd_prior(c, t), mu_f, y_f, eps1, eps2, pf[1], pf[3], dlogp_mu, dlogp_dy,
+                                loss_fin);
                 const double Gmu = gmu - dlogp_mu;
                 const double Gy = gy - dlogp_dy;
-                emit_grad_pre<ADAM>(c, 0, t, Gmu, ak, pf[0], mf[0], vf[0]);
-                emit_grad_pre<ADAM>(c, 1, t, Gmu * eps1 * s_mu - 1.0, ak, pf[1], mf[1], vf[1]);
-                emit_grad_pre<ADAM>(c, 2, t, Gy - 1.0, ak, pf[2], mf[2], vf[2]);
-                emit_grad_pre<ADAM>(c, 3, t, Gy * eps2 * s_sd - 1.0 - eps2 * s_sd, ak, pf[3], mf[3], vf[3]);
+                emit_grad_pre<ADAM>(c, 0, t, tgt_grad(0, Gmu, eps1, s_mu), ak, pf[0], mf[0], vf[0]);
+                emit_grad_pre<ADAM>(c, 1, t, tgt_grad(1, Gmu, eps1, s_mu), ak, pf[1], mf[1], vf[1]);
+                emit_grad_pre<ADAM>(c, 2, t, tgt_grad(2, Gy, eps2, s_sd), ak, pf[2], mf[2], vf[2]);
+                emit_grad_pre<ADAM>(c, 3, t, tgt_grad(3, Gy, eps2, s_sd), ak, pf[3], mf[3], vf[3]);
             }
-            BEAN_STAMP_AT(2);
+            BEAN_STAMP_KP(2);
             if (PREP) {
                 double eps1, eps2;
                 if (c.eps_mu_in) {
@@ -855,8 +1164,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                     eps1 = (double)n.x;
                     eps2 = (double)n.y;
                 }
-                const double mu = (double)pf[0] + eps1 * exp((double)pf[1]);
-                const double y = (double)pf[2] + eps2 * exp((double)pf[3]);
+                const double mu = tgt_draw(pf[0], eps1, pf[1]);
+                const double y = tgt_draw(pf[2], eps2, pf[3]);
                 c.eps_mu[t] = eps1;
                 c.eps_sd[t] = eps2;
                 c.mu_t[t] = mu;
@@ -869,7 +1178,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 tab_y = y;
             }
         }
-        BEAN_STAMP_AT(3);
+        BEAN_STAMP_KP(3);
         // ---- Phi tables: the B entries of a target are spread over the lanes of its group
         // (thin mode: kLanesPerTarget consecutive lanes; wide mode: the block's first threads)
         if (PREP && !c.survival && c.family != kMultiMixture) {
@@ -908,30 +1217,12 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 for (int rt = 0; rt < n_tab; ++rt) {
                     const double mu_r = c.n_cov ? mu + c.cov_shift[rt] : mu;
                     const long off = (long)rt * c.B * c.T;
-                    for (int e0 = 0; e0 < 2 * c.B; e0 += kLanesPerTarget) {
-                        const int e = e0 + j, b = e >> 1;
-                        const bool upper = (e & 1) == 0, live = t < c.T && b < c.B;
-                        const double z = live ? (upper ? c.z_hi[b] : c.z_lo[b]) : 0.0;
-                        double cdf = upper ? 1.0 : 0.0, pdf = 0.0, upd = 0.0;
-                        if (live && !isinf(z)) {
-                            const double u = (z - mu_r) * inv;
-                            cdf = norm_cdf(u);
-                            pdf = norm_pdf(u);
-                            upd = u * pdf;
-                        }
-                        const double cl = __shfl_xor(cdf, 1, 64), fl = __shfl_xor(pdf, 1, 64),
-                                     ufl = __shfl_xor(upd, 1, 64);
-                        if (live && upper) {
-                            const long o = off + (long)b * c.T + t;
-                            c.tabP[o] = cdf - cl;
-                            c.tabPmu[o] = -(pdf - fl) * inv;
-                            c.tabPy[o] = -(upd - ufl) * inv * dsig_dy;
-                        }
-                    }
+                    for (int e0 = 0; e0 < 2 * c.B; e0 += kLanesPerTarget)
+                        phi_edge(c, t, t < c.T, e0 + j, mu_r, inv, dsig_dy, off);
                 }
             }
         }
-        BEAN_STAMP_AT(4);
+        BEAN_STAMP_KP(4);
     } else if (c.family == kMultiMixture) {
         if (c.wide_alleles) param_guide_tiling_wide<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
         else param_guide_tiling<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
@@ -967,170 +1258,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     } else if (mixture) {
         // ------------------------------------------------- guide part
         const int g = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
-        const bool acc_on = (c.flags & kAcc) != 0;
-        const bool fit_noise = acc_on && (c.flags & kFitNoise);
-        if (g < c.G) {
-            float nl = 0.f, ns_u = 0.f;
-            if (fit_noise) {
-                nl = c.p[5][g];
-                ns_u = c.p[6][g];
-            }
-            if (FINISH) {
-                const float u0 = c.p[4][2 * g], u1 = c.p[4][2 * g + 1];
-                const double al0 = (double)expf(u0), al1 = (double)expf(u1);
-                const double s = al0 + al1, pa0 = c.pi_a0[g];
-                const double cp[2] = {al0 / s * pa0, al1 / s * pa0};
-                const bool cl[2] = {cp[0] < 1e-5, cp[1] < 1e-5};
-                const double cq[2] = {cl[0] ? 1e-5 : cp[0], cl[1] ? 1e-5 : cp[1]};
-                double lgS_p, dgS_p, lg_p[2], dg_p[2];
-                double lgS_q, dgS_q, lg_q[2], dg_q[2];
-                if (c.dgq) {
-                    // the guide side (c_q) was tabulated by the previous PREP for this alpha_pi
-                    const long Gl = c.G;
-                    lgS_q = c.dgq[g];
-                    lg_q[0] = c.dgq[Gl + g];
-                    lg_q[1] = c.dgq[2 * Gl + g];
-                    dgS_q = c.dgq[3 * Gl + g];
-                    dg_q[0] = c.dgq[4 * Gl + g];
-                    dg_q[1] = c.dgq[5 * Gl + g];
-                    lgS_p = lgS_q, dgS_p = dgS_q, lg_p[0] = lg_q[0], lg_p[1] = lg_q[1], dg_p[0] = dg_q[0], dg_p[1] = dg_q[1];
-                    if (cl[0] || cl[1]) {  // model side (c_p, unclamped) differs
-                        lgamma_digamma(cp[0] + cp[1], lgS_p, dgS_p);
-                        lgamma_digamma(cp[0], lg_p[0], dg_p[0]);
-                        lgamma_digamma(cp[1], lg_p[1], dg_p[1]);
-                    }
-                } else {
-                    lgamma_digamma(cp[0] + cp[1], lgS_p, dgS_p);
-                    lgamma_digamma(cp[0], lg_p[0], dg_p[0]);
-                    lgamma_digamma(cp[1], lg_p[1], dg_p[1]);
-                    lgS_q = lgS_p, dgS_q = dgS_p, lg_q[0] = lg_p[0], lg_q[1] = lg_p[1], dg_q[0] = dg_p[0], dg_q[1] = dg_p[1];
-                    if (cl[0] || cl[1]) {
-                        lgamma_digamma(cq[0] + cq[1], lgS_q, dgS_q);
-                        lgamma_digamma(cq[0], lg_q[0], dg_q[0]);
-                        lgamma_digamma(cq[1], lg_q[1], dg_q[1]);
-                    }
-                }
-                // per-replicate rows of the wave form: independent loads, four replicates in flight
-                double Lp_[2] = {0.0, 0.0}, Lq_[2] = {0.0, 0.0}, path_[2] = {0.0, 0.0}, nrg = 0.0;
-                double GA_[2] = {0.0, 0.0};
-                if (c.wrow && c.rows_v2) {
-                    // k_guide_wave2 rows: GA_a = sum_r of everything d loss / d c_a owes to the draws;
-                    // the (c - 1) log pi terms of the loss were added by the guide kernel
-                    const long RG = (long)c.R * c.G;
-                    const double* w = c.wrow + g;
-                    nrg = c.part[(long)kPNrg * c.G + g];  // data only (k_prepare)
-#pragma unroll 4
-                    for (int r = 0; r < c.R; ++r) {
-                        const double* wr = w + (long)r * c.G;
-                        GA_[0] += wr[3 * RG];
-                        GA_[1] += wr[4 * RG];
-                    }
-                } else if (c.wrow) {
-                    const long RG = (long)c.R * c.G;
-                    const double* w = c.wrow + g;
-                    nrg = c.part[(long)kPNrg * c.G + g];  // data only (k_prepare)
-#pragma unroll 4
-                    for (int r = 0; r < c.R; ++r) {
-                        const double* wr = w + (long)r * c.G;
-                        Lp_[0] += wr[kPLp * RG];
-                        Lp_[1] += wr[(kPLp + 1) * RG];
-                        Lq_[0] += wr[kPLq * RG];
-                        Lq_[1] += wr[(kPLq + 1) * RG];
-                        path_[0] += wr[kPPath * RG];
-                        path_[1] += wr[(kPPath + 1) * RG];
-                    }
-                } else {
-                    nrg = c.part[(long)kPNrg * c.G + g];
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        Lp_[a] = c.part[(long)(kPLp + a) * c.G + g];
-                        Lq_[a] = c.part[(long)(kPLq + a) * c.G + g];
-                        path_[a] = c.part[(long)(kPPath + a) * c.G + g];
-                    }
-                }
-                const double Rf = (double)c.R;
-                double gc[2];
-                double lp = nrg * (lgS_p - lg_p[0] - lg_p[1]);
-                double lq = Rf * (lgS_q - lg_q[0] - lg_q[1]);
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const double Lp = Lp_[a], Lq = Lq_[a], gpath = path_[a];
-                    lp += (cp[a] - 1.0) * Lp;
-                    lq += (cq[a] - 1.0) * Lq;
-                    const double g_cp = -(Lp + nrg * (dgS_p - dg_p[a]));
-                    const double g_cq = cl[a] ? 0.0 : (Lq + Rf * (dgS_q - dg_q[a]) + gpath);
-                    gc[a] = g_cp + g_cq;
-                }
-                if (c.wrow && c.rows_v2) {
-                    lp = nrg * (lgS_p - lg_p[0] - lg_p[1]);
-                    lq = Rf * (lgS_q - lg_q[0] - lg_q[1]);
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-                        gc[a] = -nrg * (dgS_p - dg_p[a]) + (cl[a] ? 0.0 : Rf * (dgS_q - dg_q[a])) + GA_[a];
-                }
-                loss_fin = -lp + lq;
-                BEAN_STAMP_AT(1);
-                const double dot = (gc[0] * al0 + gc[1] * al1) / s;
-                emit_grad<ADAM>(c, 4, 2 * g, pa0 / s * (gc[0] - dot) * al0, ak);
-                emit_grad<ADAM>(c, 4, 2 * g + 1, pa0 / s * (gc[1] - dot) * al1, ak);
-                if (acc_on) {
-                    const double lpn = c.lpn[g], eps = c.eps_noise[g];
-                    const double gl = lik_row(c, kPGnoise, g);
-                    const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
-                    // Normal(0, 0.655) prior held in float32 by the reference (utils.py:158-161)
-                    const float nsf = 0.655f;
-                    const double nvar = (double)(nsf * nsf);
-                    const double logp = -lpn * lpn / (2.0 * nvar) - (double)logf(nsf) - kHalfLog2PiC;
-                    const double logq = -0.5 * eps * eps - log(ns) - kHalfLog2PiC;
-                    loss_fin += -logp + logq;
-                    if (fit_noise) {
-                        const double Gl = gl + lpn / nvar;
-                        emit_grad<ADAM>(c, 5, g, Gl, ak);
-                        emit_grad<ADAM>(c, 6, g, Gl * eps * ns - 1.0, ak);
-                        if (ADAM) {
-                            nl = c.p[5][g];
-                            ns_u = c.p[6][g];
-                        }
-                    }
-                }
-            }
-            if (PREP && acc_on) {
-                double eps;
-                if (c.eps_noise_in) {
-                    eps = c.eps_noise_in[g];
-                } else {
-                    rocrand_state_philox4x32_10 st;
-                    rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)(c.g_off + g),
-                                 s_prep * 4ull, &st);
-                    eps = (double)rocrand_normal(&st);
-                }
-                const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
-                c.eps_noise[g] = eps;
-                c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
-                if (c.eps_noise_out) c.eps_noise_out[g] = eps;
-            }
-            BEAN_STAMP_AT(2);
-            if (PREP && c.dgq) {
-                // lgamma / digamma of the guide-side concentrations of the (updated) alpha_pi, for
-                // the next guide kernel and the next FINISH
-                const double al0 = (double)expf(c.p[4][2 * g]), al1 = (double)expf(c.p[4][2 * g + 1]);
-                const double s = al0 + al1, pa0 = c.pi_a0[g];
-                const double c0 = al0 / s * pa0, c1 = al1 / s * pa0;  // as FINISH forms c_p
-                const double q0 = c0 < 1e-5 ? 1e-5 : c0, q1 = c1 < 1e-5 ? 1e-5 : c1;
-                double lgS, dgS, lg0, dg0, lg1, dg1;
-                lgamma_digamma(q0 + q1, lgS, dgS);
-                lgamma_digamma(q0, lg0, dg0);
-                lgamma_digamma(q1, lg1, dg1);
-                const long Gl = c.G;
-                c.dgq[g] = lgS;
-                c.dgq[Gl + g] = lg0;
-                c.dgq[2 * Gl + g] = lg1;
-                c.dgq[3 * Gl + g] = dgS;
-                c.dgq[4 * Gl + g] = dg0;
-                c.dgq[5 * Gl + g] = dg1;
-            }
-            BEAN_STAMP_AT(4);
-        }
+        if (g < c.G) param_guide_mix<FINISH, ADAM, PREP, false>(c, g, ak, s_prep, loss_fin);
     }
     if (c.surv_q0lik && (int)blockIdx.x >= n_target_blocks) {
         // survival NormalModel: Dirichlet(initial_abundance) site over ALL guides, drawn per
@@ -1258,7 +1386,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         }
     }
     (void)loss_prep;
-    BEAN_STAMP_AT(7);
+    BEAN_STAMP_KP(7);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         StepCtr nxt;
         nxt.step = s_prep;
@@ -3082,6 +3210,23 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
         const double cl = isinf(zl) ? 0.0 : norm_cdf(zl);
         c.P0[threadIdx.x] = ch - cl;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && c.ue_z && !c.survival) {
+        int n = 0;
+        for (int k = 0; k < 2 * c.B; ++k) {
+            const double z = k < c.B ? c.z_hi[k] : c.z_lo[k - c.B];
+            int idx = -1;
+            if (!isinf(z)) {
+                for (int q = 0; q < n; ++q)
+                    if (c.ue_z[q] == z) idx = q;
+                if (idx < 0) {
+                    idx = n;
+                    c.ue_z[n++] = z;
+                }
+            }
+            c.ue_idx[k] = idx;
+        }
+        c.ue_idx[2 * c.B] = n;
+    }
 }
 
 // most targets spanned by one 64-guide tile (guides are target-sorted); *out must start at 0
@@ -3168,14 +3313,16 @@ __global__ __launch_bounds__(64) void k_cov_step(DevArgs c) {
     }
 }
 
-__global__ void k_set_step(StepCtr* a, StepCtr* b, unsigned long long step, unsigned long long slot) {
+__global__ void k_set_step(DevArgs c, unsigned long long step, unsigned long long slot) {
     StepCtr s;
     s.step = step;
     s.slot = slot;
-    s.step_size = 0.f;  // set by the guide kernel before any update uses it
+    // ClippedAdam step size of the first update (t = step + 1): the fused step kernel's first launch
+    // takes it from here, the two-launch path overwrites it (publish_ctr) with the same value
+    s.step_size = adam_coef(c, step + 1).step_size;
     s.pad_ = 0.f;
-    *a = s;
-    *b = s;
+    *c.ctrA = s;
+    *c.ctrB = s;
 }
 
 // Stand-alone ClippedAdam over one parameter array (bean_hip_adam).
@@ -3225,4 +3372,5 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
 }  // namespace bean
 
 #include "bean_guide_v2.hpp"
+#include "bean_step_v2.hpp"
 #include "bean_survival_v2.hpp"
