@@ -92,6 +92,7 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     const long wave_gid = wg;
 #endif
     BEAN_STAMP_AT(0);
+    BEAN_STAMP_CLK(0);
     BEAN_SETPRIO(0);
 
     const int g_first = tile * 64;
@@ -428,6 +429,7 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     }
     tot_o = wave_sum(loss);
     BEAN_STAMP_AT(7);
+    BEAN_STAMP_CLK(2);
     return true;
 }
 #undef W2_ROW_STORE

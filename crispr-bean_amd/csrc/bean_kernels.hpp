@@ -45,6 +45,19 @@ namespace bean {
 #else
 #define BEAN_STAMP_AT(slot) do {} while (0)
 #endif
+#if defined(BEAN_STAMP) && BEAN_STAMP == 4  // in-kernel clock: shader-clock and 100 MHz real-time stamps at both ends
+#define BEAN_STAMP_CLK(slot)                                                                     \
+    do {                                                                                         \
+        unsigned long long t_, u_;                                                               \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(u_)::"memory"); \
+        if (lane == 0) {                                                                         \
+            c.dbg[wave_gid * 8 + (slot)] = t_;                                                   \
+            c.dbg[wave_gid * 8 + (slot) + 1] = u_;                                               \
+        }                                                                                        \
+    } while (0)
+#else
+#define BEAN_STAMP_CLK(slot) do {} while (0)
+#endif
 #if defined(BEAN_STAMP) && BEAN_STAMP == 3  // the tail of the fused step kernel (one record per tile)
 #define BEAN_STAMP_TL(slot) BEAN_STAMP_WRITE(slot)
 #else
