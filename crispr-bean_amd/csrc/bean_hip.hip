@@ -667,7 +667,9 @@ static void launch_guide_wave2(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     const int tiles = (d.G + 63) / 64;
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8) * (unsigned)d.R), block(64);
-    const size_t lds = guide_wave2_lds(d.B, d.tile_targets);
+    // BEAN_HIP_LDS_PAD (bytes; experiments only): a larger LDS request lowers the number of resident waves
+    static const size_t lds_pad = getenv("BEAN_HIP_LDS_PAD") ? (size_t)atol(getenv("BEAN_HIP_LDS_PAD")) : 0;
+    const size_t lds = guide_wave2_lds(d.B, d.tile_targets) + lds_pad;
     const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {
