@@ -928,17 +928,19 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
 }
 
 static void launch_finalize(bean_hip_ctx* c, hipStream_t stream, uint64_t first, uint64_t n, bool cur) {
-    const unsigned blocks = cur ? 1u : (unsigned)((n + 255) / 256);
+    const unsigned blocks = cur ? 1u : (unsigned)((n + 3) / 4);  // one wave per slot
     hipLaunchKernelGGL(k_loss_finalize, dim3(blocks), dim3(cur ? 64 : 256), 0, stream, c->d, (unsigned long long)first,
                        (unsigned long long)n, cur ? 1 : 0);
 }
 
-static int clear_loss(bean_hip_ctx* c, hipStream_t stream, uint64_t first, uint64_t n) {
-    if (!n) return 0;
-    HIP_OK(hipMemsetAsync(c->d.loss_hist + first, 0, 8 * n, stream));
-    HIP_OK(hipMemsetAsync(c->d.loss_acc + (uint64_t)kLossSub * kLossWords * first, 0,
-                          sizeof(long long) * kLossSub * kLossWords * n, stream));
-    return 0;
+// step counters to (step, slot) and the loss accumulators of n slots from `slot` to zero
+static void launch_set_step(bean_hip_ctx* c, hipStream_t stream, uint64_t step, uint64_t slot, uint64_t n) {
+    const uint64_t words = n * kLossSub * kLossWords;
+    unsigned blocks = (unsigned)((words + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_set_step, dim3(blocks), dim3(256), 0, stream, c->d, (unsigned long long)step,
+                       (unsigned long long)slot, (unsigned long long)n);
 }
 
 extern "C" int bean_hip_elbo_grad(bean_hip_ctx* c, uint64_t seed, uint64_t step, uint64_t loss_index,
@@ -949,9 +951,7 @@ extern "C" int bean_hip_elbo_grad(bean_hip_ctx* c, uint64_t seed, uint64_t step,
     if (loss_index >= c->loss_capacity) return fail("bean_hip_elbo_grad: loss_index beyond loss_hist");
     hipStream_t stream = (hipStream_t)stream_;
     c->d.seed = seed;
-    if (clear_loss(c, stream, loss_index, 1)) return -1;
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d, (unsigned long long)step,
-                       (unsigned long long)loss_index);
+    launch_set_step(c, stream, step, loss_index, 1);
     launch_param<false, false, true>(c, stream);
     launch_guide(c, stream);
     launch_param<true, false, false>(c, stream);
@@ -1066,9 +1066,7 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
             c->graph_seed = seed;
         }
     }
-    if (clear_loss(c, stream, first_step, n_steps)) return -1;
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d, (unsigned long long)first_step,
-                       (unsigned long long)first_step);
+    launch_set_step(c, stream, first_step, first_step, n_steps);
     launch_param<false, false, true>(c, stream);
     if (fused) {
         // n launches of k_step_wave2 = {guide work, FINISH, PREP of the next step}; graphs hold even
@@ -1086,11 +1084,15 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
         launch_guide(c, stream);
         uint64_t pairs = n_steps - 1;
         if (use_graph) {
-            for (int k = (int)c->graphs.size() - 1; k >= 0; --k)
-                while (pairs >= (1ull << k)) {
-                    HIP_OK(hipGraphLaunch(c->graphs[k], stream));
-                    pairs -= 1ull << k;
-                }
+            // smallest graphs first: the device works on them while the host submits the larger ones
+            // (a launch of the 64-pair graph costs the host more than the step or two already enqueued)
+            const int kmax = (int)c->graphs.size() - 1;
+            uint64_t big = pairs >> kmax;           // launches of the largest graph
+            uint64_t rest = pairs - (big << kmax);  // < 2^kmax: one launch per set bit, ascending
+            for (int k = 0; k < kmax; ++k)
+                if (rest & (1ull << k)) HIP_OK(hipGraphLaunch(c->graphs[k], stream));
+            for (uint64_t i = 0; i < big; ++i) HIP_OK(hipGraphLaunch(c->graphs[kmax], stream));
+            pairs = 0;
         }
         enqueue_pairs(c, stream, pairs);
         launch_param<true, true, false>(c, stream);
@@ -1117,9 +1119,7 @@ extern "C" int bean_hip_sharded_begin(bean_hip_ctx* c, uint64_t seed, uint64_t f
         return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_TGRAD for a sharded ControlNormal / tiling fit");
     hipStream_t stream = (hipStream_t)stream_;
     c->d.seed = seed;
-    if (clear_loss(c, stream, first_step, n_steps)) return -1;
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, stream, c->d, (unsigned long long)first_step,
-                       (unsigned long long)first_step);
+    launch_set_step(c, stream, first_step, first_step, n_steps);
     launch_param<false, false, true>(c, stream);
     HIP_OK(hipGetLastError());
     return 0;

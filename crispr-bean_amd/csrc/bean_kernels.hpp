@@ -3252,16 +3252,27 @@ __global__ __launch_bounds__(256) void k_tile_targets(const int* g2t, int G, int
 
 // loss_hist[i] = accumulated parts of step i + the data-only constant, for n slots from `first`
 // (cur != 0: the one slot of the step that has just finished, read from the device step counter)
+// One wave per slot: lane l reads accumulator line l (kLossSub = 64 lines), integer wave sums.
 __global__ __launch_bounds__(256) void k_loss_finalize(DevArgs c, unsigned long long first, unsigned long long n,
                                                        int cur) {
-    unsigned long long i = first + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    unsigned long long i = first + (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (cur) {
-        if (blockIdx.x != 0 || threadIdx.x != 0) return;
+        if (blockIdx.x != 0 || threadIdx.x >= 64) return;
         i = c.ctrA->slot;
     } else if (i >= first + n) {
         return;
     }
-    c.loss_hist[i] = fixed_value(c.loss_acc + (long)i * kLossSub * kLossWords, kLossSub) + fixed_value(c.const_acc, 1);
+    static_assert(kLossSub == 64, "one accumulator line per lane");
+    const long long* acc = c.loss_acc + ((long)i * kLossSub + lane) * kLossWords;
+    const long long hi = wave_sum_i64(acc[0]), lo = wave_sum_i64(acc[1]);
+    long long bad = acc[2] != 0 ? 1 : 0;
+    bad = wave_sum_i64(bad);
+    if (lane == 0) {
+        const double v = bad != 0 ? __builtin_nan("")
+                                  : (double)hi * (1.0 / 1024.0) + (double)lo * (1.0 / 1099511627776.0);
+        c.loss_hist[i] = v + fixed_value(c.const_acc, 1);
+    }
 }
 
 // ---- sample covariates of the sorting NormalModel
@@ -3326,7 +3337,17 @@ __global__ __launch_bounds__(64) void k_cov_step(DevArgs c) {
     }
 }
 
-__global__ void k_set_step(DevArgs c, unsigned long long step, unsigned long long slot) {
+// grid = 1 + blocks over the accumulator words: also clears loss_hist and the loss accumulators of the
+// n slots from `slot` (two memsets less per call)
+__global__ __launch_bounds__(256) void k_set_step(DevArgs c, unsigned long long step, unsigned long long slot,
+                                                  unsigned long long n) {
+    const unsigned long long words = n * kLossSub * kLossWords;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < words;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        c.loss_acc[slot * kLossSub * kLossWords + i] = 0;
+        if (i < n) c.loss_hist[slot + i] = 0.0;
+    }
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     StepCtr s;
     s.step = step;
     s.slot = slot;
