@@ -1051,6 +1051,22 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     }
     double loss_fin = 0.0, loss_prep = 0.0;
     const bool mixture = c.family == kMixture;
+    // The guide kernel's per-wave loss parts (wave_loss_out).  Thin mode: every target block takes its
+    // share; the block's LAST wave issues the loads now and adds them up while it would otherwise idle at
+    // the barrier behind phase B (summed by the first blocks at the end of the kernel, they were the last
+    // ~2 us of its critical path).  Other modes: the strided pass at the end.
+    __shared__ long long lp3[3];
+    const bool lp_early = FINISH && c.lpart != nullptr && !c.wide_targets && !c.tgrad;
+    long long lw0 = 0, lw1 = 0, lw2 = 0;
+    if (lp_early && (int)blockIdx.x < n_target_blocks && threadIdx.x >= blockDim.x - 64) {
+        const long per = (c.n_lpart + n_target_blocks - 1) / n_target_blocks;
+        const long e0 = (long)blockIdx.x * per, e1 = e0 + per < c.n_lpart ? e0 + per : c.n_lpart;
+        for (long i = e0 + (threadIdx.x & 63); i < e1; i += 64) {
+            lw0 += c.lpart[3 * i];
+            lw1 += c.lpart[3 * i + 1];
+            lw2 += c.lpart[3 * i + 2];
+        }
+    }
 
     if ((int)blockIdx.x < n_target_blocks) {
         // ------------------------------------------------ target part
@@ -1104,6 +1120,16 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 if (active) {
                     gmu = hand[0][threadIdx.x];
                     gy = hand[1][threadIdx.x];
+                }
+                if (lp_early && threadIdx.x >= blockDim.x - 64) {  // idle until the next barrier
+                    lw0 = wave_sum_i64(lw0);
+                    lw1 = wave_sum_i64(lw1);
+                    lw2 = wave_sum_i64(lw2);
+                    if ((threadIdx.x & 63) == 0) {
+                        lp3[0] = lw0;
+                        lp3[1] = lw1;
+                        lp3[2] = lw2;
+                    }
                 }
             }
         }
@@ -1363,10 +1389,27 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         if ((int)blockIdx.x < n_target_blocks && c.not_loss_owner) loss_fin = 0.0;
         const double tot = block_sum(loss_fin, scratch);
         if (threadIdx.x == 0) {
-            loss_add(c, ctr.slot, tot);
+            if (lp_early && (int)blockIdx.x < n_target_blocks) {
+                // this block's prior / entropy terms and its share of the guide kernel's loss parts in
+                // one set of integer atomics
+                long long a = lp3[0], b = lp3[1], d = lp3[2];
+                if (fabs(tot) < 4.0e15) {
+                    const double hi = rint(tot * 1024.0);
+                    a += (long long)hi;
+                    b += (long long)rint((tot - hi * (1.0 / 1024.0)) * 1099511627776.0);
+                } else {
+                    d += 1;
+                }
+                long long* acc = c.loss_acc + ((long)ctr.slot * kLossSub + (blockIdx.x & (kLossSub - 1))) * kLossWords;
+                atomicAdd((unsigned long long*)acc, (unsigned long long)a);
+                atomicAdd((unsigned long long*)acc + 1, (unsigned long long)b);
+                if (d) atomicAdd((unsigned long long*)acc + 2, (unsigned long long)d);
+            } else {
+                loss_add(c, ctr.slot, tot);
+            }
         }
-        // the guide kernel's per-wave loss parts (wave_loss_out): the first blocks take 256 each
-        if (c.lpart && (long)blockIdx.x * blockDim.x < c.n_lpart) {
+        // other modes: the first blocks take 256 loss parts each
+        if (c.lpart && !lp_early && (long)blockIdx.x * blockDim.x < c.n_lpart) {
             __shared__ long long isum[3][16];
             long long ph = 0, pl = 0, pb = 0;
             for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < c.n_lpart; i += (long)gridDim.x * blockDim.x) {
