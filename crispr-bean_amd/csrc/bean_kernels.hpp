@@ -288,16 +288,49 @@ __device__ __forceinline__ void wave_loss_out(const DevArgs& c, unsigned long lo
 }
 
 // ---------------------------------------------------------------- reductions
+// Wave-wide sums by DPP row shifts / broadcasts (the GFX9 scan: row_shr 1, 2, 4, 8, row_bcast 15, 31; the
+// total ends in lane 63 and is read back as a scalar): twelve 32-bit DPP moves for a 64-bit value where
+// the shuffle form needed twelve trips through the LDS crossbar (~1 000 cycles at the end of every wave).
+// Fixed order; the result is valid in every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_pair(int lo, int hi, int& olo, int& ohi) {
+    olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    int lo, hi;
+    dpp_pair<CTRL, ROW_MASK>((int)b, (int)(b >> 32), lo, hi);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_i64(long long b) {
+    int lo, hi;
+    dpp_pair<CTRL, ROW_MASK>((int)b, (int)(b >> 32), lo, hi);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    v += dpp_i64<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_i64<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_i64<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_i64<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_i64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_i64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return ((long long)hi << 32) | (unsigned int)lo;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    v += dpp_f64<0x111, 0xf>(v);
+    v += dpp_f64<0x112, 0xf>(v);
+    v += dpp_f64<0x114, 0xf>(v);
+    v += dpp_f64<0x118, 0xf>(v);
+    v += dpp_f64<0x142, 0xa>(v);
+    v += dpp_f64<0x143, 0xc>(v);
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
 // Sum over the block; result valid in thread 0.  `scratch` holds >= 16 doubles.
