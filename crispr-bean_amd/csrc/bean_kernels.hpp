@@ -516,7 +516,8 @@ __device__ __forceinline__ void phi_edge(const DevArgs& c, int t, bool live_t, i
         pdf = norm_pdf(u);
         upd = u * pdf;
     }
-    const double cl = __shfl_xor(cdf, 1, 64), fl = __shfl_xor(pdf, 1, 64), ufl = __shfl_xor(upd, 1, 64);
+    // the other edge of the bin sits on the neighbouring lane: quad_perm [1, 0, 3, 2]
+    const double cl = dpp_f64<0xB1, 0xf>(cdf), fl = dpp_f64<0xB1, 0xf>(pdf), ufl = dpp_f64<0xB1, 0xf>(upd);
     if (live && upper) {
         const long o = off + (long)b * c.T + t;
         c.tabP[o] = cdf - cl;
@@ -705,6 +706,22 @@ __device__ __forceinline__ void target_of_group(const DevArgs& c, int& t, bool& 
     }
 }
 
+// Sum of two values over each aligned group of 16 lanes, in every lane: the xor tree 8, 4, 2, 1 as DPP
+// row rotations (a row IS 16 lanes; after the step with offset 8 the values repeat with period 8, after 4
+// with period 4, ..., so rotating by the offset reads the same operand the xor partner holds: same
+// additions, same bits as the shuffle tree, without the LDS crossbar).
+static_assert(kLanesPerTarget == 16, "group16_allsum: one DPP row per target");
+__device__ __forceinline__ void group16_allsum(double& a, double& b) {
+    a += dpp_f64<0x128, 0xf>(a);  // row_ror:8
+    b += dpp_f64<0x128, 0xf>(b);
+    a += dpp_f64<0x124, 0xf>(a);  // row_ror:4
+    b += dpp_f64<0x124, 0xf>(b);
+    a += dpp_f64<0x122, 0xf>(a);  // row_ror:2
+    b += dpp_f64<0x122, 0xf>(b);
+    a += dpp_f64<0x121, 0xf>(a);  // row_ror:1
+    b += dpp_f64<0x121, 0xf>(b);
+}
+
 // Likelihood gradient of one target w.r.t. its drawn mu_t / y_t: the guide -> target segmented
 // sum (a8), in a fixed order.  Valid in the `active` thread.
 __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool active, double* scratch,
@@ -744,11 +761,7 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
                 if (!c.survival) b += trow_sum(c, q_gsig + a1, gs) * sd * sd / c.sig_a[o];
             }
         }
-#pragma unroll
-        for (int off = kLanesPerTarget / 2; off > 0; off >>= 1) {
-            a += __shfl_xor(a, off, kLanesPerTarget);
-            b += __shfl_xor(b, off, kLanesPerTarget);
-        }
+        group16_allsum(a, b);
         gmu = a;
         gy = b;
         return;
@@ -794,11 +807,7 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
                     }
             }
         }
-#pragma unroll
-        for (int off = kLanesPerTarget / 2; off > 0; off >>= 1) {
-            a += __shfl_xor(a, off, kLanesPerTarget);
-            b += __shfl_xor(b, off, kLanesPerTarget);
-        }
+        group16_allsum(a, b);
         gmu = a;
         gy = b;
     }
