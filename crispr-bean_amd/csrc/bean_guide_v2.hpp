@@ -93,7 +93,6 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
 #endif
     BEAN_STAMP_AT(0);
     BEAN_STAMP_CLK(0);
-    BEAN_SETPRIO(0);
 
     const int g_first = tile * 64;
     const int g_last = (g_first + 63 < G ? g_first + 63 : G - 1);
@@ -277,8 +276,6 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
             if (lik == 1 && !use_bc) break;
             if (lik == 0) BEAN_STAMP_AT(2);
             else BEAN_STAMP_AT(5);
-            if (lik == 0) BEAN_SETPRIO(1);
-            else BEAN_SETPRIO(2);
             // the site is masked by (sum_b x > mask_thres) & repguide_mask (model.py:526-547)
             const double nn = lik ? n_bc : n_x;
             if (!(rgm && nn > (double)c.mask_thres)) continue;
@@ -353,7 +350,6 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
             g1 += S_1 - W * t_1;
         }
         BEAN_STAMP_AT(6);
-        BEAN_SETPRIO(3);
         double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
         W2_ROW_STORE(row + kW2Gmu * RG, a_mu);
         W2_ROW_STORE(row + kW2Gy * RG, a_y);

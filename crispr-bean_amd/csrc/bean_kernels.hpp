@@ -1061,24 +1061,6 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     const int lane = threadIdx.x & 63;
     const long wave_gid = (long)blockIdx.x * (kParamBlock / 64) + (threadIdx.x >> 6);
 #endif
-#ifdef BEAN_KP_SPECIAL  // experiment: what does the code of the other families cost this one?
-    __builtin_assume(c.family == kMixture);
-    __builtin_assume(!c.survival);
-    __builtin_assume(c.tgrad == nullptr);
-    __builtin_assume(!c.wide_targets);
-    __builtin_assume(c.n_cov == 0);
-    __builtin_assume(c.flags == 0);
-    __builtin_assume(c.pr_sd_loc == nullptr);
-    __builtin_assume(c.pr_sd_scale == nullptr);
-    __builtin_assume(c.eps_mu_in == nullptr);
-    __builtin_assume(c.eps_mu_out == nullptr);
-    __builtin_assume(c.dgq != nullptr);
-    __builtin_assume(c.wrow != nullptr);
-    __builtin_assume(c.rows_v2);
-    __builtin_assume(!c.surv_q0lik);
-    __builtin_assume(!c.not_loss_owner);
-    __builtin_assume(c.lpart != nullptr);
-#endif
     BEAN_STAMP_KP(0);
     const StepCtr ctr = *c.ctrA;
     const unsigned long long s_fin = ctr.step;
@@ -1550,17 +1532,6 @@ __device__ __forceinline__ double dirmult_nll(const float* __restrict__ xp, long
 #ifndef BEAN_WAVE_EU
 #define BEAN_WAVE_EU 4
 #endif
-// Experiment knob: wave priority by phase (s_setprio), see DESIGN.md "k_guide_wave"
-#ifndef BEAN_PRIO
-#define BEAN_PRIO 0
-#endif
-#if BEAN_PRIO == 1
-#define BEAN_SETPRIO(phase) __builtin_amdgcn_s_setprio(3 - (phase))
-#elif BEAN_PRIO == 2
-#define BEAN_SETPRIO(phase) __builtin_amdgcn_s_setprio(phase)
-#else
-#define BEAN_SETPRIO(phase) do {} while (0)
-#endif
 template <int FAM, bool ACC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BEAN_WAVE_EU)))
 void k_guide_wave(DevArgs c) {
@@ -1580,7 +1551,6 @@ void k_guide_wave(DevArgs c) {
     const long wave_gid = (long)blockIdx.y * gridDim.x + blockIdx.x;
 #endif
     BEAN_STAMP_AT(0);
-    BEAN_SETPRIO(0);
 
     // Guides are target-sorted, so the tile's targets are one contiguous range of at most 64:
     // lane i stages the 3 B table entries of target t0 + i (coalesced); every lane then reads its
@@ -1752,8 +1722,6 @@ void k_guide_wave(DevArgs c) {
             if (lik == 1 && !use_bc) break;
             if (lik == 0) BEAN_STAMP_AT(2);
             else BEAN_STAMP_AT(5);
-            if (lik == 0) BEAN_SETPRIO(1);
-            else BEAN_SETPRIO(2);
             const float* xp = xs + lik * B * 64 + lane;  // xp[b * 64]
             const double* sf = (lik ? c.sf_bc : c.sf) + r * B;
             // n = sum x_b is data: k_prepare leaves it in nobs (-1 where the (rep, guide) is masked)
@@ -1814,7 +1782,6 @@ void k_guide_wave(DevArgs c) {
             g1 += d0.dp * U_1 - V_1 - W * t_1;
         }
         BEAN_STAMP_AT(6);
-        BEAN_SETPRIO(3);
         double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
         row[kPGmu * RG] = a_mu;
         row[kPGy * RG] = a_y;
@@ -1860,13 +1827,8 @@ void k_guide_wave(DevArgs c) {
 #pragma unroll 1
             for (int a = 0; a < 2; ++a) {
                 if (a ? cl1 : cl0) continue;
-#if BEAN_DG_INLINE
-                const double v = dirichlet_grad_one_inl(a ? pi1 : pi0, a ? cq1 : cq0, total) *
-                                 ((a ? gpi1 : gpi0) - proj);
-#else
                 const double v = dirichlet_grad_one(a ? pi1 : pi0, a ? cq1 : cq0, total) *
                                  ((a ? gpi1 : gpi0) - proj);
-#endif
                 path0 = a ? path0 : v;
                 path1 = a ? v : path1;
             }

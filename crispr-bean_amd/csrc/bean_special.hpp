@@ -413,9 +413,6 @@ __device__ __forceinline__ Pair uniform_pair(Rng& rng) {
 // counter: words (x, y) give two standard normals by Box-Muller evaluated in float32 (the
 // reference draws in float32; a 32-bit radius uniform reaches 6.7 sigma), words (z, w) the two
 // acceptance uniforms in (0, 1).
-#ifndef BEAN_FAST_BM
-#define BEAN_FAST_BM 0
-#endif
 struct GammaRound {
     double na, nb, ua, ub;
 };
@@ -424,16 +421,9 @@ __device__ __noinline__ GammaRound gamma_round_at(unsigned long long seed, unsig
     const uint4 v = philox_block(seed, sub, offset);  // inlined: a leaf function needs no stack frame
     const float u1 = ((float)v.x + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
     const float u2 = (float)v.y * 2.3283064365386963e-10f;           // [0, 1]
-#if BEAN_FAST_BM
-    // hardware transcendentals: v_log_f32 is log2, v_sin_f32 / v_cos_f32 take their argument in
-    // revolutions (exactly the 2 pi u2 of Box-Muller); ~1e-6 absolute, the draws are float32 anyway
-    const float rad = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
-    const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
-#else
     const float rad = sqrtf(-2.0f * logf(u1));
     float sn, cs;
     sincospif(2.0f * u2, &sn, &cs);
-#endif
     GammaRound q;
     q.na = (double)(rad * cs);
     q.nb = (double)(rad * sn);
@@ -442,21 +432,8 @@ __device__ __noinline__ GammaRound gamma_round_at(unsigned long long seed, unsig
     return q;
 }
 
-// log in the Marsaglia-Tsang acceptance test (taken only when the squeeze test fails).
-// BEAN_SAMPLER_F32: hardware float32 log - the test compares against a uniform draw, so a 1e-7
-// relative error in the boundary moves the accepted region by that much (no effect on parity, which
-// replays the exported draws; the distribution tests in tests/test_gpu_samplers.py cover the draws).
-#ifndef BEAN_SAMPLER_F32
-#define BEAN_SAMPLER_F32 0
-#endif
-
-__device__ __forceinline__ double accept_log(double x) {
-#if BEAN_SAMPLER_F32
-    return (double)__logf((float)x);
-#else
-    return flog(x);
-#endif
-}
+// log in the Marsaglia-Tsang acceptance test (taken only when the squeeze test fails)
+__device__ __forceinline__ double accept_log(double x) { return flog(x); }
 
 struct GammaPair {
     double g0, g1;
