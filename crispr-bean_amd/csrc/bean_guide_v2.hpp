@@ -42,21 +42,10 @@ __device__ __forceinline__ double alpha_raw(double w0, double p0, double w1, dou
 }
 
 // Diagnostic builds only (wrong results): -DBEAN_GW_DIAG=n removes one piece of the kernel so that A/B
-// timings give that piece's cost in place: 1 sampler, 2 implicit-gradient calls, 3 lgamma/digamma
-// differences (replaced by two multiplies), 4 second bin loop.
+// timings give that piece's cost in place: 1 sampler, 2 implicit-gradient calls, 4 second bin loop.
 #ifndef BEAN_GW_DIAG
 #define BEAN_GW_DIAG 0
 #endif
-__device__ __forceinline__ DD gw_lgamma_diff(double a, double x) {
-#if BEAN_GW_DIAG == 3
-    DD d;
-    d.d = a * x;
-    d.dp = x;
-    return d;
-#else
-    return lgamma_digamma_diff_inl(a, x);
-#endif
-}
 
 // A row of this (replicate, guide) for the launch that follows (k_param), or - fused step kernel, STEP -
 // for the wave of the SAME launch that finishes the tile: then an agent-scope store (global_store ... sc1).
@@ -271,34 +260,64 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
             n_x += (double)xs[b * 64 + lane];
             n_bc += (double)xs[(B + b) * 64 + lane];
         }
+        // ---- loop 1 of BOTH likelihoods in one pass over the bins: the lgamma / digamma differences of
+        // X[b] and X_bcmatch[b] are independent dependency chains, evaluated side by side
+        // (lgamma_digamma_diff2).  The digamma differences are parked in LDS: those of X in dps[b], those
+        // of X_bcmatch as two 32-bit halves in the count slots of bin b, which are dead once read.
+        // The site is masked by (sum_b x > mask_thres) & repguide_mask (model.py:526-547): lane by lane.
+        const bool on_x = rgm && n_x > (double)c.mask_thres;
+        const bool on_bc = use_bc && rgm && n_bc > (double)c.mask_thres;
+        const double inv_x = frcp(S_x + kEps), inv_bc = frcp(S_bc + kEps);
+        const double ai_x = ms[0] * inv_x, ai_bc = ms[64] * inv_bc;
+        double A0_x = 0.0, A0_bc = 0.0, lsum_x = 0.0, lsum_bc = 0.0;
+        bool fl_x = false, fl_bc = false;
+        BEAN_STAMP_AT(2);
+        if (use_bc) {
+            unsigned int* xu = reinterpret_cast<unsigned int*>(xs);
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const double p0 = MIX ? c_p0[b] : 0.0, p1 = tp[b * ntm], smb = c_sm[b];
+                const double x0 = (double)xs[b * 64 + lane], x1 = (double)xs[(B + b) * 64 + lane];
+                const double ar0 = alpha_raw(w0, p0, w1, p1, c_sf[b], epsB, ai_x * smb);
+                const double ar1 = alpha_raw(w0, p0, w1, p1, c_sf[B + b], epsB, ai_bc * smb);
+                fl_x = fl_x || ar0 < kEps;
+                fl_bc = fl_bc || ar1 < kEps;
+                const double al0 = ar0 < kEps ? kEps : ar0, al1 = ar1 < kEps ? kEps : ar1;
+                A0_x += al0;
+                A0_bc += al1;
+                const DD2 dd = lgamma_digamma_diff2(al0, x0, al1, x1);
+                lsum_x += dd.a.d;
+                lsum_bc += dd.b.d;
+                dps[b * 64] = dd.a.dp;
+                const unsigned long long bits = __builtin_bit_cast(unsigned long long, dd.b.dp);
+                xu[b * 64 + lane] = (unsigned int)bits;
+                xu[(B + b) * 64 + lane] = (unsigned int)(bits >> 32);
+            }
+        } else {
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const double x0 = (double)xs[b * 64 + lane];
+                const double ar0 = alpha_raw(w0, MIX ? c_p0[b] : 0.0, w1, tp[b * ntm], c_sf[b], epsB, ai_x * c_sm[b]);
+                fl_x = fl_x || ar0 < kEps;
+                const double al0 = ar0 < kEps ? kEps : ar0;
+                A0_x += al0;
+                const DD db = lgamma_digamma_diff(al0, x0);
+                lsum_x += db.d;
+                dps[b * 64] = db.dp;
+            }
+        }
 #pragma unroll 1
         for (int lik = 0; lik < 2; ++lik) {
             if (lik == 1 && !use_bc) break;
-            if (lik == 0) BEAN_STAMP_AT(2);
-            else BEAN_STAMP_AT(5);
-            // the site is masked by (sum_b x > mask_thres) & repguide_mask (model.py:526-547)
-            const double nn = lik ? n_bc : n_x;
-            if (!(rgm && nn > (double)c.mask_thres)) continue;
-            const float* xp = xs + lik * B * 64 + lane;  // xp[b * 64]
+            if (lik == 1) BEAN_STAMP_AT(5);
+            if (!(lik ? on_bc : on_x)) continue;
             const double* sf = c_sf + lik * B;
-            const double S = lik ? S_bc : S_x;
+            const double nn = lik ? n_bc : n_x;
             const double a0 = ms[lik * 64];
-            const double inv = frcp(S + kEps);
-            const double ai = a0 * inv;
-            // loop 1: the lgamma / digamma differences; digamma differences parked in LDS
-            double A0 = 0.0, lsum = 0.0;
-            bool floored = false;
-#pragma unroll 1
-            for (int b = 0; b < B; ++b) {
-                const double x = (double)xp[b * 64];
-                const double araw = alpha_raw(w0, MIX ? c_p0[b] : 0.0, w1, tp[b * ntm], sf[b], epsB, ai * c_sm[b]);
-                const double alpha = araw < kEps ? kEps : araw;
-                floored = floored || araw < kEps;
-                A0 += alpha;
-                const DD db = gw_lgamma_diff(alpha, x);
-                lsum += db.d;
-                dps[b * 64] = db.dp;
-            }
+            const double inv = lik ? inv_bc : inv_x;
+            const double ai = lik ? ai_bc : ai_x;
+            const double A0 = lik ? A0_bc : A0_x, lsum = lik ? lsum_bc : lsum_x;
+            const bool floored = lik ? fl_bc : fl_x;
             if (lik == 0) BEAN_STAMP_AT(3);
             // total term lgamma(A0 + n) - lgamma(A0): data unless a bin sits on its floor
             // (DevArgs::tot_const); a lane's arithmetic does not depend on its wave's other lanes
@@ -328,7 +347,13 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
                 const double sfb = sf[b];
                 const double km = ai * c_sm[b];
                 const double araw = alpha_raw(w0, p0, w1, p1, sfb, epsB, km);
-                const double ga = araw < kEps ? 0.0 : d0.dp - dps[b * 64];
+                double dpb = dps[b * 64];
+                if (lik) {
+                    const unsigned int* xu = reinterpret_cast<const unsigned int*>(xs);
+                    dpb = __builtin_bit_cast(double, ((unsigned long long)xu[(B + b) * 64 + lane] << 32) |
+                                                         (unsigned long long)xu[b * 64 + lane]);
+                }
+                const double ga = araw < kEps ? 0.0 : d0.dp - dpb;
                 Wa += ga * araw;
                 const double cb = ga * km * sfb;
                 S_mu += cb * pmu;

@@ -34,6 +34,7 @@ __device__ __forceinline__ double frcp(double x) {
 // natural log of a positive normal double: x = m 2^e, m in [sqrt(1/2), sqrt(2)),
 // log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, series to s^19.
 __device__ __forceinline__ double flog(double x) {
+#pragma clang fp contract(off)  // every rounding pinned: the same bits wherever this is inlined
     int e = __builtin_amdgcn_frexp_exp(x);
     double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
     const bool lo = m < 0.70710678118654752440;
@@ -55,46 +56,54 @@ __device__ __forceinline__ double flog(double x) {
     // e*ln2 split so that the leading product is exact for |e| < 2^11
     const double hi = ed * 6.93147180369123816490e-01;
     const double lo2 = fma(ed, 1.90821492927058770002e-10, s * z * p);
-    return hi + (2.0 * s + lo2);
+    return hi + fma(2.0, s, lo2);
 }
 
 // Stirling tails, valid to ~1e-14 absolute for z >= 10 (r = 1/z, w = r*r).
 __device__ __forceinline__ double stirling_lgamma_tail(double r, double w) {
     // 1/(12 z) - 1/(360 z^3) + 1/(1260 z^5) - 1/(1680 z^7) + 1/(1188 z^9)
-    return r * (8.3333333333333333e-2 +
-                w * (-2.7777777777777778e-3 +
-                     w * (7.9365079365079365e-4 +
-                          w * (-5.9523809523809524e-4 + w * 8.4175084175084175e-4))));
+    double t = 8.4175084175084175e-4;
+    t = fma(w, t, -5.9523809523809524e-4);
+    t = fma(w, t, 7.9365079365079365e-4);
+    t = fma(w, t, -2.7777777777777778e-3);
+    t = fma(w, t, 8.3333333333333333e-2);
+    return r * t;
 }
 __device__ __forceinline__ double stirling_digamma_tail(double w) {
     // 1/(12 z^2) - 1/(120 z^4) + 1/(252 z^6) - 1/(240 z^8) + 1/(132 z^10) - 691/(32760 z^12)
-    return w * (8.3333333333333333e-2 +
-                w * (-8.3333333333333333e-3 +
-                     w * (3.9682539682539683e-3 +
-                          w * (-4.1666666666666667e-3 +
-                               w * (7.5757575757575758e-3 + w * -2.1092796092796093e-2)))));
+    double t = -2.1092796092796093e-2;
+    t = fma(w, t, 7.5757575757575758e-3);
+    t = fma(w, t, -4.1666666666666667e-3);
+    t = fma(w, t, 3.9682539682539683e-3);
+    t = fma(w, t, -8.3333333333333333e-3);
+    t = fma(w, t, 8.3333333333333333e-2);
+    return w * t;
 }
 
 // Longer Stirling tails, valid to ~1e-14 / 3e-14 absolute for z >= 6 (terms through B16): used for
 // the small argument of a difference so that its shift loop (divergent, and followed by a log and a
 // division) is only needed below 6 instead of below 10.
 __device__ __forceinline__ double stirling_lgamma_tail_long(double r, double w) {
-    return r * (8.3333333333333333e-2 +
-                w * (-2.7777777777777778e-3 +
-                     w * (7.9365079365079365e-4 +
-                          w * (-5.9523809523809524e-4 +
-                               w * (8.4175084175084175e-4 +
-                                    w * (-1.9175269175269175e-3 +
-                                         w * (6.4102564102564103e-3 + w * -2.9550653594771242e-2)))))));
+    double t = -2.9550653594771242e-2;
+    t = fma(w, t, 6.4102564102564103e-3);
+    t = fma(w, t, -1.9175269175269175e-3);
+    t = fma(w, t, 8.4175084175084175e-4);
+    t = fma(w, t, -5.9523809523809524e-4);
+    t = fma(w, t, 7.9365079365079365e-4);
+    t = fma(w, t, -2.7777777777777778e-3);
+    t = fma(w, t, 8.3333333333333333e-2);
+    return r * t;
 }
 __device__ __forceinline__ double stirling_digamma_tail_long(double w) {
-    return w * (8.3333333333333333e-2 +
-                w * (-8.3333333333333333e-3 +
-                     w * (3.9682539682539683e-3 +
-                          w * (-4.1666666666666667e-3 +
-                               w * (7.5757575757575758e-3 +
-                                    w * (-2.1092796092796093e-2 +
-                                         w * (8.3333333333333333e-2 + w * -4.4325980392156863e-1)))))));
+    double t = -4.4325980392156863e-1;
+    t = fma(w, t, 8.3333333333333333e-2);
+    t = fma(w, t, -2.1092796092796093e-2);
+    t = fma(w, t, 7.5757575757575758e-3);
+    t = fma(w, t, -4.1666666666666667e-3);
+    t = fma(w, t, 3.9682539682539683e-3);
+    t = fma(w, t, -8.3333333333333333e-3);
+    t = fma(w, t, 8.3333333333333333e-2);
+    return w * t;
 }
 
 constexpr double kShift = 10.0;
@@ -132,11 +141,54 @@ __device__ __forceinline__ double digamma(double z) {
     return dg;
 }
 
+// The series part of D(a, x) for shifted arguments z1 >= kShiftLo (from a, shift product P1 and its
+// derivative Q1) and z2 >= kShift: roundings pinned.  With P1 == 1 (no shift) log P1 = 0 and Q1 = 0 exactly,
+// so the correction is added unconditionally.
+__device__ __forceinline__ void stirling_diff(double z1, double z2, double P1, double Q1, double& d, double& dp) {
+#pragma clang fp contract(off)
+    const double l1 = flog(z1), l2 = flog(z2);
+    const double r1 = frcp(z1), r2 = frcp(z2);
+    const double w1 = r1 * r1, w2 = r2 * r2;
+    const double head = (z2 - 0.5) * l2 - (z1 - 0.5) * l1 - (z2 - z1);
+    d = head + (stirling_lgamma_tail(r2, w2) - stirling_lgamma_tail_long(r1, w1));
+    dp = (l2 - l1) - 0.5 * (r2 - r1) - (stirling_digamma_tail(w2) - stirling_digamma_tail_long(w1));
+    if (P1 != 1.0) {
+        d += flog(P1);
+        dp += Q1 * frcp(P1);
+    }
+}
+// two at once: the same operations, written side by side so that the scheduler interleaves the chains
+__device__ __forceinline__ void stirling_diff2(double z1a, double z2a, double P1a, double Q1a, double z1b, double z2b,
+                                               double P1b, double Q1b, double& da, double& dpa, double& db,
+                                               double& dpb) {
+#pragma clang fp contract(off)
+    const double l1a = flog(z1a), l1b = flog(z1b), l2a = flog(z2a), l2b = flog(z2b);
+    const double r1a = frcp(z1a), r1b = frcp(z1b), r2a = frcp(z2a), r2b = frcp(z2b);
+    const double w1a = r1a * r1a, w1b = r1b * r1b, w2a = r2a * r2a, w2b = r2b * r2b;
+    const double heada = (z2a - 0.5) * l2a - (z1a - 0.5) * l1a - (z2a - z1a);
+    const double headb = (z2b - 0.5) * l2b - (z1b - 0.5) * l1b - (z2b - z1b);
+    da = heada + (stirling_lgamma_tail(r2a, w2a) - stirling_lgamma_tail_long(r1a, w1a));
+    db = headb + (stirling_lgamma_tail(r2b, w2b) - stirling_lgamma_tail_long(r1b, w1b));
+    dpa = (l2a - l1a) - 0.5 * (r2a - r1a) - (stirling_digamma_tail(w2a) - stirling_digamma_tail_long(w1a));
+    dpb = (l2b - l1b) - 0.5 * (r2b - r1b) - (stirling_digamma_tail(w2b) - stirling_digamma_tail_long(w1b));
+    if (__any(P1a != 1.0 || P1b != 1.0)) {  // (adds exact zeros where nothing was shifted)
+        if (P1a != 1.0) {
+            da += flog(P1a);
+            dpa += Q1a * frcp(P1a);
+        }
+        if (P1b != 1.0) {
+            db += flog(P1b);
+            dpb += Q1b * frcp(P1b);
+        }
+    }
+}
+
 // D(a, x) = lgamma(a + x) - lgamma(a) and its derivative in a, for a > 0 and
 // x >= 0.  Counts are integer-valued, so small x uses the exact product form
 // prod_{i<x}(a + i); everything else is a difference of Stirling series, with
 // both arguments first raised to >= kShift.
 __device__ __forceinline__ DD lgamma_digamma_diff_inl(double a, double x) {
+#pragma clang fp contract(off)
     DD out;
     if (x == 0.0) {
         out.d = 0.0;
@@ -158,23 +210,45 @@ __device__ __forceinline__ DD lgamma_digamma_diff_inl(double a, double x) {
     double z1 = a, z2 = a + x, P1, Q1, P2, Q2;
     shift_up(z1, P1, Q1, kShiftLo);  // the concentration: longer tails instead of a longer shift
     shift_up(z2, P2, Q2);
-    const double l1 = flog(z1), l2 = flog(z2);
-    const double r1 = frcp(z1), r2 = frcp(z2);
-    const double w1 = r1 * r1, w2 = r2 * r2;
-    double d = (z2 - 0.5) * l2 - (z1 - 0.5) * l1 - (z2 - z1) +
-               (stirling_lgamma_tail(r2, w2) - stirling_lgamma_tail_long(r1, w1));
-    double dp = (l2 - l1) - 0.5 * (r2 - r1) -
-                (stirling_digamma_tail(w2) - stirling_digamma_tail_long(w1));
-    if (P1 != 1.0) {
-        d += flog(P1);
-        dp += Q1 * frcp(P1);
-    }
+    stirling_diff(z1, z2, P1, Q1, out.d, out.dp);
     if (P2 != 1.0) {
-        d -= flog(P2);
-        dp -= Q2 * frcp(P2);
+        out.d -= flog(P2);
+        out.dp -= Q2 * frcp(P2);
     }
-    out.d = d;
-    out.dp = dp;
+    return out;
+}
+
+// Two differences at once, as two INDEPENDENT dependency chains in one straight line of code: a wave
+// alone on its SIMD issues a float64 instruction every ~11 cycles along one chain, and a loop over bins
+// that evaluates one difference per iteration is one chain.  Same operations per chain as
+// lgamma_digamma_diff (bit-identical results); arguments with x <= 12 (product form, or a second
+// argument that still needs shifting) send the whole wave through the one-chain function.
+struct DD2 {
+    DD a, b;
+};
+__device__ BEAN_NOINLINE DD lgamma_digamma_diff(double a, double x);
+__device__ __forceinline__ DD2 lgamma_digamma_diff2(double a0, double x0, double a1, double x1) {
+    DD2 out;
+    if (__any(x0 <= 12.0 || x1 <= 12.0)) {
+        out.a = lgamma_digamma_diff(a0, x0);
+        out.b = lgamma_digamma_diff(a1, x1);
+        return out;
+    }
+    double z1a = a0, z1b = a1, P1a = 1.0, Q1a = 0.0, P1b = 1.0, Q1b = 0.0;
+    while (z1a < kShiftLo || z1b < kShiftLo) {
+        if (z1a < kShiftLo) {
+            Q1a = fma(Q1a, z1a, P1a);
+            P1a *= z1a;
+            z1a += 1.0;
+        }
+        if (z1b < kShiftLo) {
+            Q1b = fma(Q1b, z1b, P1b);
+            P1b *= z1b;
+            z1b += 1.0;
+        }
+    }
+    // a + x > 12 >= kShift: the second arguments need no shift
+    stirling_diff2(z1a, a0 + x0, P1a, Q1a, z1b, a1 + x1, P1b, Q1b, out.a.d, out.a.dp, out.b.d, out.b.dp);
     return out;
 }
 
