@@ -98,6 +98,7 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     float* xs = (float*)(cst + 4 * B + B * 64 + kW2Misc * 64);
     const bool use_bc = (c.flags & kUseBc) != 0;
     int tcol = 0;
+    uint4 philox_first = make_uint4(0u, 0u, 0u, 0u);
     bool rgm = false;
     float api0 = 0.f, api1 = 0.f;
     double pa0 = 0.0;
@@ -148,6 +149,12 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
             pa0 = c.pi_a0[gc];
         }
         const double a00 = c.a0[gc], a01 = use_bc ? c.a0_bc[gc] : 0.0;
+        // the draw's first Philox block needs the step and the guide index only: computed here, while
+        // the loads above are in flight (after a kernel boundary they take ~3.5 us and every wave of the
+        // SIMD waits for them at the same time)
+        if (MIX && !c.pi_in) philox_first = philox_block(c.seed, ((unsigned long long)kSitePi << 48) +
+                                                                   ((unsigned long long)r * c.G_tot + (c.g_off + gc)),
+                                                         ctr.step * 256ull);
         double cnt0 = 0.0, cnt1 = 0.0;
         if (MIX)
             for (int cc = 0; cc < c.C; ++cc) {
@@ -220,7 +227,7 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
 #endif
                 BEAN_STAMP_AT(1);
                 Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
-                const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng);
+                const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng, &philox_first);
                 const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
                 const double rs2 = frcp(gm0 + gm1);
                 pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);

@@ -490,9 +490,7 @@ __device__ __forceinline__ Pair uniform_pair(Rng& rng) {
 struct GammaRound {
     double na, nb, ua, ub;
 };
-__device__ __noinline__ GammaRound gamma_round_at(unsigned long long seed, unsigned long long sub,
-                                                  unsigned long long offset) {
-    const uint4 v = philox_block(seed, sub, offset);  // inlined: a leaf function needs no stack frame
+__device__ __forceinline__ GammaRound gamma_round_from(const uint4 v) {
     const float u1 = ((float)v.x + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
     const float u2 = (float)v.y * 2.3283064365386963e-10f;           // [0, 1]
     const float rad = sqrtf(-2.0f * logf(u1));
@@ -504,6 +502,10 @@ __device__ __noinline__ GammaRound gamma_round_at(unsigned long long seed, unsig
     q.ua = ((double)v.z + 0.5) * 2.3283064365386963e-10;
     q.ub = ((double)v.w + 0.5) * 2.3283064365386963e-10;
     return q;
+}
+__device__ __noinline__ GammaRound gamma_round_at(unsigned long long seed, unsigned long long sub,
+                                                  unsigned long long offset) {
+    return gamma_round_from(philox_block(seed, sub, offset));  // inlined: a leaf function needs no stack frame
 }
 
 // log in the Marsaglia-Tsang acceptance test (taken only when the squeeze test fails)
@@ -518,10 +520,19 @@ struct GammaPair {
 // alpha < 1 boost (the method behind torch's sample_gamma), sharing one
 // rejection loop: each round costs one Philox counter for both components (gamma_round_at),
 // and a wave only iterates until its slowest lane has accepted both.
-__device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1, Rng rng) {
+// `first`: the Philox block at the generator's first counter, where the caller has computed it ahead
+// (every lane consumes that block first, as the boost's uniforms or as the inputs of its first round).
+__device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1, Rng rng, const uint4* first = nullptr) {
     double scale0 = 1.0, scale1 = 1.0;
     if (a0 < 1.0 || a1 < 1.0) {
-        const Pair u = uniform_pair(rng);
+        Pair u;
+        if (first) {
+            u.a = Rng::to_unit(first->x, first->y);
+            u.b = Rng::to_unit(first->z, first->w);
+            ++rng.k;
+        } else {
+            u = uniform_pair(rng);
+        }
         if (a0 < 1.0) {
             scale0 = a0 == 0.0 ? 0.0 : exp(flog(u.a) * frcp(a0 == 0.0 ? 1.0 : a0));
             a0 += 1.0;
@@ -537,7 +548,9 @@ __device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1,
     double g0 = d0, g1 = d1;
 #pragma unroll 1
     for (int it = 0; it < 64 && !(done0 && done1); ++it) {  // >= 95 % acceptance per round
-        const GammaRound q = gamma_round_at(rng.seed, rng.sub, rng.off + 4ull * rng.k);
+        GammaRound q;
+        if (first && rng.k == 0) q = gamma_round_from(*first);
+        else q = gamma_round_at(rng.seed, rng.sub, rng.off + 4ull * rng.k);
         ++rng.k;
         if (!done0) {
             const double y = 1.0 + c0 * q.na;
