@@ -54,6 +54,7 @@ void k_guide_survival_wave(DevArgs c) {
     const bool use_bc = (c.flags & kUseBc) != 0;
     const bool q0lik = !MIX && c.surv_q0lik;
     bool rgm = false, negc = false;
+    uint4 philox_first = make_uint4(0u, 0u, 0u, 0u);
     float api0 = 0.f, api1 = 0.f, p7 = 0.f;
     double pa0 = 0.0, mu_t = 0.0, u = 0.0, gam = 0.0, lobs = 0.0;
     {
@@ -78,6 +79,10 @@ void k_guide_survival_wave(DevArgs c) {
         negc = q0lik && c.negctrl && c.negctrl[gc] != 0;
         mu_t = c.mu_t[c.g2t[gc]];
         const double a00 = c.a0[gc], a01 = use_bc ? c.a0_bc[gc] : 0.0;
+        // the pi draw's first Philox block, under the latency of the loads above (as in k_guide_wave2)
+        if (MIX && !c.pi_in) philox_first = philox_block(c.seed, ((unsigned long long)kSitePi << 48) +
+                                                                   ((unsigned long long)r * c.G_tot + (c.g_off + gc)),
+                                                         ctr.step * 256ull);
         if (MIX) {
             api0 = c.p[4][2 * gc];
             api1 = c.p[4][2 * gc + 1];
@@ -140,7 +145,7 @@ void k_guide_survival_wave(DevArgs c) {
                 pi1 = c.pi_in[rgi * 2 + 1];
             } else {
                 Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
-                const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng);
+                const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng, &philox_first);
                 const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
                 const double rs2 = frcp(gm0 + gm1);
                 pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
