@@ -577,16 +577,24 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
         if (FINISH) hipLaunchKernelGGL(k_cov_sum, dim3(d.R), dim3(1024), 0, stream, d);
         hipLaunchKernelGGL((k_cov_step<FINISH, ADAM, PREP>), dim3(1), dim3(64), 0, stream, d);
     }
+    // the specialised build of the kernel (k_param<..., 1>) where its launch conditions hold
+    const bool kind1 = !d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
+                       d.rows_v2 && !d.rrow && !d.surv_q0lik && !d.not_loss_owner && d.lpart &&
+                       (d.dgq || d.family != kMixture);
     if (c->profile && c->profile_param && FINISH && PREP && c->ev.size() < 8192) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
-        hipExtLaunchKernelGGL((k_param<FINISH, ADAM, PREP>), dim3(nb), dim3(kParamBlock), 0, stream, e0, e1, 0, d, ntb);
+        if (kind1)
+            hipExtLaunchKernelGGL((k_param<FINISH, ADAM, PREP, 1>), dim3(nb), dim3(kParamBlock), 0, stream, e0, e1, 0, d, ntb);
+        else
+            hipExtLaunchKernelGGL((k_param<FINISH, ADAM, PREP, 0>), dim3(nb), dim3(kParamBlock), 0, stream, e0, e1, 0, d, ntb);
         c->ev.push_back(e0);
         c->ev.push_back(e1);
         return;
     }
-    hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP>), dim3(nb), dim3(kParamBlock), 0, stream, d, ntb);
+    if (kind1) hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP, 1>), dim3(nb), dim3(kParamBlock), 0, stream, d, ntb);
+    else hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP, 0>), dim3(nb), dim3(kParamBlock), 0, stream, d, ntb);
 }
 
 template <int B>
