@@ -581,20 +581,32 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
     const bool kind1 = !d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
                        d.rows_v2 && !d.rrow && !d.surv_q0lik && !d.not_loss_owner && d.lpart &&
                        (d.dgq || d.family != kMixture);
-    if (c->profile && c->profile_param && FINISH && PREP && c->ev.size() < 8192) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool kind2 = d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
+                       d.rows_v2 && !d.rrow && d.lpart;
+    const bool kind3 = d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov &&
+                       !d.lpart && d.trow && d.trow_summed && !d.surv_q0lik;
+    const int kind = kind1 ? 1 : (kind2 ? 2 : (kind3 ? 3 : 0));
+    const bool prof = c->profile && c->profile_param && FINISH && PREP && c->ev.size() < 8192;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
-        if (kind1)
-            hipExtLaunchKernelGGL((k_param<FINISH, ADAM, PREP, 1>), dim3(nb), dim3(kParamBlock), 0, stream, e0, e1, 0, d, ntb);
-        else
-            hipExtLaunchKernelGGL((k_param<FINISH, ADAM, PREP, 0>), dim3(nb), dim3(kParamBlock), 0, stream, e0, e1, 0, d, ntb);
         c->ev.push_back(e0);
         c->ev.push_back(e1);
-        return;
     }
-    if (kind1) hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP, 1>), dim3(nb), dim3(kParamBlock), 0, stream, d, ntb);
-    else hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP, 0>), dim3(nb), dim3(kParamBlock), 0, stream, d, ntb);
+    const dim3 grid(nb), block(kParamBlock);
+#define BEAN_LAUNCH_PARAM(K)                                                                                    \
+    do {                                                                                                         \
+        if (prof) hipExtLaunchKernelGGL((k_param<FINISH, ADAM, PREP, K>), grid, block, 0, stream, e0, e1, 0, d, ntb); \
+        else hipLaunchKernelGGL((k_param<FINISH, ADAM, PREP, K>), grid, block, 0, stream, d, ntb);              \
+    } while (0)
+    switch (kind) {
+        case 1: BEAN_LAUNCH_PARAM(1); break;
+        case 2: BEAN_LAUNCH_PARAM(2); break;
+        case 3: BEAN_LAUNCH_PARAM(3); break;
+        default: BEAN_LAUNCH_PARAM(0); break;
+    }
+#undef BEAN_LAUNCH_PARAM
 }
 
 template <int B>

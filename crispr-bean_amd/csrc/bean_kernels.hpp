@@ -1069,6 +1069,28 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(c.lpart != nullptr);
         __builtin_assume(c.dgq != nullptr || c.family != kMixture);
     }
+    if (KIND == 2) {  // the survival variant families on the wave-form path (thin mode, unsharded parameters)
+        __builtin_assume(c.survival != 0);
+        __builtin_assume(c.family != kMultiMixture);
+        __builtin_assume(!c.wide_targets);
+        __builtin_assume(c.tgrad == nullptr);
+        __builtin_assume(c.n_cov == 0);
+        __builtin_assume(c.wrow != nullptr);
+        __builtin_assume(c.rows_v2 != 0);
+        __builtin_assume(c.rrow == nullptr);
+        __builtin_assume(c.lpart != nullptr);
+    }
+    if (KIND == 3) {  // tiling (MultiMixtureNormal) in the register-resident wave form, thin mode
+        __builtin_assume(c.family == kMultiMixture);
+        __builtin_assume(!c.wide_targets);
+        __builtin_assume(!c.wide_alleles);
+        __builtin_assume(c.tgrad == nullptr);
+        __builtin_assume(c.n_cov == 0);
+        __builtin_assume(c.lpart == nullptr);
+        __builtin_assume(c.trow != nullptr);
+        __builtin_assume(c.trow_summed != 0);
+        __builtin_assume(!c.surv_q0lik);
+    }
     __shared__ double scratch[16];
     __shared__ double hand[4][kTargetsPerBlock];  // phase hand-over: gmu, gy (A -> B), mu, y (B -> C)
 #if BEAN_KP_DIAG == 1  // diagnostic builds (wrong results): time the target part alone ...
