@@ -3488,6 +3488,12 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
         const double s = g0 + g1;
         o0[i] = fmin(fmax(g0 / s, kDblMin), kOneMinus);
         o1[i] = fmin(fmax(g1 / s, kDblMin), kOneMinus);
+    } else if (op == 5) {
+        // the two-chain form: this element as chain a, element i ^ 1 as chain b (must equal op 0 bit for bit)
+        const long j = (i ^ 1) < n ? (i ^ 1) : i;
+        const DD2 d = lgamma_digamma_diff2(a[i], x[i], a[j], x[j]);
+        o0[i] = d.a.d;
+        o1[i] = d.a.dp;
     }
 }
 

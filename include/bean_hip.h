@@ -277,7 +277,8 @@ int bean_hip_get_profile(bean_hip_ctx* ctx, double* avg_ms, uint64_t* launches);
  *   op 1: out0 = lgamma(a),             out1 = digamma(a)
  *   op 2: out0 = dirichlet_grad(x, a, total=b)
  *   op 3: out0 = Phi(a)
- *   op 4: out0, out1 = Dirichlet(a, b) draw (seed = x[0] bits, element index) */
+ *   op 4: out0, out1 = Dirichlet(a, b) draw (seed = x[0] bits, element index)
+ *   op 5: as op 0 through the two-chain evaluation (element i paired with element i ^ 1) */
 int bean_hip_test_special(int32_t op, uint64_t n, const double* a, const double* x,
                           const double* b, double* out0, double* out1, void* stream);
 

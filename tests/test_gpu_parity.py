@@ -56,6 +56,21 @@ def test_lgamma_digamma_differences(engine):
     assert np.max(np.abs(d.cpu().numpy() - ref_d)[small] / np.maximum(1.0, np.abs(ref_d[small]))) < 1e-13
 
 
+def test_two_chain_difference_is_bitwise_the_one_chain_function(engine):
+    """lgamma_digamma_diff2 (two independent chains side by side, csrc/bean_special.hpp) must return exactly
+    what lgamma_digamma_diff returns per element: waves mix the two (a wave with a count <= 12 in any lane
+    takes the one-chain function), so a lane's result must not depend on which one its wave ran."""
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    a = np.exp(rng.uniform(np.log(1e-5), np.log(1e5), n))
+    x = np.floor(np.exp(rng.uniform(np.log(13.0), np.log(1e5), n)))  # series branch in every lane of most waves
+    x[: n // 8] = rng.integers(0, 14, n // 8)                        # waves that fall back to the one-chain form
+    x[n // 8: n // 4] += 0.5
+    d1, p1 = engine.test_special(0, a, x)
+    d2, p2 = engine.test_special(5, a, x)
+    assert torch.equal(d1, d2) and torch.equal(p1, p2)
+
+
 def test_lgamma_digamma_and_phi(engine):
     rng = np.random.default_rng(1)
     a = np.exp(rng.uniform(np.log(1e-5), np.log(1e6), 100_000))
