@@ -585,7 +585,9 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
                        d.rows_v2 && !d.rrow && d.lpart;
     const bool kind3 = d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov &&
                        !d.lpart && d.trow && d.trow_summed && !d.surv_q0lik;
-    const int kind = kind1 ? 1 : (kind2 ? 2 : (kind3 ? 3 : 0));
+    // BEAN_HIP_PARAM_KIND=0 forces the generic build (the test that the specialised builds change nothing)
+    static const bool generic_only = getenv("BEAN_HIP_PARAM_KIND") && !strcmp(getenv("BEAN_HIP_PARAM_KIND"), "0");
+    const int kind = generic_only ? 0 : (kind1 ? 1 : (kind2 ? 2 : (kind3 ? 3 : 0)));
     const bool prof = c->profile && c->profile_param && FINISH && PREP && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {
