@@ -6,19 +6,29 @@
 One "step" is one full SVI step (draw, ELBO, gradient, ClippedAdam; ``bean/model/run.py:376-377``) over
 a synthetic screen that is already resident in HBM.
 
+``--gpus N`` with N > 1 works with or without a launcher: under ``torch.distributed.run`` (RANK /
+WORLD_SIZE in the environment) this process is one rank; started bare, it starts the N ranks itself as
+a child ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...``
+before anything touches the GPU, and passes rank 0's JSON line and the exit code through.
+
 ``--config`` (BASELINE.json ``configs``; default = the configuration ``metric`` is quoted on):
   metric    variant sorting MixtureNormal, 50k guides x 5 replicates x (4 sort bins + bulk)   [configs[1] shape x10]
   tiling    tiling sorting MultiMixtureNormal, 50k guides / ~193k edited alleles x 5 reps     [configs[2]]
   survival  survival MixtureNormal, 100k guides x 6 timepoints x 3 replicates                 [configs[4]]
 
-``--scaling`` with N > 1 ranks (launched by ``torch.distributed.run``, one process per GPU, RCCL):
-  weak    (default) every rank holds its own screen of the configured size; ``value`` counts steps of
-          one such screen summed over ranks.
-  strong  ONE screen (default 500k guides: BASELINE configs[3]) is cut on target boundaries into N
-          shards (``parallel.plan_shards``), one per rank, exactly as ``run_inference`` does under
-          torchrun; ``value`` = steps/s of the WHOLE screen.  The variant sorting family shares no
-          parameter across shards, so the only collective is the all-reduce of the loss window every 100
-          steps (the reference's reporting cadence, ``run.py:378``).
+Every run times TWO legs in the same process group (``--no-strong`` skips the second):
+  weak    every rank holds its own screen of the configured size; steps of one such screen summed over
+          ranks.  This is ``value`` (``--scaling weak``, the default) and the ``weak`` object.
+  strong  ONE screen - 500k-guide variant sorting (BASELINE configs[3]) for ``metric``, the 50k-guide
+          tiling screen (configs[2]) for ``tiling``, the 100k-guide survival screen (configs[4]) for
+          ``survival`` - cut into N shards exactly as ``run_inference`` cuts it under torchrun
+          (``parallel.plan_shards`` / ``plan_guide_shards``); steps/s of the WHOLE screen: the ``strong``
+          object (and ``value`` with ``--scaling strong``).  The variant sorting family shares no
+          parameter across shards (only the loss window is all-reduced, every 100 steps, the reference's
+          reporting cadence, ``run.py:378``); tiling and survival exchange inside every step
+          (``HipSVI.run_exchanged``: per-edit gradients / Dirichlet normalisers over RCCL).
+The driver's N = 1, 2, 4, 8 series therefore carries both curves; the north star's ">= 6x 1 -> 8" is
+``strong.value`` at N = 8 over ``strong.value`` at N = 1.
 
 Rank 0 prints ONE JSON line; DESIGN.md section 4 defines the ``roofline`` and ``cpu_baseline`` objects.
 """
@@ -98,6 +108,24 @@ def cpu_baseline(family, data, loss_fn, loss_kw, init_fn, seconds_budget=20.0):
         svi.svi_step(loss_fn, data, params, optim, **loss_kw)
         n += 1
     dt = time.perf_counter() - t0
+    # the reference enables anomaly detection on every step (bean/model/model.py:399): the same loop
+    # with it on, a few steps (the slower of the two numbers; `value` stays the conservative one)
+    prev = torch.is_anomaly_enabled()
+    torch.autograd.set_detect_anomaly(True)
+    try:
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            svi.svi_step(loss_fn, data, params, optim, **loss_kw)
+            ta = time.perf_counter()
+            na = 0
+            while na < 3 or (time.perf_counter() - ta < seconds_budget / 4 and na < 50):
+                svi.svi_step(loss_fn, data, params, optim, **loss_kw)
+                na += 1
+            dta = time.perf_counter() - ta
+    finally:
+        torch.autograd.set_detect_anomaly(prev)
     return {
         "value": n / dt,
         "unit": "steps/s",
@@ -105,6 +133,9 @@ def cpu_baseline(family, data, loss_fn, loss_kw, init_fn, seconds_budget=20.0):
         "kind": "port",
         "sample": f"{n} SVI steps of the same {data.n_guides}-guide screen (float64 eager-torch oracle, "
                   f"anomaly detection off, {dt:.1f} s; fastest of 8/16/32/64/{avail} threads)",
+        "value_anomaly_detection_on": na / dta,
+        "sample_anomaly_detection_on": f"{na} further steps with torch.autograd.set_detect_anomaly(True), as the "
+                                       f"reference runs (model.py:399), {dta:.1f} s",
     }
 
 
@@ -166,117 +197,254 @@ def valu_issue_roofline(config, kernel_name, kernel_ms):
     return out
 
 
+def self_launch(argv, n_ranks):
+    """``bench.py --gpus N`` started WITHOUT a launcher: start the N ranks ourselves.
+
+    Runs before this process has imported torch.cuda or made any GPU call: the ranks are a CHILD
+    process tree (``python -m torch.distributed.run``, rendezvous on 127.0.0.1), whose stdout - rank
+    0's JSON line - and exit code are passed through.  Under torchrun (RANK / WORLD_SIZE set) this is
+    never reached."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Leg:
+    """One timed workload of this rank: a screen (weak: its own; strong: its shard of ONE screen)
+    bound to a HipSVI engine, and the loop that steps it the way ``run_inference`` does."""
+
+    def __init__(self, args, config, strong, guides, rank, world, dev, total_steps):
+        import torch
+
+        from bean_amd import engine, parallel
+
+        self.strong, self.world, self.dev, self.guides = strong, world, dev, guides
+        self.graph_chunk = args.graph_chunk
+        acc = args.scale_by_acc and config == "metric"
+        # strong: every rank builds the SAME whole screen and keeps its shard
+        fam, data_cpu, loss_fn, loss_kw, init_fn, desc = workload(config, guides, 0 if strong else rank, acc=acc)
+        self.family, self.loss_fn, self.loss_kw, self.init_fn, self.desc = fam, loss_fn, loss_kw, init_fn, desc
+        self.eng_kw = dict(scale_by_accessibility=True) if acc else {}
+        tiling = fam == "MultiMixtureNormal"
+        survival = data_cpu.selection == "survival"
+        self.exchange = "none: every parameter is per target or per guide (loss window all-reduced every " \
+                        f"{LOSS_SYNC_EVERY} steps)"
+        if strong:
+            # the cut run_inference makes under torchrun (parallel.run_sharded)
+            if tiling:
+                shards = parallel.plan_guide_shards(data_cpu.n_guides, world, getattr(data_cpu, "n_targets", 0))
+            else:
+                shards = parallel.plan_shards(data_cpu.target_lengths.numpy(), world)
+            sh = shards[rank]
+            self.shard_cpu = parallel.shard_screen(data_cpu, sh)
+            self.offsets = dict(guide_offset=sh[0], target_offset=sh[2], n_guides_total=data_cpu.n_guides)
+            if tiling:
+                self.offsets["loss_owner"] = rank == 0
+            if survival:
+                self.offsets["t0_totals"] = (data_cpu.X[:, 0, :].to(torch.float32) + 1).sum(-1)
+        else:
+            self.shard_cpu = data_cpu
+            n_t = getattr(data_cpu, "n_targets", 0)
+            self.offsets = dict(guide_offset=rank * guides, target_offset=rank * n_t, n_guides_total=world * guides)
+            if tiling or survival:
+                self.offsets = {}  # independent screens: these families couple guides through shared quantities
+        self.data = self.shard_cpu.to(dev)
+        self.eng = engine.HipSVI(fam, self.data, num_steps=max(total_steps, 1), loss_capacity=total_steps + 64,
+                                 device=dev, **self.eng_kw, **self.offsets)
+        # families with something shared across shards step with an exchange inside every step
+        self.exchanged = strong and world > 1 and bool(self.eng.exchange_buffers())
+        if self.exchanged:
+            x = self.eng.exchange_buffers()
+            self.exchange = "per step: " + ", ".join(f"all-reduce {k} ({v.numel()} f64)" for k, v in x.items())
+
+    def run_steps(self, n):
+        import torch
+        import torch.distributed as dist
+
+        eng, done = self.eng, 0
+        while done < n:
+            k = min(LOSS_SYNC_EVERY, n - done)
+            first = eng.steps_done
+            if self.exchanged:
+                eng.run_exchanged(k, dist.all_reduce, seed=101)
+            else:
+                eng.run(k, seed=101, graph_chunk=self.graph_chunk)
+            if self.world > 1:
+                with torch.cuda.stream(eng.stream):
+                    dist.all_reduce(eng.loss_hist[first:first + k])
+            done += k
+
+    def fence(self):
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(self.dev)
+
+    def timed(self, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
+        import torch
+        import torch.distributed as dist
+
+        self.run_steps(warmup)
+        self.fence()
+        t0 = time.perf_counter()
+        self.run_steps(steps)
+        self.fence()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def kernel_profile(self, eng_steps=50):
+        """Dominant-kernel duration: HIP events carrying the kernel's own begin/end timestamps, on the
+        launch stream (eager launches of a second engine on the same screen)."""
+        import torch
+
+        from bean_amd import engine
+
+        prof = engine.HipSVI(self.family, self.data, num_steps=eng_steps, device=self.dev, **self.eng_kw,
+                             **self.offsets)
+        prof.set_profile(True)
+        prof.run(eng_steps, seed=101, graph_chunk=0)
+        torch.cuda.synchronize(self.dev)
+        k_ms, k_n = prof.get_profile()
+        out = (k_ms, k_n, prof.step_bytes, prof.dominant_kernel)
+        prof.close()
+        return out
+
+    def close(self):
+        self.eng.close()
+
+
+def dry_rehearsal(args, rank, world):
+    """BEAN_BENCH_REHEARSAL=dry (CPU containers, tests): the ranks rendezvous over gloo and rank 0
+    prints the JSON line with null measurements - checks the launch path, measures nothing."""
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": METRICS[args.config], "value": None, "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "rehearsal": "dry: no GPU touched, nothing measured",
+                          "config": {"workload": None, "config": args.config},
+                          "strong": {"guides": args.strong_guides or STRONG_GUIDES[args.config], "value": None,
+                                     "ms_per_step": None}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+METRICS = {"metric": "SVI steps/sec, 50k-guide x 20-sample sorting model",
+           "tiling": "SVI steps/sec, 50k-guide x 200k-allele tiling sorting model",
+           "survival": "SVI steps/sec, 100k-guide x 6-timepoint x 3-rep survival model"}
+# the ONE screen of the strong leg: BASELINE configs[3] (500k-guide variant sorting), configs[2], configs[4]
+STRONG_GUIDES = {"metric": 500_000, "tiling": 50_000, "survival": 100_000}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", choices=("metric", "tiling", "survival"), default="metric")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--guides", type=int, default=0, help="guides per GPU (weak) or of the whole screen (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="which leg `value` reports; the other one is still run (see --no-strong)")
+    ap.add_argument("--guides", type=int, default=0, help="guides per GPU of the weak leg")
+    ap.add_argument("--strong-guides", type=int, default=0, help="guides of the one screen of the strong leg")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong leg (weak `value` only)")
     ap.add_argument("--graph-chunk", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale-by-acc", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
-    import bean_amd  # noqa: F401
-    from bean_amd import engine, parallel
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher (nothing has touched the GPU yet)
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # rehearsal on a one-GPU box only: BEAN_BENCH_REHEARSAL=1 puts every rank on device 0 and
-    # exchanges over gloo (RCCL refuses two ranks on one device); never set by the driver
-    rehearsal = os.environ.get("BEAN_BENCH_REHEARSAL") == "1"
-    if rehearsal:
+    # rehearsals, never set by the driver: "1" puts every rank on device 0 of a one-GPU box and
+    # exchanges over gloo (RCCL refuses two ranks on one device); "dry" touches no GPU at all
+    rehearsal = os.environ.get("BEAN_BENCH_REHEARSAL", "")
+    if rehearsal == "dry":
+        return dry_rehearsal(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+
+    import bean_amd  # noqa: F401
+
+    if rehearsal == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        if rehearsal:
+        if rehearsal == "1":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    strong = args.scaling == "strong"
-    if strong and args.config != "metric":
-        raise SystemExit("--scaling strong is defined for --config metric (BASELINE configs[3])")
-    guides = args.guides or (STRONG_GUIDES if strong else DEFAULT_GUIDES[args.config])
-    # strong: every rank builds the SAME whole screen and keeps its target-aligned shard
-    family, data_cpu, loss_fn, loss_kw, init_fn, desc = workload(args.config, guides, 0 if strong else rank,
-                                                                 acc=args.scale_by_acc)
-    eng_kw = dict(scale_by_accessibility=True) if args.scale_by_acc else {}
-    if strong:
-        shards = parallel.plan_shards(data_cpu.target_lengths.numpy(), world)
-        sh = shards[rank]
-        shard_cpu = parallel.shard_screen(data_cpu, sh)
-        offsets = dict(guide_offset=sh[0], target_offset=sh[2], n_guides_total=data_cpu.n_guides)
-    else:
-        shard_cpu = data_cpu
-        n_t = getattr(data_cpu, "n_targets", 0)
-        offsets = dict(guide_offset=rank * guides, target_offset=rank * n_t, n_guides_total=world * guides)
-        if family == "MultiMixtureNormal" or data_cpu.selection == "survival":
-            offsets = {}  # independent screens: these families couple guides through shared quantities
-    data = shard_cpu.to(dev)
     total = args.warmup + args.steps
-    eng = engine.HipSVI(family, data, num_steps=max(total, 1), loss_capacity=total + 64, device=dev, **eng_kw,
-                        **offsets)
+    weak_guides = args.guides or DEFAULT_GUIDES[args.config]
+    strong_guides = args.strong_guides or STRONG_GUIDES[args.config]
+    want_strong = not args.no_strong or args.scaling == "strong"
+    # at one rank the strong leg of tiling / survival IS the weak leg (same screen, nothing to cut)
+    same_leg = world == 1 and strong_guides == weak_guides and not args.scale_by_acc
 
-    def run_steps(n):
-        done = 0
-        while done < n:
-            k = min(LOSS_SYNC_EVERY, n - done)
-            first = eng.steps_done
-            eng.run(k, seed=101, graph_chunk=args.graph_chunk)
-            if world > 1:
-                with torch.cuda.stream(eng.stream):
-                    dist.all_reduce(eng.loss_hist[first:first + k])
-            done += k
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    run_steps(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    losses = eng.losses()
-
-    # ---- dominant-kernel timing (HIP events with the kernel's own timestamps, on the launch stream)
-    eng_steps = 50
-    prof = engine.HipSVI(family, data, num_steps=eng_steps, device=dev, **eng_kw, **offsets)
-    prof.set_profile(True)
-    prof.run(eng_steps, seed=101, graph_chunk=0)
-    torch.cuda.synchronize(dev)
-    k_ms, k_n = prof.get_profile()
-    step_bytes = prof.step_bytes
-    kernel_name = prof.dominant_kernel
-    prof.close()
+    weak = Leg(args, args.config, False, weak_guides, rank, world, dev, total)
+    dt_weak = weak.timed(args.steps, args.warmup)
+    losses = weak.eng.losses()
+    k_ms, k_n, step_bytes, kernel_name = weak.kernel_profile()
+    strong_obj = None
+    if want_strong:
+        if same_leg:
+            sleg, dt_strong = weak, dt_weak
+        else:
+            weak.close()
+            sleg = Leg(args, args.config, True, strong_guides, rank, world, dev, total)
+            dt_strong = sleg.timed(args.steps, args.warmup)
+        strong_obj = {
+            "guides": strong_guides,
+            "guides_this_rank": int(sleg.data.n_guides),
+            "value": args.steps / dt_strong,
+            "unit": "steps/s of the WHOLE screen",
+            "ms_per_step": dt_strong / args.steps * 1e3,
+            "workload": sleg.desc + f"; ONE screen cut into {world} shard(s) as run_inference cuts it under torchrun",
+            "exchange": sleg.exchange,
+            "final_loss": sleg.eng.losses()[-1] if rank == 0 else None,
+        }
+        if sleg is not weak:
+            sleg.close()
 
     if rank == 0:
-        value = args.steps / dt if strong else world * args.steps / dt
-        std_size = guides == (STRONG_GUIDES if strong else DEFAULT_GUIDES[args.config]) and not args.scale_by_acc
-        traffic, traffic_src = pmc_traffic(args.config) if (std_size and not strong) else (None, None)
+        report_strong = args.scaling == "strong"
+        value = strong_obj["value"] if report_strong else world * args.steps / dt_weak
+        ms = strong_obj["ms_per_step"] if report_strong else dt_weak / args.steps * 1e3
+        std_size = weak_guides == DEFAULT_GUIDES[args.config] and not args.scale_by_acc
+        traffic, traffic_src = pmc_traffic(args.config) if std_size else (None, None)
         achieved = step_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        metric = {"metric": "SVI steps/sec, 50k-guide x 20-sample sorting model",
-                  "tiling": "SVI steps/sec, 50k-guide x 200k-allele tiling sorting model",
-                  "survival": "SVI steps/sec, 100k-guide x 6-timepoint x 3-rep survival model"}[args.config]
-        if strong:
-            metric = f"SVI steps/sec, {guides}-guide x 20-sample sorting screen guide-sharded over the ranks"
+        metric = METRICS[args.config]
+        if report_strong:
+            metric = f"SVI steps/sec, ONE {strong_guides}-guide screen ({args.config}) guide-sharded over the ranks"
         out = {
             "metric": metric,
             "value": value,
@@ -284,25 +452,26 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": ms,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": desc + "; one SVI step = draw + ELBO + grad + ClippedAdam"
-                            + (f"; this is the WHOLE screen, cut into {world} target-aligned shards" if strong
-                               else "; per GPU"),
+                "workload": (strong_obj["workload"] if report_strong else
+                             weak.desc + "; one SVI step = draw + ELBO + grad + ClippedAdam; per GPU"),
                 "config": args.config,
-                "guides": guides,
-                "guides_this_rank": int(data.n_guides),
-                "n_reps": int(data.n_reps),
-                "n_condits": int(data.n_condits),
-                "parallelism": (f"one screen guide-sharded x{world}" if strong else f"one screen per GPU x{world}")
+                "guides": strong_guides if report_strong else weak_guides,
+                "guides_this_rank": strong_obj["guides_this_rank"] if report_strong else int(weak.data.n_guides),
+                "n_reps": int(weak.data.n_reps),
+                "n_condits": int(weak.data.n_condits),
+                "parallelism": (f"one screen guide-sharded x{world}" if report_strong
+                                else f"one screen per GPU x{world}")
                                + f", loss all-reduce every {LOSS_SYNC_EVERY} steps",
                 "graph_chunk": args.graph_chunk,
-                "value_counts": "steps of the whole screen" if strong else "steps of one screen, summed over ranks",
+                "value_counts": ("steps of the whole screen" if report_strong
+                                 else "steps of one screen, summed over ranks"),
                 "final_loss": losses[-1] if losses else None,
             },
             "roofline": {
@@ -317,17 +486,24 @@ def main():
                 "algorithmic_bytes_per_launch": step_bytes,
                 "kernel_ms": k_ms,
                 "kernel_launches_timed": k_n,
+                "measured_on": f"the weak leg's screen ({weak_guides} guides on this rank)",
             },
         }
-        if std_size and not strong:
+        if strong_obj is not None:
+            out["strong"] = strong_obj
+        if not report_strong:
+            out["weak"] = {"guides_per_gpu": weak_guides, "value": world * args.steps / dt_weak,
+                           "ms_per_step": dt_weak / args.steps * 1e3}
+        if std_size:
             valu = valu_issue_roofline(args.config, kernel_name, k_ms)
             if valu is not None:
                 out["roofline"]["valu_issue"] = valu
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(family, shard_cpu, loss_fn, loss_kw, init_fn)
-            out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    eng.close()
+            out["cpu_baseline"] = cpu_baseline(weak.family, weak.shard_cpu, weak.loss_fn, weak.loss_kw, weak.init_fn)
+            out["config"]["gpu_over_cpu"] = (world * args.steps / dt_weak) / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if not (want_strong and not same_leg):
+        weak.close()
     if world > 1:
         dist.destroy_process_group()
 
