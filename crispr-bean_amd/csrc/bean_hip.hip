@@ -44,6 +44,8 @@ struct bean_hip_ctx {
     int* tile_targets_dev;
     bool tiling_wave;  // tiling families, default: k_guide_tiling_wave (BEAN_HIP_TILING=block: k_guide_tiling)
     bool tiling_wide;  // more alleles per guide than this build's kAMax: bean_tiling_wide.hpp
+    int tiling_rep_w;  // ... with this many waves per workgroup
+    bool tiling_rep;   // tiling families, default: k_guide_tiling_rep, the replicates of a guide share a wave (bean_tiling_v2.hpp)
     double* gsum_ws;  // library-owned normaliser buffer (replaced by BEAN_BUF_XCHG_GSUM when bound)
     double* sq_ws;    // library-owned projection sums (replaced by BEAN_BUF_XCHG_SQ when bound)
     // graph cache: graphs[k] replays 2^k {k_param, guide} pairs
@@ -316,11 +318,21 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
 
     c->tiling_wide = is_tiling(*s) && s->n_max_alleles > kAMax;
     c->tiling_wave = c->tiling_wave && is_tiling(*s) && !c->tiling_wide;
+    {
+        // default: the replicates of a guide share a wave and every row is reduced there
+        // (BEAN_HIP_TILING=wave: the per-replicate wave form + k_sum_trow, the A/B reference)
+        const char* tmode = getenv("BEAN_HIP_TILING");
+        c->tiling_rep = c->tiling_wave && s->n_reps <= kTilingRepMaxR && !(tmode && !strcmp(tmode, "wave"));
+        if (c->tiling_rep) c->tiling_wave = false;
+        // BEAN_HIP_TILING_W (1, 2 or 4; experiments only) overrides the number of waves per workgroup
+        const int w_env = getenv("BEAN_HIP_TILING_W") ? atoi(getenv("BEAN_HIP_TILING_W")) : 0;
+        c->tiling_rep_w = (w_env == 1 || w_env == 2 || w_env == 4) ? w_env : tiling_rep_waves(s->n_reps);
+    }
     d.wide_alleles = c->tiling_wide ? 1 : 0;
-    d.trow_summed = c->tiling_wave ? 1 : 0;
+    d.trow_summed = (c->tiling_wave || c->tiling_rep) ? 1 : 0;
     {
         const char* tc = getenv("BEAN_HIP_TOT_CONST");  // =0: the total terms are evaluated every step (A/B)
-        d.tot_const = ((c->wave2 || c->surv_wave || c->tiling_wave || c->tiling_wide) && !(tc && !strcmp(tc, "0"))) ? 1 : 0;
+        d.tot_const = ((c->wave2 || c->surv_wave || c->tiling_wave || c->tiling_rep || c->tiling_wide) && !(tc && !strcmp(tc, "0"))) ? 1 : 0;
     }
     {
         // one launch per step (bean_step_v2.hpp), opt-in (BEAN_HIP_STEP=fused; measured slower than the
@@ -344,7 +356,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     // per-wave loss parts of the wave-form guide kernels (1-D grid of padded tiles x replicates)
     const uint64_t n_lpart = (c->wave2 || c->surv_wave) ? ((G + 63) / 64 + 7) / 8 * 8 * Rr : 0;
     const uint64_t n_dgq = ((c->wave2 || c->surv_wave) && s->family == BEAN_FAMILY_MIXTURE_NORMAL) ? 6 * G : 0;
-    const uint64_t n_dgq_t = c->tiling_wave ? (uint64_t)(kAMax + 1) * G : 0;
+    const uint64_t n_dgq_t = (c->tiling_wave || c->tiling_rep) ? (uint64_t)(kAMax + 1) * G : 0;
     // arrival counters of the fused step kernel: per tile and per tile boundary (ints, zero between launches)
     const uint64_t n_ctr = c->wave2 ? ((G + 63) / 64 + 7) / 8 * 8 + 2 + 3 * B + 2 : 0;
     const uint64_t n_dbl = n_ctr + 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
@@ -584,7 +596,7 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
     const bool kind2 = d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
                        d.rows_v2 && !d.rrow && d.lpart;
     const bool kind3 = d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov &&
-                       !d.lpart && d.trow && d.trow_summed && !d.surv_q0lik;
+                       !d.lpart && d.trow_summed && !d.surv_q0lik;
     // BEAN_HIP_PARAM_KIND=0 forces the generic build (the test that the specialised builds change nothing)
     static const bool generic_only = getenv("BEAN_HIP_PARAM_KIND") && !strcmp(getenv("BEAN_HIP_PARAM_KIND"), "0");
     const int kind = generic_only ? 0 : (kind1 ? 1 : (kind2 ? 2 : (kind3 ? 3 : 0)));
@@ -794,6 +806,39 @@ static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
     hipLaunchKernelGGL(k_sum_trow, dim3((d.G + 255) / 256, kTNumPart), dim3(256), 0, stream, d);
 }
 
+// tiling families, the replicates of a guide in one wave (bean_tiling_v2.hpp): rows go straight to `part`
+static void launch_guide_tiling_rep(bean_hip_ctx* c, hipStream_t stream) {
+    const DevArgs& d = c->d;
+    const bool acc = (d.flags & kAcc) != 0;
+    const int waves = c->tiling_rep_w;
+    const int nt = 64 * waves;
+    const int gw = nt / d.R;  // guides per workgroup (R <= kTilingRepMaxR = 64, so >= 1)
+    const dim3 grid((unsigned)((d.G + gw - 1) / gw)), block(nt);
+    const size_t lds = (size_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * nt * sizeof(double) +
+                       (size_t)2 * d.B * nt * sizeof(float);
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {  // events with the kernel's own timestamps
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+    }
+#define BEAN_LAUNCH_TREP(ACC_, SURV_)                                                                              \
+    do {                                                                                                          \
+        if (prof) hipExtLaunchKernelGGL((k_guide_tiling_rep<ACC_, SURV_>), grid, block, lds, stream, e0, e1, 0, d, gw); \
+        else hipLaunchKernelGGL((k_guide_tiling_rep<ACC_, SURV_>), grid, block, lds, stream, d, gw);              \
+    } while (0)
+    if (d.survival) {
+        if (acc) BEAN_LAUNCH_TREP(true, true);
+        else BEAN_LAUNCH_TREP(false, true);
+    } else {
+        if (acc) BEAN_LAUNCH_TREP(true, false);
+        else BEAN_LAUNCH_TREP(false, false);
+    }
+#undef BEAN_LAUNCH_TREP
+}
+
 // survival variant families, one wave per (guide tile, replicate) (bean_survival_v2.hpp)
 // One SVI step in one launch (bean_step_v2.hpp); `flip` alternates the step-counter buffers.
 static void launch_step_wave2(bean_hip_ctx* c, hipStream_t stream, int flip) {
@@ -880,6 +925,10 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
     if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
         const long n = (long)(d.A - 1) * d.G;
         hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
+    }
+    if (c->tiling_rep) {
+        launch_guide_tiling_rep(c, stream);
+        return;
     }
     if (c->tiling_wave) {
         launch_guide_tiling_wave(c, stream);
@@ -1204,7 +1253,8 @@ extern "C" uint64_t bean_hip_step_bytes(const bean_hip_ctx* c) {
 
 extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
     if (c && c->d.family == kMultiMixture)
-        return c->tiling_wide ? "k_guide_tiling_wide" : (c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling");
+        return c->tiling_wide ? "k_guide_tiling_wide"
+                              : (c->tiling_rep ? "k_guide_tiling_rep" : (c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling"));
     if (c && c->d.survival) return c->surv_wave ? "k_guide_survival_wave" : "k_guide_survival";
     if (c && c->wave_guide) return c->wave2 ? (c->fused_step ? "k_step_wave2" : "k_guide_wave2") : "k_guide_wave";
     return "k_lik";

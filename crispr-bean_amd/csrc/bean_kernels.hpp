@@ -1087,7 +1087,6 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(c.tgrad == nullptr);
         __builtin_assume(c.n_cov == 0);
         __builtin_assume(c.lpart == nullptr);
-        __builtin_assume(c.trow != nullptr);
         __builtin_assume(c.trow_summed != 0);
         __builtin_assume(!c.surv_q0lik);
     }
@@ -3502,3 +3501,4 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
 #include "bean_guide_v2.hpp"
 #include "bean_step_v2.hpp"
 #include "bean_survival_v2.hpp"
+#include "bean_tiling_v2.hpp"

@@ -1,0 +1,394 @@
+// k_guide_tiling_rep: the per-(replicate, guide) kernel of the tiling families (MultiMixtureNormal,
+// up to kAMax alleles per guide), third form: THE REPLICATES OF A GUIDE SHARE A WORKGROUP.
+//
+// Same per-lane arithmetic as k_guide_tiling_wave (bean_kernels.hpp; reference semantics:
+// bean/model/model.py:550-751 model, 878-962 guide; survival_model.py:427-626, 738-833); what changed is
+// the thread map and, with it, what leaves the kernel:
+//   * thread = r * Gb + j: a workgroup of NT = 64 W threads holds Gb = NT / R consecutive guides times all
+//     R replicates (W = 4: 51 guides x 5 replicates = 255 of 256 lanes at the shape of BASELINE config 3;
+//     the host picks the W in {1, 2, 4} that fills most lanes).  Everything k_param needs
+//     from this kernel is a sum over the replicates of a guide, so each row is reduced IN THE WORKGROUP
+//     (through a dead LDS column, fixed order r = 0, 1, ... - the order k_sum_trow used, same bits) and the
+//     thread of replicate 0 stores one value to part[(q, g)].  The wave form wrote 32 rows per (replicate,
+//     guide) (79 MB per launch at config 3, the largest item of its traffic) for a second launch,
+//     k_sum_trow, to read back and add: both are gone.
+//   * the R threads of a guide read the same allele-table entries, per-guide values and parameters: one
+//     request per workgroup instead of one per replicate's wave (the wave form relied on an XCD-aware
+//     block order to get those re-reads out of L2 at least).
+//   * register diet (the wave form: 128 VGPRs + 10 spilled, 64 B of scratch per lane): the guide's
+//     concentrations (alpha_a, c_q a: 32 VGPRs) are needed by the sampler at the start and by the
+//     Dirichlet terms at the end, and are RECOMPUTED there from alpha_pi instead of held across the
+//     likelihoods; a row is reduced and stored where it is formed instead of collected in an array.
+//   * why not simply one wave = 12 guides x 5 replicates: 60 of 64 lanes, i.e. 4 167 waves for 50k guides
+//     against the chip's 4 096 wave slots (256 CUs x 16): a second round of 71 waves, measured + 50 %
+//     (205 us against 137).  The launch must stay inside one round at this size, so lanes cannot idle.
+// All threads run the whole body (threads past the last guide / past R * Gb on clamped indices, threads
+// whose (replicate, guide) is masked by repguide_mask on their real data): the row reductions have
+// workgroup barriers.
+#pragma once
+
+namespace bean {
+
+constexpr int kTilingRepMaxR = 64;  // more replicates than that: the wave form + k_sum_trow
+// waves per workgroup of k_guide_tiling_rep: of 1, 2, 4 the one that fills most lanes with (replicate,
+// guide) pairs, the smaller on a tie (R = 5: 60 / 64, 125 / 128, 255 / 256 -> 4; measured at config 3:
+// W = 2 188.6 us per step, W = 4 183.1)
+__host__ inline int tiling_rep_waves(int R) {
+    int best = 1;
+    double best_eff = 0.0;
+    for (int w = 1; w <= 4; w *= 2) {
+        const double eff = (double)((64 * w / R) * R) / (double)(64 * w);
+        if (eff > best_eff + 1e-12) {
+            best_eff = eff;
+            best = w;
+        }
+    }
+    return best;
+}
+
+template <bool ACC, bool SURV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+void k_guide_tiling_rep(DevArgs c, int Gw) {
+    extern __shared__ double tls[];
+    const int lane = threadIdx.x;  // thread of the workgroup: columns in LDS have NT entries
+    const int NT = blockDim.x;
+    const int G = c.G, A = c.A, A1 = c.A - 1, B = c.B, R = c.R;
+    // thread -> (replicate, guide of the workgroup); threads >= R * Gw are spare
+    int r = (int)(((float)lane + 0.5f) / (float)Gw);
+    const bool spare = r >= R;
+    if (spare) r = R - 1;
+    const int j = lane - r * Gw;
+    const long g_raw = (long)blockIdx.x * Gw + j;
+    const bool valid = !spare && g_raw < G;
+    const int g = g_raw < G ? (int)g_raw : G - 1;
+    const StepCtr ctr = *c.ctrB;
+    double* es = tls + lane;                 // e[b]              at es[b * NT]
+    double* gs = tls + B * NT + lane;        // d nll / d e[b]    at gs[b * NT]
+    double* ds = tls + 2 * B * NT + lane;    // digamma diffs     at ds[b * NT]
+    double* ps = tls + 3 * B * NT + lane;    // ACC: pe, d pe / d pi, d pe / d l at ps[(k * kAMax + a) * NT]
+    float* xs = (float*)(tls + (3 * B + (ACC ? 3 * kAMax : 0)) * NT) + lane;  // xs[(lik * B + b) * NT]
+
+    const bool rgm = c.rg[(long)r * G + g] != 0;
+    // both pi sites, the Multinomial and the count likelihoods are masked by repguide_mask in tiling
+    // (model.py:659,682,731; guide 941): a masked (replicate, guide) contributes nothing
+    const bool on = valid && rgm;
+    const bool store = valid && r == 0;
+    const bool use_bc = (c.flags & kUseBc) != 0;
+    // row q of this guide = sum over its replicates, r = 0 first.  Staged in the first column of e[] /
+    // of the digamma differences in turn - both dead once the likelihoods are done, which is before the
+    // first row exists - so one barrier per row is enough: the column written for row n + 2 is the one
+    // read for row n, and the barrier of row n + 1 lies between the two.
+    int n_rows_out = 0;
+    auto row_out = [&](int q, double v) {
+        double* col = tls + ((n_rows_out & 1) ? 2 * B * NT : 0);
+        ++n_rows_out;
+        col[lane] = on ? v : 0.0;
+        __syncthreads();
+        if (store) {
+            double s = col[j];
+            for (int rr = 1; rr < R; ++rr) s += col[rr * Gw + j];
+            c.part[(long)q * G + g] = s;
+        }
+    };
+
+    // counts of both likelihoods: one batch of loads, then LDS
+    {
+        float xv[2][kBMax];
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) {
+            const long xo = ((long)r * B + (b < B ? b : B - 1)) * G + g;
+            xv[0][b] = c.X[xo];
+            xv[1][b] = use_bc ? c.Xbc[xo] : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) {
+            const int bb = b < B ? b : B - 1;
+            xs[(0 * B + bb) * NT] = xv[0][b];
+            xs[(1 * B + bb) * NT] = xv[1][b];
+        }
+    }
+    const double pa0 = c.pi_a0[g];
+    // ---- draw: the concentrations of the guide's Dirichlet live only until the draw is done
+    double pi[kAMax];
+    {
+        double alpha[kAMax], Ssum = 0.0;
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {
+            const bool am = a < A && c.amask[(long)g * A + a] != 0;
+            alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
+            Ssum += alpha[a];
+        }
+        const double rsq = frcp(Ssum) * pa0;
+        if (c.pi_in) {
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a) pi[a] = a < A ? c.pi_in[((long)r * G + g) * A + a] : 0.0;
+        } else {
+            Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+            double sum = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; a += 2) {
+                pi[a] = 0.0;
+                pi[a + 1] = 0.0;
+                if (a < A) {  // components are drawn two at a time (one rejection loop per pair)
+                    double cq0 = alpha[a] * rsq, cq1 = a + 1 < A ? alpha[a + 1] * rsq : 1.0;
+                    if (SURV) {  // guide-side clamp (survival_model.py:813-821)
+                        cq0 = cq0 < 1e-5 ? 1e-5 : cq0;
+                        if (a + 1 < A) cq1 = cq1 < 1e-5 ? 1e-5 : cq1;
+                    }
+                    const GammaPair gp = sample_gamma_pair(cq0, cq1, rng);
+                    rng.k = gp.k;
+                    pi[a] = fmax(gp.g0, kDblMin);
+                    sum += pi[a];
+                    if (a + 1 < A) {
+                        pi[a + 1] = fmax(gp.g1, kDblMin);
+                        sum += pi[a + 1];
+                    }
+                }
+            }
+            const double rs = frcp(sum);
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a)
+                if (a < A) pi[a] = fmin(fmax(pi[a] * rs, kDblMin), kOneMinus);
+        }
+    }
+    if ((c.flags & kDumpPi) && valid) {
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a)
+            if (a < A) c.pi_out[((long)r * G + g) * A + a] = rgm ? pi[a] : 1.0 / A;
+    }
+    // ---- accessibility transform (utils.py:106-178); its per-allele pieces live in LDS
+    double pe0 = pi[0];
+    if (ACC) {
+        const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+        const double lpn = c.lpn[g];
+        double sum = 0.0;
+#pragma unroll
+        for (int a = 1; a < kAMax; ++a) {
+            if (a < A) {
+                const double s1 = pi[a] * kacc;
+                const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+                const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+                const double l = flog(p1c * frcp(1.0 - p1c)) + lpn;
+                const double el = exp(l);
+                const double pn = el * frcp(1.0 + el);
+                const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+                const double pea = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+                const double dl = in2 ? pn * (1.0 - pn) : 0.0;
+                ps[(0 * kAMax + a) * NT] = pea;
+                ps[(1 * kAMax + a) * NT] = in1 ? dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+                ps[(2 * kAMax + a) * NT] = dl;
+                sum += pea;
+            }
+        }
+        pe0 = 1.0 - sum;
+    }
+    const double u = SURV ? c.u_g[g] : 0.0;
+    // ---- e[b] = sum_a pe_a P_a[b]
+#pragma unroll 1
+    for (int b = 0; b < B; ++b) {
+        double v = pe0 * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
+#pragma unroll
+        for (int a = 1; a < kAMax; ++a)
+            if (a < A)
+                v += (ACC ? ps[(0 * kAMax + a) * NT] : pi[a]) * c.tabP[((long)b * A1 + (a - 1)) * G + g];
+        es[b * NT] = v;
+        gs[b * NT] = 0.0;
+    }
+    // ---- both Dirichlet-Multinomial terms, d nll / d e[b] accumulated in gs
+    double nll = 0.0;
+    {
+        const double* sm = c.smask + r * B;
+        const double epsB = kEps / (double)B;
+#pragma unroll 1
+        for (int lik = 0; lik < 2; ++lik) {
+            if (lik == 1 && !use_bc) break;
+            const float* xp = xs + lik * B * NT;
+            const double* sf = (lik ? c.sf_bc : c.sf) + r * B;
+            double nn = 0.0, S = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                nn += (double)xp[b * NT];
+                S += es[b * NT] * sf[b];
+            }
+            if (!(nn > (double)c.mask_thres)) continue;
+            const double a0 = lik ? c.a0_bc[g] : c.a0[g];
+            const double inv = frcp(S + kEps);
+            double A0 = 0.0, lsum = 0.0, Ua = 0.0, Va = 0.0;
+            bool anyfl = false;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const double araw = (es[b * NT] * sf[b] + epsB) * inv * a0 * sm[b];
+                const bool floored = araw < kEps;
+                anyfl = anyfl || floored;
+                const double al = floored ? kEps : araw;
+                A0 += al;
+                const DD db = lgamma_digamma_diff_inl(al, (double)xp[b * NT]);
+                lsum += db.d;
+                ds[b * NT] = db.dp;
+                Ua += floored ? 0.0 : araw;
+                Va += floored ? 0.0 : db.dp * araw;
+            }
+            // total term: data unless a bin sits on its floor (DevArgs::tot_const)
+            DD d0;
+            d0.d = 0.0;
+            d0.dp = 0.0;
+            if (!c.tot_const) {
+                d0 = lgamma_digamma_diff(A0, nn);
+            } else if (__any(anyfl)) {
+                const DD dt = lgamma_digamma_diff(A0, nn), dc = lgamma_digamma_diff(a0, nn);
+                if (anyfl) {
+                    d0.d = dt.d - dc.d;
+                    d0.dp = dt.dp;
+                }
+            }
+            nll += d0.d - lsum;
+            const double W = (d0.dp * Ua - Va) * inv;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const double sfb = sf[b], smb = sm[b];
+                const double araw = (es[b * NT] * sfb + epsB) * inv * a0 * smb;
+                const double ga = araw < kEps ? 0.0 : d0.dp - ds[b * NT];
+                gs[b * NT] += (ga * a0 * smb * inv - W) * sfb;
+            }
+        }
+    }
+    // ---- back through the mixture: d loss / d pi_a and the per-allele-slot rows
+    double s0 = 0.0;
+#pragma unroll 1
+    for (int b = 0; b < B; ++b)
+        s0 += gs[b * NT] * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
+    double gpi[kAMax], gnoise = 0.0;
+    double gm[SURV ? kAMax - 1 : 1];  // survival: the control-count term below adds to d / d mu_a
+    gpi[0] = ACC ? 0.0 : s0;
+#pragma unroll
+    for (int a = 1; a < kAMax; ++a) {
+        gpi[a] = 0.0;
+        if (SURV) gm[a - 1] = 0.0;
+        if (a < A) {
+            double sa = 0.0, dm = 0.0, dsg = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const long o = ((long)b * A1 + (a - 1)) * G + g;
+                const double ge = gs[b * NT];
+                sa += ge * c.tabP[o];
+                dm += ge * c.tabPmu[o];
+                if (!SURV) dsg += ge * c.tabPy[o];
+            }
+            const double pea = ACC ? ps[(0 * kAMax + a) * NT] : pi[a];
+            if (SURV) gm[a - 1] = pea * dm;
+            else row_out(kTGmu + a - 1, pea * dm);
+            row_out(kTGsig + a - 1, pea * dsg);
+            if (ACC) {
+                gpi[a] = (sa - s0) * ps[(1 * kAMax + a) * NT];
+                gnoise += (sa - s0) * ps[(2 * kAMax + a) * NT];
+            } else {
+                gpi[a] = sa;
+            }
+        }
+    }
+    // ---- Multinomial on control allele counts
+    if (!SURV) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a)
+            if (a < A) s += pi[a];
+        const double ls = s == 1.0 ? 0.0 : flog(s);
+        const double rsum = s == 1.0 ? 1.0 : frcp(s);
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {
+            if (a < A) {
+                const double pr = pi[a] * rsum;
+                const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+                const double lg = inside ? flog(pi[a]) - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                double cnt = 0.0;
+                for (int cc = 0; cc < c.C; ++cc)
+                    cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                nll -= cnt * lg;
+                if (inside) gpi[a] -= cnt * frcp(pi[a]);
+            }
+        }
+    } else {
+        // control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)), mu = [u, u + mu_a]
+        // (survival_model.py:535-548): gradients to pi and, through the growth, to mu_a
+        for (int cc = 0; cc < c.C; ++cc) {
+            const double tc = c.ctrl_time[cc];
+            double W = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a)
+                if (a < A) W += pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+            const double rW = frcp(W);
+            double n_in = 0.0;
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a)
+                if (a < A) {
+                    const double wv = pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+                    const double pr = wv * rW;
+                    const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                    nll -= cnt * flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                    if (pr > kProbEps && pr < 1.0 - kProbEps) n_in += cnt;
+                }
+#pragma unroll
+            for (int a = 0; a < kAMax; ++a)
+                if (a < A) {
+                    const double gr = exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+                    const double wv = pi[a] * gr, pr = wv * rW;
+                    const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+                    const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                    gpi[a] += ((inside ? -cnt * frcp(wv) : 0.0) + n_in * rW) * gr;
+                    if (a >= 1) gm[a - 1] += ((inside ? -cnt : 0.0) + n_in * wv * rW) * tc;
+                }
+        }
+#pragma unroll
+        for (int a = 1; a < kAMax; ++a)
+            if (a < A) row_out(kTGmu + a - 1, gm[a - 1]);
+    }
+    // ---- the two Dirichlet log-densities of the pi site; the concentrations are formed again from
+    // alpha_pi (same expressions as before the draw, same values).  The barrier keeps the compiler
+    // from carrying them across the likelihoods instead (which is what spilled).
+    __asm__ volatile("" ::: "memory");
+    {
+        double alpha[kAMax], Ssum = 0.0;
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {
+            const bool am = a < A && c.amask[(long)g * A + a] != 0;
+            alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
+            Ssum += alpha[a];
+        }
+        const double rsq = frcp(Ssum) * pa0;
+        // model-side floored concentration c_p (model.py:640-651) for - d log p / d pi
+        const double rSe = frcp(Ssum + kEps) * pa0;
+        double total = 0.0, proj = 0.0;
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {
+            double cqa = alpha[a] * rsq;
+            if (SURV && a < A && cqa < 1e-5) cqa = 1e-5;
+            total += cqa;
+            if (a < A) {
+                const double rpi = frcp(pi[a]);
+                row_out(kTL + a, flog(pi[a]));
+                gpi[a] += (cqa - 1.0) * rpi;  // + d log q / d pi
+                const double v = (alpha[a] + kEps / A) * rSe;
+                gpi[a] -= ((v < kEps ? kEps : v) - 1.0) * rpi;
+                proj += pi[a] * gpi[a];
+            }
+        }
+        const double dgS_t = c.dgq_t[(long)kAMax * G + g];  // digamma(sum c_q), tabulated by k_param
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a)
+            if (a < A) {
+                double cqa = alpha[a] * rsq;
+                if (SURV && cqa < 1e-5) cqa = 1e-5;
+                row_out(kTPath + a,
+                        dirichlet_grad_one_pre(pi[a], cqa, total, c.dgq_t[(long)a * G + g], dgS_t) * (gpi[a] - proj));
+            }
+    }
+    if (ACC) row_out(kTGnoise, gnoise);
+    row_out(kTNrg, 1.0);
+    const double tot = wave_sum(on ? nll : 0.0);
+    if ((lane & 63) == 0) {  // every wave of the workgroup adds its part
+        loss_add(c, ctr.slot, tot);
+        if (blockIdx.x == 0 && lane == 0) publish_ctr(c, ctr);
+    }
+}
+
+}  // namespace bean
