@@ -298,7 +298,15 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->gsum_ws = nullptr;
     c->sq_ws = nullptr;
     const uint64_t Rr = d.R;
-    const uint64_t n_gblk = (G + kParamBlock - 1) / kParamBlock;
+    // guide blocks of k_param: kParamBlock guides each; in the survival families with a
+    // Dirichlet-over-all-guides site kParamBlock / q0_npar, the other lanes join for the site's gamma
+    // draws (one lane group per replicate pair, at most 4 groups: see q0_draws_and_totals)
+    {
+        const int npairs = (s->n_reps + 1) / 2;
+        d.q0_npar = (surv_mix || surv_norm) ? (npairs >= 4 ? 4 : (npairs >= 2 ? 2 : 1)) : 1;
+        d.q0_gpb = kParamBlock / d.q0_npar;
+    }
+    const uint64_t n_gblk = (G + d.q0_gpb - 1) / d.q0_gpb;
     d.n_gamma_blocks = (int)n_gblk;
     const uint64_t n_surv = (surv_mix ? 2 * G + Rr * G + n_gblk * (Rr + 1) + (Rr + 1) : 0) +
                             (surv_norm ? 2 * Rr * G + n_gblk * (Rr + 1) + (Rr + 1) + Rr : 0) +
@@ -360,7 +368,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     // arrival counters of the fused step kernel: per tile and per tile boundary (ints, zero between launches)
     const uint64_t n_ctr = c->wave2 ? ((G + 63) / 64 + 7) / 8 * 8 + 2 + 3 * B + 2 : 0;
     const uint64_t n_dbl = n_ctr + 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
-                           n_split + n_dbg + n_trow + 3 * n_lpart + n_dgq + n_dgq_t + 2 * n_cov + 2 * Rr;
+                           n_split + n_dbg + n_trow + 3 * n_lpart + n_dgq + n_dgq_t + 2 * n_cov + 2 * Rr + 1;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
     if (e != hipSuccess) {
@@ -456,6 +464,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         d.lpart = (long long*)w; w += 3 * n_lpart;
         d.n_lpart = (int)n_lpart;
     }
+    d.q0_ctr = (int*)w; w += 1;
     static_assert(sizeof(StepCtr) == 24, "two StepCtr take 6 of the 8 spare workspace doubles");
     d.ctrA = (StepCtr*)w; w += 3;
     d.ctrB = (StepCtr*)w; w += 3;
@@ -575,7 +584,7 @@ static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_block
     int guide_blocks = 0;
     if (d.family == kMultiMixture)  // kAMax lanes per guide, or one wave per guide on the wide path
         guide_blocks = (int)(((long)d.G * (d.wide_alleles ? 64 : kAMax) + kParamBlock - 1) / kParamBlock);
-    else if (d.family == kMixture || d.surv_q0lik) guide_blocks = (d.G + kParamBlock - 1) / kParamBlock;
+    else if (d.family == kMixture || d.surv_q0lik) guide_blocks = (d.G + d.q0_gpb - 1) / d.q0_gpb;
     n_blocks = n_target_blocks + guide_blocks;
 }
 
@@ -766,15 +775,6 @@ static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
     }
 }
 
-// normalisers of the Dirichlet-over-guides draw (survival): gsum from this rank's block partials
-static void launch_sums(bean_hip_ctx* c, hipStream_t stream) {
-    const DevArgs& d = c->d;
-    if (d.survival && (d.family == kMixture || d.surv_q0lik)) {
-        hipLaunchKernelGGL(k_q0_draws, dim3(d.n_gamma_blocks, (d.R + 1) / 2), dim3(kParamBlock), 0, stream, d);
-        hipLaunchKernelGGL(k_sum_parts, dim3(d.R + 1), dim3(256), 0, stream, d);
-    }
-}
-
 // tiling families, one wave per (guide tile, replicate), then the sum over replicates
 static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
@@ -905,7 +905,7 @@ static void launch_guide_survival_wave(bean_hip_ctx* c, hipStream_t stream) {
         hipLaunchKernelGGL(k_sum_q, dim3(d.R), dim3(1024), 0, stream, d);
 }
 
-static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = true) {
+static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     if (!c->fused_guide && !d.survival && d.family != kMultiMixture) {
         launch_guide_split(c, stream);
@@ -917,7 +917,6 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream, bool with_sums = t
         return;
     }
     const int nw = waves_per_block(c);
-    if (with_sums) launch_sums(c, stream);
     if (c->surv_wave) {
         launch_guide_survival_wave(c, stream);
         return;
@@ -1204,15 +1203,17 @@ extern "C" int bean_hip_sharded_begin(bean_hip_ctx* c, uint64_t seed, uint64_t f
 
 extern "C" int bean_hip_sharded_sums(bean_hip_ctx* c, void* stream_) {
     if (!c) return fail("bean_hip_sharded_sums: null handle");
-    launch_sums(c, (hipStream_t)stream_);
-    HIP_OK(hipGetLastError());
+    // the normalisers of the survival families' Dirichlet-over-all-guides draw are formed at the tail of
+    // the k_param launch that prepares the step (bean_hip_sharded_begin / _update): this rank's part is
+    // already in BEAN_BUF_XCHG_GSUM when this returns.  Kept as the exchange point of the protocol.
+    (void)stream_;
     return 0;
 }
 
 extern "C" int bean_hip_sharded_guide(bean_hip_ctx* c, void* stream_) {
     if (!c) return fail("bean_hip_sharded_guide: null handle");
     hipStream_t stream = (hipStream_t)stream_;
-    launch_guide(c, stream, false);
+    launch_guide(c, stream);
     if (c->slot_ptr[BEAN_BUF_XCHG_TGRAD]) {
         int ntb, nb;
         grid_param(c, ntb, nb);

@@ -195,6 +195,8 @@ struct DevArgs {
     double *gq;                      // (R, G) d loss / d q_0[r, g]
     double *sq;                      // (R) sum_g q_0[r, g] * gq[r, g]
     int n_gamma_blocks;
+    int* q0_ctr;                     // arrivals of k_param's guide blocks (last one forms gsum), zero between launches
+    int q0_gpb, q0_npar;             // survival: guides per guide block of k_param (kParamBlock / q0_npar) and lane groups drawing in parallel
 };
 
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
@@ -1046,6 +1048,104 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
     }
 }
 
+// Survival, tail of k_param's guide part (PREP): the Gamma draws of the Dirichlet-over-all-guides site
+// (survival MixtureNormal q0, survival NormalModel initial_abundance) of the step just prepared, from
+// the concentration the lane has just updated, and their normalisers.
+//   gam[r, g]          one lane per guide draws its R gammas, two per rejection loop;
+//   gpart[block, j]    block sums (j < R: gammas of replicate j; j = R: the concentrations);
+//   gsum[j]            the guide block that arrives LAST adds the partials of all blocks, in the fixed
+//                      order (strided partials, block tree) the separate reduction launch used: same bits.
+// These were two more launches per step (k_q0_draws 13 us, k_sum_parts 6 us at BASELINE config 5) whose
+// only product is R + 1 sums.  Hand-over as in the fused step kernel (bean_step_v2.hpp): agent-scope
+// stores, s_waitcnt, one relaxed agent-scope atomic per block; no fence.
+// torch draws this site in float32 (the concentration is a float32 parameter): the gamma underflows
+// to 0 and is floored at FLT_MIN (ATen _s_dirichlet_cpu).
+__device__ __forceinline__ void q0_draws_and_totals(const DevArgs& c, int gb, int g, bool in, double conc,
+                                                    unsigned long long step, double* scratch) {
+    (void)scratch;
+    constexpr int kChunk = 16;                 // values reduced per barrier pair
+    constexpr int kWaves = kParamBlock / 64;
+    __shared__ double qs[kChunk][kWaves];      // wave sums of the current chunk of values
+    __shared__ double qc[kParamBlock];         // the block's updated concentrations
+    __shared__ int is_last;
+    const int R = c.R, np1 = c.R + 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // The block's q0_gpb guides were updated by its first q0_gpb lanes; the draws are spread over
+    // q0_npar lane groups (1, 2 or 4: whole waves), group k taking replicate pairs k, k + q0_npar, ...:
+    // a rejection loop with a 1e-5 concentration is a long dependent chain, and k_param has too few
+    // waves to hide one behind another.
+    const int gpb = c.q0_gpb, npar = c.q0_npar;
+    qc[threadIdx.x] = in ? conc : 0.0;
+    __syncthreads();
+    const int grp = (int)threadIdx.x / gpb, jl = (int)threadIdx.x - grp * gpb;
+    const int gg = gb * gpb + jl;
+    const bool live = grp < npar && gg < c.G;
+    const double cc = qc[jl];
+    (void)g;
+    double* mine = c.gpart + (long)gb * np1;
+    // value j of the block: j < R the gammas of replicate j, j = R the concentrations; wave sums go to
+    // LDS, and once per chunk (or at the end) thread k adds the waves' parts of value k in fixed order
+    int n_in_chunk = 0, j0 = 0;
+    auto flush = [&]() {
+        __syncthreads();
+        if ((int)threadIdx.x < n_in_chunk) {
+            double t = 0.0;
+            for (int i = 0; i < kWaves; ++i) t += qs[threadIdx.x][i];
+            __hip_atomic_store(mine + j0 + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        j0 += n_in_chunk;
+        n_in_chunk = 0;
+    };
+    auto put = [&](bool mine_to_sum, double v) {  // mine_to_sum is uniform over the wave
+        const double t = mine_to_sum ? wave_sum(v) : 0.0;
+        if (lane == 0) qs[n_in_chunk][w] = t;
+        if (++n_in_chunk == kChunk) flush();
+    };
+    int pair = 0;
+    for (int r0 = 0; r0 < R; r0 += 2, ++pair) {
+        const int r1 = r0 + 1;
+        const bool two = r1 < R;
+        const bool my_pair = grp < npar && pair % npar == grp;  // uniform over the wave (gpb is a multiple of 64)
+        double gm0 = 0.0, gm1 = 0.0;
+        if (my_pair && live) {
+            if (c.x0_in) {
+                gm0 = c.x0_in[(long)r0 * c.G + gg];  // injected draws: already normalised
+                if (two) gm1 = c.x0_in[(long)r1 * c.G + gg];
+            } else {
+                Rng rng(c.seed, kSiteQ0, (unsigned long long)r0 * c.G_tot + (c.g_off + gg), step * 256ull);
+                const GammaPair gp = sample_gamma_pair(cc, two ? cc : 1.0, rng);
+                gm0 = (double)fmaxf((float)gp.g0, 1.17549435e-38f);
+                gm1 = two ? (double)fmaxf((float)gp.g1, 1.17549435e-38f) : 0.0;
+            }
+            c.gam[(long)r0 * c.G + gg] = gm0;
+            if (two) c.gam[(long)r1 * c.G + gg] = gm1;
+        }
+        put(my_pair, gm0);
+        if (two) put(my_pair, gm1);
+    }
+    put(grp == 0, grp == 0 && live ? cc : 0.0);
+    if (n_in_chunk) flush();
+    // this block's partials are out; count in, and the block that arrives last forms the totals:
+    // wave i takes values i, i + 4, ...; lanes stride over the blocks' partials, fixed tree
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial stores (all issued by wave 0) are acknowledged
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(c.q0_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == c.n_gamma_blocks - 1;
+        if (is_last) __hip_atomic_store(c.q0_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (is_last) {
+        for (int j = w; j < np1; j += kWaves) {
+            double v = 0.0;
+            for (int b = lane; b < c.n_gamma_blocks; b += 64)
+                v += __hip_atomic_load(c.gpart + (long)b * np1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double tot = wave_sum(v);
+            if (lane == 0) c.gsum[j] = tot;
+        }
+    }
+}
+
 // -------------------------------------------------------------------- k_param
 // grid = n_target_blocks + n_guide_blocks, 256 threads.
 // KIND 1: the variant sorting families on the wave-form path in thin mode (what a `bean run ... variant`
@@ -1360,16 +1460,18 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         }
     } else if (mixture) {
         // ------------------------------------------------- guide part
-        const int g = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
-        if (g < c.G) param_guide_mix<FINISH, ADAM, PREP, false>(c, g, ak, s_prep, loss_fin);
+        // survival: a guide block holds q0_gpb guides (its other lanes join for the gamma draws below)
+        const int gpb = c.survival ? c.q0_gpb : (int)blockDim.x;
+        const int g = ((int)blockIdx.x - n_target_blocks) * gpb + threadIdx.x;
+        if ((int)threadIdx.x < gpb && g < c.G) param_guide_mix<FINISH, ADAM, PREP, false>(c, g, ak, s_prep, loss_fin);
     }
     if (c.surv_q0lik && (int)blockIdx.x >= n_target_blocks) {
         // survival NormalModel: Dirichlet(initial_abundance) site over ALL guides, drawn per
         // replicate and used by the likelihood (survival_model.py:62-67, 629-639).  The prior is
         // Dirichlet(1 / G), so unlike the MixtureNormal q0 site nothing cancels.
         const int gb = (int)blockIdx.x - n_target_blocks;
-        const int g = gb * blockDim.x + threadIdx.x;
-        const bool in = g < c.G;
+        const int g = gb * c.q0_gpb + threadIdx.x;
+        const bool in = (int)threadIdx.x < c.q0_gpb && g < c.G;
         float iau = in ? c.p[7][g] : 0.f;
         if (FINISH && in) {
             const double ia = (double)expf(iau);
@@ -1402,19 +1504,17 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
             }
         }
         if (PREP) {
-            // the gamma draws of the site follow in k_q0_draws (one thread per (replicate, guide))
             double ia = 0.0;
             if (in) ia = (double)expf(iau);
-            const double tq = block_sum(ia, scratch);
-            if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + c.R] = tq;
+            q0_draws_and_totals(c, gb, g, in, ia, s_prep, scratch);
         }
     }
     if (c.survival && mixture && (int)blockIdx.x >= n_target_blocks) {
         // survival MixtureNormal: the Dirichlet(q0) site over ALL guides and the per-guide
         // baseline growth draw (survival_model.py:259-274,306-311,660-669)
         const int gb = (int)blockIdx.x - n_target_blocks;
-        const int g = gb * blockDim.x + threadIdx.x;
-        const bool in = g < c.G;
+        const int g = gb * c.q0_gpb + threadIdx.x;
+        const bool in = (int)threadIdx.x < c.q0_gpb && g < c.G;
         float q0u = in ? c.p[7][g] : 0.f;
         if (FINISH && in) {
             const double q0 = (double)expf(q0u);
@@ -1442,9 +1542,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 c.u_g[g] = (double)(float)c.neg_loc + eps * (double)(float)c.neg_scale;
                 if (c.eps_u_out) c.eps_u_out[g] = eps;
             }
-            // the gamma draws of the Dirichlet(q0) site follow in k_q0_draws
-            const double tq = block_sum(q0, scratch);
-            if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + c.R] = tq;
+            q0_draws_and_totals(c, gb, g, in, q0, s_prep, scratch);
         }
     }
     if (FINISH) {
@@ -2214,53 +2312,6 @@ void k_pi_terms(DevArgs c) {
 }
 
 // ------------------------------------------------------------ survival kernels
-// Totals of the per-block sums written by k_param's survival guide part:
-// Gamma draws of the Dirichlet-over-all-guides site (survival MixtureNormal q0, survival NormalModel
-// initial_abundance), one thread per (replicate pair, guide), after k_param has updated the
-// parameter: gam[r, g] and the block partial sums gpart[block, r].  grid = (n_gamma_blocks, ceil(R/2)).
-// torch draws this site in float32 (the concentration is a float32 parameter): the gamma underflows
-// to 0 and is floored at FLT_MIN (ATen _s_dirichlet_cpu).
-__global__ __launch_bounds__(kParamBlock) void k_q0_draws(DevArgs c) {
-    __shared__ double scratch[16];
-    // replicates are drawn two at a time (one rejection loop per pair): grid.y = ceil(R / 2)
-    const int gb = blockIdx.x, r0 = 2 * blockIdx.y, r1 = r0 + 1;
-    const bool two = r1 < c.R;
-    const int g = gb * blockDim.x + threadIdx.x;
-    const unsigned long long step = c.ctrB->step;  // the step k_param has just prepared
-    double gm0 = 0.0, gm1 = 0.0;
-    if (g < c.G) {
-        if (c.x0_in) {
-            gm0 = c.x0_in[(long)r0 * c.G + g];  // injected draws: already normalised
-            if (two) gm1 = c.x0_in[(long)r1 * c.G + g];
-        } else {
-            const double conc = (double)expf(c.p[7][g]);
-            Rng rng(c.seed, kSiteQ0, (unsigned long long)r0 * c.G_tot + (c.g_off + g), step * 256ull);
-            const GammaPair gp = sample_gamma_pair(conc, two ? conc : 1.0, rng);
-            gm0 = (double)fmaxf((float)gp.g0, 1.17549435e-38f);
-            gm1 = two ? (double)fmaxf((float)gp.g1, 1.17549435e-38f) : 0.0;
-        }
-        c.gam[(long)r0 * c.G + g] = gm0;
-        if (two) c.gam[(long)r1 * c.G + g] = gm1;
-    }
-    const double t0 = block_sum(gm0, scratch);
-    if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + r0] = t0;
-    if (two) {
-        const double t1 = block_sum(gm1, scratch);
-        if (threadIdx.x == 0) c.gpart[(long)gb * (c.R + 1) + r1] = t1;
-    }
-}
-
-// gsum[r] = sum_g gamma[r, g] (normaliser of the Dirichlet(q0) draw), gsum[R] = sum_g q0.
-// grid = R + 1 blocks, one per total (fixed order: strided partials, block tree).
-__global__ __launch_bounds__(256) void k_sum_parts(DevArgs c) {
-    __shared__ double scratch[16];
-    const int j = blockIdx.x;
-    double v = 0.0;
-    for (int b = threadIdx.x; b < c.n_gamma_blocks; b += blockDim.x) v += c.gpart[(long)b * (c.R + 1) + j];
-    const double tot = block_sum(v, scratch);
-    if (threadIdx.x == 0) c.gsum[j] = tot;
-}
-
 // survival NormalModel: sq[r] = sum_g q_0[r, g] * gq[r, g] (fixed order: strided partials, block tree)
 __global__ __launch_bounds__(1024) void k_sum_q(DevArgs c) {
     __shared__ double scratch[16];
