@@ -73,7 +73,7 @@ BUF = {
     "P": 32, "G": 48, "M": 64, "V": 80,
     "EPS_MU_IN": 96, "EPS_SD_IN": 97, "PI_IN": 98, "EPS_NOISE_IN": 99,
     "EPS_MU_OUT": 100, "EPS_SD_OUT": 101, "PI_OUT": 102, "EPS_NOISE_OUT": 103,
-    "X0_IN": 104, "EPS_U_IN": 105, "X0_OUT": 106, "EPS_U_OUT": 107, "PRIOR_IA": 108,
+    "X0_IN": 104, "EPS_U_IN": 105, "X0_OUT": 106, "EPS_U_OUT": 107, "PRIOR_IA": 108, "XCHG_COV": 109,
     "LOSS_HIST": 112,
 }
 PARAM_ORDER = ("mu_loc", "mu_scale", "sd_loc", "sd_scale", "alpha_pi", "noise_loc", "noise_scale", "q0")
@@ -93,6 +93,10 @@ SYMBOLS = [
     ("bean_hip_sharded_sums", c_int32, [c_void_p, c_void_p]),
     ("bean_hip_sharded_guide", c_int32, [c_void_p, c_void_p]),
     ("bean_hip_sharded_update", c_int32, [c_void_p, c_int32, c_void_p]),
+    ("bean_hip_comm_unique_id", c_int32, [c_char_p, c_void_p]),
+    ("bean_hip_comm_init", c_int32, [c_void_p, c_char_p, c_void_p, c_int32, c_int32]),
+    ("bean_hip_comm_destroy", c_int32, [c_void_p]),
+    ("bean_hip_svi_run_exchanged", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_int32, c_void_p]),
     ("bean_hip_step_bytes", c_uint64, [c_void_p]),
     ("bean_hip_dominant_kernel", c_char_p, [c_void_p]),
     ("bean_hip_set_profile", c_int32, [c_void_p, c_int32]),
@@ -190,6 +194,15 @@ def load(amax: int = 8):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def rccl_path() -> str:
+    """The RCCL shared object of this process: the copy PyTorch ships and has loaded (the library
+    resolves ncclAllReduce ... from it at run time, ``bean_hip_comm_*``)."""
+    import torch
+
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else "librccl.so"
 
 
 def check(status: int, what: str = "", lib=None):

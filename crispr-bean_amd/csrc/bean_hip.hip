@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the functions are resolved with dlsym (bean_hip_comm_*)
 
 #include <string>
 #include <vector>
@@ -48,6 +50,7 @@ struct bean_hip_ctx {
     bool tiling_rep;   // tiling families, default: k_guide_tiling_rep, the replicates of a guide share a wave (bean_tiling_v2.hpp)
     double* gsum_ws;  // library-owned normaliser buffer (replaced by BEAN_BUF_XCHG_GSUM when bound)
     double* sq_ws;    // library-owned projection sums (replaced by BEAN_BUF_XCHG_SQ when bound)
+    double* cov_sum_ws;  // library-owned covariate gradient sums (replaced by BEAN_BUF_XCHG_COV when bound)
     // graph cache: graphs[k] replays 2^k {k_param, guide} pairs
     std::vector<hipGraphExec_t> graphs;
     unsigned long long graph_seed;
@@ -55,6 +58,10 @@ struct bean_hip_ctx {
     bool profile;
     bool profile_param;  // profile mode 2: time k_param<FINISH, ADAM, PREP> instead of the guide kernel
     std::vector<hipEvent_t> ev;  // start/stop pairs
+    // RCCL communicator of a guide-sharded fit (bean_hip_comm_init) and graphs of 2^k exchanged steps
+    ncclComm_t comm;
+    int comm_world;
+    std::vector<hipGraphExec_t> graphs_xchg;
 };
 
 extern "C" const char* bean_hip_version(void) {
@@ -116,6 +123,7 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
             return ((is_survival(s) && s.family == BEAN_FAMILY_MIXTURE_NORMAL) || is_surv_normal(s)) ? 8 * (R + 1) : 0;
         case BEAN_BUF_XCHG_SQ: return is_surv_normal(s) ? 8 * R : 0;
         case BEAN_BUF_XCHG_TGRAD: return 8 * 2 * T;
+        case BEAN_BUF_XCHG_COV: return s.n_sample_covariates > 0 ? 8 * R : 0;
         case BEAN_BUF_EPS_U_IN: case BEAN_BUF_EPS_U_OUT: return (is_survival(s) && is_mixture(s)) ? 8 * G : 0;
         case BEAN_BUF_PRIOR_IA: return (is_surv_normal(s) && s.prior_ia_total > 0.0) ? 8 * G : 0;
         case BEAN_BUF_TARGET_OFFSETS: return is_tiling(s) ? 0 : 4 * (T + 1);
@@ -191,6 +199,7 @@ static void sync_devargs(bean_hip_ctx* c) {
     else d.gsum = c->gsum_ws;
     if (P(BEAN_BUF_XCHG_SQ)) d.sq = (double*)P(BEAN_BUF_XCHG_SQ);
     else d.sq = c->sq_ws;
+    if (c->cov_sum_ws) d.cov_sum = P(BEAN_BUF_XCHG_COV) ? (double*)P(BEAN_BUF_XCHG_COV) : c->cov_sum_ws;
     d.ctrl_time = (const double*)P(BEAN_BUF_CONTROL_TIME);
     d.log_obs0 = (const double*)P(BEAN_BUF_LOG_OBS0);
     d.x0_in = (const double*)P(BEAN_BUF_X0_IN);
@@ -208,6 +217,9 @@ static void drop_graph(bean_hip_ctx* c) {
     for (hipGraphExec_t g : c->graphs_fused)
         if (g) (void)hipGraphExecDestroy(g);
     c->graphs_fused.clear();
+    for (hipGraphExec_t g : c->graphs_xchg)
+        if (g) (void)hipGraphExecDestroy(g);
+    c->graphs_xchg.clear();
 }
 
 extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
@@ -267,6 +279,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
 #endif
     }
     c->graph_seed = 0;
+    c->comm = nullptr;
+    c->comm_world = 0;
     c->loss_acc = nullptr;
     c->profile = false;
     c->profile_param = false;
@@ -297,6 +311,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.not_loss_owner = (s->flags & BEAN_FLAG_NOT_LOSS_OWNER) ? 1 : 0;
     c->gsum_ws = nullptr;
     c->sq_ws = nullptr;
+    c->cov_sum_ws = nullptr;
     const uint64_t Rr = d.R;
     // guide blocks of k_param: kParamBlock guides each; in the survival families with a
     // Dirichlet-over-all-guides site kParamBlock / q0_npar, the other lanes join for the site's gamma
@@ -315,10 +330,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const bool use_split = split_ok && !c->fused_guide;
     c->wave_guide = c->wave_guide && split_ok;
     c->wave2 = c->wave2 && c->wave_guide;
-    if (s->n_sample_covariates > 0 && (!c->wave2 || s->n_guides_total > s->n_guides)) {
+    if (s->n_sample_covariates > 0 && !c->wave2) {
         delete c;
-        return fail("bean_hip_create: sample covariates need the default guide kernel (k_guide_wave2) and an unsharded "
-                    "screen: mu_cov is shared by every guide");
+        return fail("bean_hip_create: sample covariates need the default guide kernel (k_guide_wave2)");
     }
     d.n_cov = s->n_sample_covariates;
     c->surv_wave = c->surv_wave && is_survival(*s) && !is_tiling(*s);
@@ -453,6 +467,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         d.cov_eps = w; w += n_cov;
         d.cov_shift = w; w += Rr;
         d.cov_sum = w; w += Rr;
+        c->cov_sum_ws = d.cov_sum;
     }
     if (n_dgq) {
         d.dgq = w; w += n_dgq;
@@ -472,9 +487,11 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     return 0;
 }
 
+extern "C" int bean_hip_comm_destroy(bean_hip_ctx* c);
 extern "C" int bean_hip_destroy(bean_hip_ctx* c) {
     if (!c) return 0;
     drop_graph(c);
+    (void)bean_hip_comm_destroy(c);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->workspace) (void)hipFree(c->workspace);
     if (c->loss_acc) (void)hipFree(c->loss_acc);
@@ -508,7 +525,7 @@ extern "C" int bean_hip_bind(bean_hip_ctx* c, int slot, void* ptr, uint64_t nbyt
     sync_devargs(c);
     drop_graph(c);
     if (slot < BEAN_BUF_P_MU_LOC && slot != BEAN_BUF_XCHG_GSUM && slot != BEAN_BUF_XCHG_TGRAD &&
-        slot != BEAN_BUF_XCHG_SQ)
+        slot != BEAN_BUF_XCHG_SQ)  // (BEAN_BUF_XCHG_COV lies above the parameter slots)
         c->prepared = false;  // data changed: the data-only precomputation is stale
     return 0;
 }
@@ -589,13 +606,14 @@ static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_block
 }
 
 template <bool FINISH, bool ADAM, bool PREP>
-static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgrad = nullptr) {
+static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgrad = nullptr, bool cov_exchanged = false) {
     int ntb, nb;
     grid_param(c, ntb, nb);
     DevArgs d = c->d;
     d.tgrad = tgrad;
     if (d.n_cov) {  // sample covariates: their own small step runs first (it owns the replicates' shifts)
-        if (FINISH) hipLaunchKernelGGL(k_cov_sum, dim3(d.R), dim3(1024), 0, stream, d);
+        // (guide-sharded: the sums were formed by bean_hip_sharded_guide and all-reduced by the caller)
+        if (FINISH && !cov_exchanged) hipLaunchKernelGGL(k_cov_sum, dim3(d.R), dim3(1024), 0, stream, d);
         hipLaunchKernelGGL((k_cov_step<FINISH, ADAM, PREP>), dim3(1), dim3(64), 0, stream, d);
     }
     // the specialised build of the kernel (k_param<..., 1>) where its launch conditions hold
@@ -1220,6 +1238,8 @@ extern "C" int bean_hip_sharded_guide(bean_hip_ctx* c, void* stream_) {
         hipLaunchKernelGGL(k_target_reduce, dim3(ntb), dim3(kParamBlock), 0, stream, c->d,
                            (double*)c->slot_ptr[BEAN_BUF_XCHG_TGRAD]);
     }
+    if (c->d.n_cov && c->slot_ptr[BEAN_BUF_XCHG_COV])
+        hipLaunchKernelGGL(k_cov_sum, dim3(c->d.R), dim3(1024), 0, stream, c->d);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1228,11 +1248,170 @@ extern "C" int bean_hip_sharded_update(bean_hip_ctx* c, int32_t last, void* stre
     if (!c) return fail("bean_hip_sharded_update: null handle");
     hipStream_t stream = (hipStream_t)stream_;
     const double* tg = (const double*)c->slot_ptr[BEAN_BUF_XCHG_TGRAD];
+    const bool covx = c->d.n_cov && c->slot_ptr[BEAN_BUF_XCHG_COV];
     if (last)
-        launch_param<true, true, false>(c, stream, tg);
+        launch_param<true, true, false>(c, stream, tg, covx);
     else
-        launch_param<true, true, true>(c, stream, tg);
+        launch_param<true, true, true>(c, stream, tg, covx);
     launch_finalize(c, stream, 0, 1, true);  // the slot of the step that has just finished
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+
+// ---- RCCL owned by the library (see bean_hip.h): resolved at run time from the shared object the
+// caller names (the copy PyTorch has loaded), so libbean_hip.so has no link-time dependency on it
+struct RcclApi {
+    void* handle;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)();
+    ncclResult_t (*GroupEnd)();
+    const char* (*GetErrorString)(ncclResult_t);
+};
+static RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+static int rccl_load(const char* path) {
+    if (g_rccl.handle) return 0;
+    void* h = nullptr;
+    if (path && path[0]) h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(std::string("RCCL not found (") + (path ? path : "") + "): " + (dlerror() ? dlerror() : ""));
+    RcclApi a;
+    a.handle = h;
+#define BEAN_RCCL_SYM(field, name)                                               \
+    a.field = (decltype(a.field))dlsym(h, name);                                 \
+    if (!a.field) return fail(std::string("RCCL symbol missing: ") + name)
+    BEAN_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    BEAN_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    BEAN_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    BEAN_RCCL_SYM(AllReduce, "ncclAllReduce");
+    BEAN_RCCL_SYM(GroupStart, "ncclGroupStart");
+    BEAN_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    BEAN_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef BEAN_RCCL_SYM
+    g_rccl = a;
+    return 0;
+}
+#define RCCL_OK(expr)                                                                        \
+    do {                                                                                     \
+        ncclResult_t r_ = (expr);                                                            \
+        if (r_ != ncclSuccess)                                                               \
+            return fail(std::string(#expr) + ": " + g_rccl.GetErrorString(r_));              \
+    } while (0)
+
+extern "C" int bean_hip_comm_unique_id(const char* rccl_path, uint8_t* id) {
+    if (!id) return fail("bean_hip_comm_unique_id: null id");
+    if (rccl_load(rccl_path)) return -1;
+    static_assert(sizeof(ncclUniqueId) == BEAN_HIP_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    RCCL_OK(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+extern "C" int bean_hip_comm_init(bean_hip_ctx* c, const char* rccl_path, const uint8_t* id, int32_t rank,
+                                  int32_t world) {
+    if (!c || !id) return fail("bean_hip_comm_init: null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail("bean_hip_comm_init: rank / world out of range");
+    if (c->comm) return fail("bean_hip_comm_init: communicator already initialised");
+    if (rccl_load(rccl_path)) return -1;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    RCCL_OK(g_rccl.CommInitRank(&comm, world, u, rank));
+    c->comm = comm;
+    c->comm_world = world;
+    drop_graph(c);
+    return 0;
+}
+
+extern "C" int bean_hip_comm_destroy(bean_hip_ctx* c) {
+    if (!c || !c->comm) return 0;
+    drop_graph(c);
+    ncclComm_t comm = c->comm;
+    c->comm = nullptr;
+    c->comm_world = 0;
+    RCCL_OK(g_rccl.CommDestroy(comm));
+    return 0;
+}
+
+// one exchanged step on `stream`: [all-reduce gsum] guide [all-reduce tgrad (+ sq)] update
+static int enqueue_exchanged_step(bean_hip_ctx* c, hipStream_t stream, bool last) {
+    const bean_hip_shape& s = c->shape;
+    double* gsum = (double*)c->slot_ptr[BEAN_BUF_XCHG_GSUM];
+    double* tg = (double*)c->slot_ptr[BEAN_BUF_XCHG_TGRAD];
+    double* sq = (double*)c->slot_ptr[BEAN_BUF_XCHG_SQ];
+    if (gsum) RCCL_OK(g_rccl.AllReduce(gsum, gsum, (size_t)s.n_reps + 1, ncclFloat64, ncclSum, c->comm, stream));
+    launch_guide(c, stream);
+    if (tg) {
+        int ntb, nb;
+        grid_param(c, ntb, nb);
+        hipLaunchKernelGGL(k_target_reduce, dim3(ntb), dim3(kParamBlock), 0, stream, c->d, tg);
+    }
+    double* cov = c->d.n_cov ? (double*)c->slot_ptr[BEAN_BUF_XCHG_COV] : nullptr;
+    if (cov) hipLaunchKernelGGL(k_cov_sum, dim3(c->d.R), dim3(1024), 0, stream, c->d);
+    const int n_coll = (tg ? 1 : 0) + (sq ? 1 : 0) + (cov ? 1 : 0);
+    if (n_coll > 1) RCCL_OK(g_rccl.GroupStart());
+    if (tg) RCCL_OK(g_rccl.AllReduce(tg, tg, (size_t)2 * s.n_targets, ncclFloat64, ncclSum, c->comm, stream));
+    if (sq) RCCL_OK(g_rccl.AllReduce(sq, sq, (size_t)s.n_reps, ncclFloat64, ncclSum, c->comm, stream));
+    if (cov) RCCL_OK(g_rccl.AllReduce(cov, cov, (size_t)s.n_reps, ncclFloat64, ncclSum, c->comm, stream));
+    if (n_coll > 1) RCCL_OK(g_rccl.GroupEnd());
+    if (last) launch_param<true, true, false>(c, stream, tg, cov != nullptr);
+    else launch_param<true, true, true>(c, stream, tg, cov != nullptr);
+    launch_finalize(c, stream, 0, 1, true);  // the slot of the step that has just finished
+    return 0;
+}
+
+extern "C" int bean_hip_svi_run_exchanged(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
+                                          int32_t graph_chunk, void* stream_) {
+    if (!c) return fail("bean_hip_svi_run_exchanged: null handle");
+    if (!c->comm) return fail("bean_hip_svi_run_exchanged: call bean_hip_comm_init first");
+    if (n_steps == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c->graphs_xchg.empty() && c->graph_seed != seed) drop_graph(c);
+    if (bean_hip_sharded_begin(c, seed, first_step, n_steps, stream_)) return -1;  // checks, loss window, draw of step 0
+    uint64_t left = n_steps;
+    // hipGraphs of 2, 4, ... <= graph_chunk exchanged steps (never holding a run's last step, whose update
+    // prepares no further draw); the remainder is enqueued directly
+    if (graph_chunk > 1 && stream != nullptr && !c->profile) {
+        int kmax = 0;
+        while ((4ull << kmax) <= (uint64_t)graph_chunk && kmax < 9) ++kmax;
+        if (c->graphs_xchg.empty()) {
+            for (int k = 0; k <= kmax; ++k) {
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t ge = nullptr;
+                bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    for (uint64_t i = 0; ok && i < (2ull << k); ++i) ok = enqueue_exchanged_step(c, stream, false) == 0;
+                    hipError_t e = hipStreamEndCapture(stream, &graph);
+                    ok = ok && e == hipSuccess && graph != nullptr;
+                }
+                if (ok) ok = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) (void)hipGraphDestroy(graph);
+                if (!ok) {
+                    // RCCL (or HIP) refused the capture: forget graphs, keep going eagerly
+                    (void)hipGetLastError();
+                    drop_graph(c);
+                    g_err = "bean_hip_svi_run_exchanged: the exchanged step could not be captured into a hipGraph; "
+                            "running it with eager launches";
+                    break;
+                }
+                c->graphs_xchg.push_back(ge);
+            }
+            c->graph_seed = seed;
+        }
+        for (int k = (int)c->graphs_xchg.size() - 1; k >= 0; --k)
+            while (left > (2ull << k)) {  // strictly more: the last step stays outside the graphs
+                HIP_OK(hipGraphLaunch(c->graphs_xchg[k], stream));
+                left -= 2ull << k;
+            }
+    }
+    for (; left > 0; --left)
+        if (enqueue_exchanged_step(c, stream, left == 1)) return -1;
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -1548,7 +1548,9 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     if (FINISH) {
         // replicated per-target parameters (sharded ControlNormal / tiling): their prior and entropy
         // terms are counted by one rank only
-        if ((int)blockIdx.x < n_target_blocks && c.not_loss_owner) loss_fin = 0.0;
+        // (sorting NormalModel with sample covariates: the replicated parameters are mu_cov's, handled by
+        // k_cov_step; its per-target parameters are shard-local and count on every rank)
+        if ((int)blockIdx.x < n_target_blocks && c.not_loss_owner && !c.n_cov) loss_fin = 0.0;
         const double tot = block_sum(loss_fin, scratch);
         if (threadIdx.x == 0) {
             if (lp_early && (int)blockIdx.x < n_target_blocks) {
@@ -3470,7 +3472,8 @@ __global__ __launch_bounds__(64) void k_cov_step(DevArgs c) {
         }
     }
     if (FINISH) {
-        const double tot = wave_sum(loss);
+        // guide-sharded: mu_cov is replicated on every rank, one of them counts its prior / entropy terms
+        const double tot = wave_sum(c.not_loss_owner ? 0.0 : loss);
         if (threadIdx.x == 0) loss_add(c, ctr.slot, tot);
     }
 }

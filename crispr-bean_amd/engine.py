@@ -139,14 +139,17 @@ class HipSVI:
         # the regrouped replicates and then fails in write_result_table (readwrite.py:88-90)
         covs = getattr(data, "sample_covariates", None)
         self.n_cov = 0
+        if covs is not None and family == "ControlNormal":
+            # the reference's ControlNormalModel / Guide have no mu_cov site (model.py:168-252, 861-875): the
+            # negative-control fit of a screen with sample covariates just sees the regrouped
+            # (replicate, covariate) replicates
+            covs = None
         if covs is not None:
             if not (family == "Normal" and not survival):
                 raise ValueError(
                     "this screen carries uns['sample_covariates']: only the sorting Normal model (--uniform-edit) "
                     f"models them (bean/model/model.py:73-91); the {family} family cannot write its result table "
                     "in the reference (readwrite.py:88-90) and is refused here")
-            if n_guides_total and int(n_guides_total) != G:
-                raise NotImplementedError("sample covariates (mu_cov is shared by all guides) with a guide-sharded fit")
             self.n_cov = int(data.n_sample_covariates)
         self.prior_params = prior_params
         if prior_params is not None and ("mu_loc" in prior_params or "mu_scale" in prior_params):
@@ -406,16 +409,78 @@ class HipSVI:
             if self.family in ("ControlNormal", "MultiMixtureNormal"):
                 self._xchg["tgrad"] = torch.zeros(2 * self.T, dtype=torch.float64, device=self.device)
                 self._bind("XCHG_TGRAD", self._xchg["tgrad"])
+            if self.n_cov and int(self._shape.n_guides_total) not in (0, self.data.n_guides):
+                # guide shard of a screen with sample covariates: mu_cov is shared by every guide
+                self._xchg["cov"] = torch.zeros(R, dtype=torch.float64, device=self.device)
+                self._bind("XCHG_COV", self._xchg["cov"])
         return self._xchg
 
-    def run_exchanged(self, n_steps: int, all_reduce, seed: int = 101, first_step: Optional[int] = None):
-        """``n_steps`` SVI steps of one guide shard; ``all_reduce(tensor)`` must sum the tensor over
-        the ranks in place on the current stream (``torch.distributed.all_reduce``)."""
+    def init_native_comm(self, group=None) -> bool:
+        """Give the library its own RCCL communicator over the ranks of ``group`` (default group when
+        None), so that ``run_exchanged`` steps without the host in the loop
+        (``bean_hip_svi_run_exchanged``: kernels and ``ncclAllReduce`` enqueued by the library on the
+        engine's stream).  Collective: every rank of the group must call it.  Only with the ``nccl``
+        backend (the unique id travels by a ``torch.distributed`` broadcast); returns False - and the
+        Python stepping loop stays in use - on any other backend or if RCCL refuses."""
+        import torch.distributed as dist
+
+        if getattr(self, "_native_comm", False):
+            return True
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+            return False
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        path = _lib.rccl_path().encode()
+        idt = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        ok = torch.ones(1, dtype=torch.int32, device=self.device)
+        if rank == 0:
+            buf = (ctypes.c_uint8 * 128)()
+            if self.lib.bean_hip_comm_unique_id(path, buf) == 0:
+                idt.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+            else:
+                ok.zero_()
+        dist.broadcast(ok, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if int(ok.item()) == 0:  # every rank learns that rank 0 could not load RCCL
+            return False
+        dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(idt.cpu().numpy().tobytes())
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(raw)
+        self.exchange_buffers()
+        with torch.cuda.device(self.device):
+            st = self.lib.bean_hip_comm_init(self._h, path, buf, rank, world)
+        # all ranks agree on the outcome (a rank that failed alone would leave the others in a collective)
+        flag = torch.tensor([1 if st == 0 else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            if st == 0:
+                self.lib.bean_hip_comm_destroy(self._h)
+            return False
+        self._native_comm = True
+        return True
+
+    def run_exchanged(self, n_steps: int, all_reduce, seed: int = 101, first_step: Optional[int] = None,
+                      graph_chunk: Optional[int] = None):
+        """``n_steps`` SVI steps of one guide shard.  With a native communicator (``init_native_comm``)
+        the whole loop, collectives included, is enqueued by the library; otherwise the step is driven
+        from here and ``all_reduce(tensor)`` must sum the tensor over the ranks in place on the current
+        stream (``torch.distributed.all_reduce``).  ``graph_chunk`` > 1 (native path; default from
+        ``BEAN_HIP_XCHG_GRAPH``, else 0) replays hipGraphs of that many steps, collectives captured."""
         first = self.steps_done if first_step is None else int(first_step)
         if first + n_steps > self.loss_hist.numel():
             raise ValueError("loss history too small: raise num_steps / loss_capacity")
         x = self.exchange_buffers()
         sp = self._sptr()
+        if getattr(self, "_native_comm", False):
+            import os
+
+            chunk = int(os.environ.get("BEAN_HIP_XCHG_GRAPH", "0")) if graph_chunk is None else int(graph_chunk)
+            with self._on_stream():
+                self._check(self.lib.bean_hip_svi_run_exchanged(self._h, int(seed), first, int(n_steps), chunk, sp),
+                            "svi_run_exchanged")
+            self.last_exchange_path = ("native: kernels + ncclAllReduce enqueued by the library"
+                                       + (f", hipGraphs of up to {chunk} steps" if chunk > 1 else ", eager launches"))
+            self.steps_done = first + n_steps
+            return
+        self.last_exchange_path = "python loop: 3 ctypes calls + torch.distributed.all_reduce per step"
         with self._on_stream(), torch.cuda.stream(self.stream):
             self._check(self.lib.bean_hip_sharded_begin(self._h, int(seed), first, int(n_steps), sp), "sharded_begin")
             for i in range(n_steps):
@@ -427,6 +492,8 @@ class HipSVI:
                     all_reduce(x["tgrad"])
                 if "sq" in x:
                     all_reduce(x["sq"])
+                if "cov" in x:
+                    all_reduce(x["cov"])
                 self._check(self.lib.bean_hip_sharded_update(self._h, 1 if i == n_steps - 1 else 0, sp),
                            "sharded_update")
         self.steps_done = first + n_steps
@@ -440,6 +507,9 @@ class HipSVI:
     def close(self):
         if getattr(self, "_h", None):
             torch.cuda.synchronize(self.device)
+            if getattr(self, "_native_comm", False):
+                self.lib.bean_hip_comm_destroy(self._h)
+                self._native_comm = False
             self.lib.bean_hip_destroy(self._h)
             self._h = None
 

@@ -120,6 +120,7 @@ class _Group:
 
 PER_TARGET = ("mu_loc", "mu_scale", "sd_loc", "sd_scale")
 PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale", "q0", "initial_abundance")
+REPLICATED = ("mu_cov_loc", "mu_cov_scale")  # shared by every guide: identical on every rank
 
 
 def run_sharded(
@@ -156,13 +157,19 @@ def run_sharded(
             f"{data.n_guides} guides cannot feed {grp.world} ranks"
         )
     extra = {}
-    if replicated_targets:
+    if replicated_targets or getattr(data, "sample_covariates", None) is not None:
+        # replicated parameters (tiling per-edit parameters; mu_cov of a screen with sample covariates):
+        # one rank counts their prior / entropy terms
         extra["loss_owner"] = grp.rank == 0
     if getattr(data, "selection", "sorting") == "survival":
         # observed initial abundance is normalised over the whole screen (survival_model.py:306-311)
         extra["t0_totals"] = (data.X[:, 0, :].to(torch.float32) + 1).sum(-1)
     eng = engine_factory(shard_screen(data, mine), mine, data.n_guides, **extra)
     exchanged = bool(eng.exchange_buffers()) if hasattr(eng, "exchange_buffers") else False
+    if exchanged and grp.on and hasattr(eng, "init_native_comm"):
+        # RCCL ranks: the library steps with its own communicator (no host in the per-step loop);
+        # any other backend (gloo rehearsals) keeps the Python stepping loop
+        eng.init_native_comm(group)
     done = 0
     while done < num_steps:
         k = min(report_every, num_steps - done)
@@ -186,7 +193,7 @@ def run_sharded(
     t_sizes = [s[3] - s[2] for s in shards]
     whole: Dict[str, torch.Tensor] = {}
     for name, t in local.items():
-        if replicated_targets and name not in PER_GUIDE:
+        if (replicated_targets and name not in PER_GUIDE) or name in REPLICATED:
             whole[name] = t  # identical on every rank
             continue
         sizes = g_sizes if name in PER_GUIDE else t_sizes

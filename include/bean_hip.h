@@ -200,6 +200,10 @@ enum bean_hip_buf {
     BEAN_BUF_EPS_U_OUT,       /* f64 (G)                                         opt  */
     BEAN_BUF_PRIOR_IA,        /* f64 (G)   survival NormalModel: prior concentration of the Dirichlet-over-guides
                                  site, prior_params["initial_abundance"]                      opt  */
+    BEAN_BUF_XCHG_COV,        /* f64 (R)   guide-sharded sorting NormalModel with sample covariates: sum over this
+                                 rank's guides of each replicate's d nll / d mu row (the likelihood gradient of
+                                 the shared mu_cov site), all-reduced by the caller between
+                                 bean_hip_sharded_guide and bean_hip_sharded_update                opt  */
     /* ---- loss */
     BEAN_BUF_LOSS_HIST = 112, /* f64 (capacity) one entry per SVI step                */
     BEAN_BUF_COUNT = 128
@@ -251,6 +255,8 @@ int bean_hip_svi_run(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step,
  *     bean_hip_sharded_guide     -> BEAN_BUF_XCHG_TGRAD  (ControlNormal, tiling: per-target likelihood
  *                                                         gradients; not written when the slot is unbound)
  *                                -> BEAN_BUF_XCHG_SQ     (survival NormalModel: projection sums)
+ *                                -> BEAN_BUF_XCHG_COV    (sorting NormalModel with sample covariates: the
+ *                                                         replicates' gradient sums of the shared mu_cov site)
  *     bean_hip_sharded_update(last)                       gradients, ClippedAdam, draws of the next step
  *
  * Families whose parameters are all per-target or per-guide with target-aligned shards (sorting
@@ -259,6 +265,28 @@ int bean_hip_sharded_begin(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step
 int bean_hip_sharded_sums(bean_hip_ctx* ctx, void* stream);
 int bean_hip_sharded_guide(bean_hip_ctx* ctx, void* stream);
 int bean_hip_sharded_update(bean_hip_ctx* ctx, int32_t last, void* stream);
+
+/* The same per-step exchange without the host in the loop: the library owns an RCCL communicator (one
+ * process per GPU; RCCL is resolved at run time from the shared object `rccl_path` names - the one
+ * PyTorch has already loaded - so that the library itself has no link-time dependency on it) and
+ * bean_hip_svi_run_exchanged enqueues, per step,
+ *     [all-reduce GSUM] guide kernels [all-reduce TGRAD (+ SQ, grouped)] update
+ * on `stream`: ncclAllReduce(sum, float64, in place) on the bound BEAN_BUF_XCHG_* buffers between the
+ * kernels, no host synchronisation, no Python.  graph_chunk > 0 additionally captures 2^k steps,
+ * collectives included, into hipGraphs (opt-in: whether RCCL's kernels can be captured depends on the
+ * RCCL build; on refusal the call falls back to eager launches and says so in bean_hip_last_error).
+ *
+ *   bean_hip_comm_unique_id   rank 0 only: fills id[128] (ncclGetUniqueId); the caller broadcasts it
+ *   bean_hip_comm_init        every rank, collectively (ncclCommInitRank on the current device)
+ *   bean_hip_comm_destroy     ncclCommDestroy
+ * Returns 0, or -1 with bean_hip_last_error() (RCCL missing, refused, ...): callers then keep stepping
+ * with bean_hip_sharded_* and their own all-reduce. */
+#define BEAN_HIP_COMM_ID_BYTES 128
+int bean_hip_comm_unique_id(const char* rccl_path, uint8_t* id);
+int bean_hip_comm_init(bean_hip_ctx* ctx, const char* rccl_path, const uint8_t* id, int32_t rank, int32_t world);
+int bean_hip_comm_destroy(bean_hip_ctx* ctx);
+int bean_hip_svi_run_exchanged(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step, uint64_t n_steps,
+                               int32_t graph_chunk, void* stream);
 
 /* Introspection for bench.py / DESIGN.md: algorithmic bytes one step moves
  * (each input read once, each parameter and moment read and written once) and

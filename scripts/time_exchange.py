@@ -1,0 +1,85 @@
+"""Per-step cost of the exchange families' stepping path against the plain device loop.
+
+    python scripts/time_exchange.py [tag]     ->  gpurun_out/exchange_1rank[_tag].json
+
+One rank, `nccl` process group (every collective is a copy, but the call path - host submission, RCCL
+launch, stream interplay - is the one an N-rank fit pays per step): tiling (BASELINE config 3) and
+survival (config 5) at full size and at 1/8 of the guides (what one of 8 ranks holds), each timed as
+  svi_run         bean_hip_svi_run, hipGraph replay, no exchange           (the floor)
+  exchanged       HipSVI.run_exchanged driven from Python with torch.distributed.all_reduce
+  native          bean_hip_svi_run_exchanged: the library enqueues kernels + ncclAllReduce itself
+  native_graph    ... replaying hipGraphs of 32 exchanged steps, collectives captured
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29577")
+
+import torch
+import torch.distributed as dist
+
+import bean_amd  # noqa: F401
+from bean_amd import engine
+from bean_amd.preprocessing import synthetic as syn
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+
+
+def time_it(fn, steps):
+    fn(20)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    fn(steps)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps * 1e6
+
+
+def case(family, data, steps=300, **kw):
+    out = {}
+    data = data.to(dev)
+    eng = engine.HipSVI(family, data, num_steps=steps + 100, device=dev, **kw)
+    out["svi_run_us"] = round(time_it(lambda n: eng.run(n), steps), 2)
+    eng.close()
+    eng = engine.HipSVI(family, data, num_steps=steps + 100, device=dev, **kw)
+    x = eng.exchange_buffers()
+    out["exchange"] = {k: int(v.numel()) for k, v in x.items()}
+    out["exchanged_us"] = round(time_it(lambda n: eng.run_exchanged(n, dist.all_reduce), steps), 2)
+    out["exchanged_path"] = getattr(eng, "last_exchange_path", "python loop: 3 ctypes calls + torch.distributed.all_reduce per step")
+    eng.close()
+    out["overhead_us"] = round(out["exchanged_us"] - out["svi_run_us"], 2)
+    for key, chunk in (("native_us", 0), ("native_graph_us", 32)):
+        eng = engine.HipSVI(family, data, num_steps=steps + 100, device=dev, **kw)
+        if not eng.init_native_comm():
+            out[key] = None
+            eng.close()
+            continue
+        out[key] = round(time_it(lambda n: eng.run_exchanged(n, None, graph_chunk=chunk), steps), 2)
+        out[key.replace("_us", "_path")] = eng.last_exchange_path
+        msg = eng.lib.bean_hip_last_error().decode()
+        if chunk and "could not be captured" in msg:
+            out[key.replace("_us", "_path")] += " (capture refused: eager)"
+        eng.close()
+    return out
+
+
+res = {}
+for name, make, family, full in (("config3 tiling", lambda g: syn.make_sorting_tiling_screen(g, 5, seed=20240503), "MultiMixtureNormal", 50000),
+                                 ("config5 survival", lambda g: syn.make_survival_variant_screen(g, 3, seed=20240506), "MixtureNormal", 100000)):
+    for frac in (1, 8):
+        g = full // frac
+        data = make(g)
+        kw = {}
+        if family == "MixtureNormal":
+            kw["t0_totals"] = (data.X[:, 0, :].float() + 1).sum(-1)
+        res[f"{name}, {g} guides ({'full' if frac == 1 else '1/8: one rank of 8'})"] = case(family, data, **kw)
+        print(json.dumps(res, indent=1), flush=True)
+tag = ("_" + sys.argv[1]) if len(sys.argv) > 1 else ""
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open(f"gpurun_out/exchange_1rank{tag}.json", "w"), indent=1)
+dist.destroy_process_group()

@@ -1,6 +1,8 @@
 """Sample covariates of the sorting NormalModel (`uns["sample_covariates"]`): the data-class side
 (bean/preprocessing/data_class.py:75-92, 972-979) on CPU, and the HIP path against the oracle
 (bean/model/model.py:73-91, 771-783) on the GPU."""
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -163,3 +165,103 @@ def test_other_families_refuse_sample_covariates():
     data.rep_by_cov = torch.tensor([[0], [1]])
     with pytest.raises(ValueError, match="sample_covariates"):
         engine.HipSVI("MixtureNormal", data.to("cuda:0"), num_steps=5)
+
+
+@pytest.mark.gpu
+def test_control_normal_ignores_sample_covariates():
+    """``--fit-negctrl`` on a screen with sample covariates: the reference's ControlNormalModel / Guide have
+    no mu_cov site (model.py:168-252, 861-875) and fit the regrouped (replicate, covariate) replicates;
+    the negative-control subset keeps the attribute (``ScreenTensors.__getitem__``) and must not be
+    refused.  The fit equals the one of the same screen without the attribute."""
+    import numpy as np
+
+    from bean_amd import engine
+
+    data = _synthetic_with_covariates(900, 4, 1, seed=29)
+    neg = data[data.negctrl_guide_idx]
+    assert getattr(neg, "sample_covariates", None) is not None
+    a = engine.HipSVI("ControlNormal", neg.to("cuda:0"), num_steps=100)
+    a.run(30, seed=3)
+    plain = data[data.negctrl_guide_idx]
+    plain.sample_covariates = None
+    b = engine.HipSVI("ControlNormal", plain.to("cuda:0"), num_steps=100)
+    b.run(30, seed=3)
+    assert set(a.constrained()) == {"mu_loc", "mu_scale", "sd_loc", "sd_scale"}
+    for k, v in a.constrained().items():
+        assert torch.equal(v, b.constrained()[k]), k
+    assert a.losses() == b.losses()
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+def test_guide_shards_share_mu_cov():
+    """Sample covariates in a guide-sharded fit: mu_cov is shared by every guide, so the replicates'
+    gradient sums are exchanged per step (BEAN_BUF_XCHG_COV) and every shard applies the same update;
+    per-target parameters stay shard-local.  Shards as engines in one process, the all-reduce done by
+    hand between the phases, as in tests/test_gpu_sharded_exchange.py."""
+    import numpy as np
+
+    from bean_amd import engine, parallel
+
+    DEV = "cuda:0"
+    data = _synthetic_with_covariates(1200, 4, 2, seed=31)
+    n = 25
+    whole = engine.HipSVI("Normal", data.to(DEV), num_steps=200)
+    whole.run(n, seed=9)
+    ref, ref_loss = whole.constrained(), np.array(whole.losses())
+    shards = parallel.plan_shards(data.target_lengths.numpy(), 3)
+    engines = [engine.HipSVI("Normal", parallel.shard_screen(data, sh).to(DEV), num_steps=200, guide_offset=sh[0],
+                             target_offset=sh[2], n_guides_total=data.n_guides, loss_owner=(k == 0))
+               for k, sh in enumerate(shards)]
+    for e in engines:
+        assert set(e.exchange_buffers()) == {"cov"}
+        e.phase("begin", 9, 0, n)
+    for i in range(n):
+        for e in engines:
+            e.phase("sums")
+            e.phase("guide")
+        torch.cuda.synchronize()
+        tot = torch.stack([e.exchange_buffers()["cov"] for e in engines]).sum(0)
+        for e in engines:
+            e.exchange_buffers()["cov"].copy_(tot)
+        torch.cuda.synchronize()
+        for e in engines:
+            e.phase("update", 1 if i == n - 1 else 0)
+    torch.cuda.synchronize()
+    for e in engines:
+        e.steps_done = n
+    for name in ("mu_cov_loc", "mu_cov_scale"):
+        for e in engines:
+            assert torch.equal(e.constrained()[name], engines[0].constrained()[name]), name
+        err = (engines[0].constrained()[name].double() - ref[name].double()).abs().max().item()
+        assert err <= 2e-5, (name, err)
+    for name in ("mu_loc", "mu_scale", "sd_loc", "sd_scale"):
+        got = torch.cat([e.constrained()[name] for e in engines])
+        err = (got.double() - ref[name].double()).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref[name].abs().max().item()), (name, err)
+    np.testing.assert_allclose(sum(np.array(e.losses()) for e in engines), ref_loss, rtol=1e-6)
+    for e in engines + [whole]:
+        e.close()
+
+
+@pytest.mark.gpu
+def test_cli_uniform_edit_fit_negctrl_on_a_screen_with_sample_covariates(tmp_path):
+    """`bean run sorting variant --uniform-edit --fit-negctrl` on an .h5ad with uns["sample_covariates"]: the
+    negative-control fit (ControlNormal, no mu_cov site) runs on the regrouped replicates, the main fit
+    models the covariate, and the element table carries the covariate and the scaled columns."""
+    from bean_amd.cli.execute import main as bean_main
+    from bean_amd.framework import h5ad_io
+
+    scr = _screen_with_covariates(n_targets=60, seed=3)
+    scr.guides["target_group"] = np.where(np.arange(len(scr.guides)) < 45, "NegCtrl", "Variant")
+    path = str(tmp_path / "cov_screen.h5ad")
+    h5ad_io.write_screen(scr, path)
+    out = str(tmp_path / "out")
+    assert bean_main(["run", "sorting", "variant", path, "--uniform-edit", "--fit-negctrl", "--n-iter", "20",
+                      "-o", out]) == 0
+    (d,) = [os.path.join(out, q) for q in os.listdir(out) if q.startswith("bean_run_result.")]
+    el = pd.read_csv(f"{d}/bean_element_result.Normal.csv")
+    assert len(el) == 60
+    assert {"mu", "mu_sd", "mu_z", "mu_scaled", "mu_z_scaled", "mu_batch"} <= set(el.columns), list(el.columns)
+    assert np.isfinite(el[["mu", "mu_sd", "mu_scaled"]].values).all()
