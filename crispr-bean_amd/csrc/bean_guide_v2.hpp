@@ -56,6 +56,274 @@ __device__ __forceinline__ void w2_row_store(double* p, double v) {
 }
 #define W2_ROW_STORE(ptr, val) w2_row_store<STEP>((ptr), (val))
 
+// The arithmetic of one (replicate, guide): draw, accessibility transform, both Dirichlet-Multinomial terms
+// with their gradients, Multinomial on the control allele counts, the pi site's densities and implicit
+// gradient; stores the five rows of the pair and returns its part of the loss.  ONE body for every kernel
+// that runs it (k_guide_wave2, k_step_wave2: a wave = 64 guides of one replicate, LS = 64; k_svi_tile:
+// a workgroup = all replicates of a tile, LS = its thread count), so that they produce the same bits.
+//   tp            this guide's column of the staged Phi tables: tp[(which * B + b) * ntm]
+//   c_sf, c_sm, c_p0   the replicate's per-bin constants (size factors of both likelihoods, sample mask, P0)
+//   xl            the pair's counts, xl[(lik * B + b) * LS] (float; reused for parked digamma halves)
+//   dps           thread-private column of B doubles, dps[b * LS]
+//   m_*           per-guide values staged by the caller (a0, a0_bcmatch, control allele counts) and two
+//                 thread-private slots for the model-side concentrations
+template <int FAM, bool ACC, bool STEP, int LS>
+__device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCtr& ctr, int r, int g, bool rgm,
+                                                  float api0, float api1, double pa0, const uint4* philox_first,
+                                                  const double* tp, int ntm, const double* c_sf, const double* c_sm,
+                                                  const double* c_p0, float* xl, double* dps, const double* m_a0,
+                                                  const double* m_a0bc, const double* m_cnt0, const double* m_cnt1,
+                                                  double* m_cp0, double* m_cp1) {
+    constexpr bool MIX = FAM == kMixture;
+    const int G = c.G, B = c.B, R = c.R;
+    const bool use_bc = (c.flags & kUseBc) != 0;
+    const long rgi = (long)r * G + g;
+    const long RG = (long)R * G;
+    double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0;
+    double dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
+    if (MIX) {
+        const double al0 = (double)expf(api0), al1 = (double)expf(api1);
+        const double rs = frcp(al0 + al1) * pa0;
+        const double cp0 = al0 * rs, cp1 = al1 * rs;
+        *m_cp0 = cp0;  // needed again after the likelihoods
+        *m_cp1 = cp1;
+        const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
+#if BEAN_GW_DIAG == 1
+        if (true) {
+            pi0 = 0.3 + 1e-3 * cq0;
+            pi1 = 0.7 - 1e-3 * cq1;
+        } else {
+#else
+        if (c.pi_in) {
+            pi0 = c.pi_in[rgi * 2];
+            pi1 = c.pi_in[rgi * 2 + 1];
+        } else {
+#endif
+            Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+            const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng, philox_first);
+            const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
+            const double rs2 = frcp(gm0 + gm1);
+            pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
+            pi1 = fmin(fmax(gm1 * rs2, kDblMin), kOneMinus);
+        }
+        if (c.flags & kDumpPi) {
+            c.pi_out[rgi * 2] = pi0;
+            c.pi_out[rgi * 2 + 1] = pi1;
+        }
+        pe1 = pi1;
+        if (ACC) {
+            // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
+            const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+            const double s1 = pi1 * kacc;
+            const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+            const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+            const double l = flog(p1c * frcp(1.0 - p1c)) + c.lpn[g];
+            const double el = exp(l);
+            const double pn = el * frcp(1.0 + el);
+            const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+            pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+            dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
+            dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+        }
+    }
+    const double w0 = MIX ? (ACC ? 1.0 - pe1 : pi0) : 0.0;  // weight of the wild-type component
+    const double w1 = MIX ? (ACC ? pe1 : pi1) : 1.0;        // weight of the edited component
+    const double epsB = kEps / (double)B;
+    double a_mu = 0.0, a_y = 0.0, g0 = 0.0, g1 = 0.0, nll = 0.0;
+    // pass 1 of both likelihoods: n = sum x_b (data) and S = sum_b e_b sf_b
+    double S_x = 0.0, S_bc = 0.0, n_x = 0.0, n_bc = 0.0;
+#pragma unroll 1
+    for (int b = 0; b < B; ++b) {
+        const double e = fma(w0, MIX ? c_p0[b] : 0.0, w1 * tp[b * ntm]);
+        S_x += e * c_sf[b];
+        S_bc += e * c_sf[B + b];
+        n_x += (double)xl[b * LS];
+        n_bc += (double)xl[(B + b) * LS];
+    }
+    // ---- loop 1 of BOTH likelihoods in one pass over the bins: the lgamma / digamma differences of
+    // X[b] and X_bcmatch[b] are independent dependency chains, evaluated side by side
+    // (lgamma_digamma_diff2).  The digamma differences are parked in LDS: those of X in dps[b], those
+    // of X_bcmatch as two 32-bit halves in the count slots of bin b, which are dead once read.
+    // The site is masked by (sum_b x > mask_thres) & repguide_mask (model.py:526-547): lane by lane.
+    const bool on_x = rgm && n_x > (double)c.mask_thres;
+    const bool on_bc = use_bc && rgm && n_bc > (double)c.mask_thres;
+    const double inv_x = frcp(S_x + kEps), inv_bc = frcp(S_bc + kEps);
+    const double ai_x = *m_a0 * inv_x, ai_bc = *m_a0bc * inv_bc;
+    double A0_x = 0.0, A0_bc = 0.0, lsum_x = 0.0, lsum_bc = 0.0;
+    bool fl_x = false, fl_bc = false;
+    if (use_bc) {
+        unsigned int* xu = reinterpret_cast<unsigned int*>(xl);
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            const double p0 = MIX ? c_p0[b] : 0.0, p1 = tp[b * ntm], smb = c_sm[b];
+            const double x0 = (double)xl[b * LS], x1 = (double)xl[(B + b) * LS];
+            const double ar0 = alpha_raw(w0, p0, w1, p1, c_sf[b], epsB, ai_x * smb);
+            const double ar1 = alpha_raw(w0, p0, w1, p1, c_sf[B + b], epsB, ai_bc * smb);
+            fl_x = fl_x || ar0 < kEps;
+            fl_bc = fl_bc || ar1 < kEps;
+            const double al0 = ar0 < kEps ? kEps : ar0, al1 = ar1 < kEps ? kEps : ar1;
+            A0_x += al0;
+            A0_bc += al1;
+            const DD2 dd = lgamma_digamma_diff2(al0, x0, al1, x1);
+            lsum_x += dd.a.d;
+            lsum_bc += dd.b.d;
+            dps[b * LS] = dd.a.dp;
+            const unsigned long long bits = __builtin_bit_cast(unsigned long long, dd.b.dp);
+            xu[b * LS] = (unsigned int)bits;
+            xu[(B + b) * LS] = (unsigned int)(bits >> 32);
+        }
+    } else {
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            const double x0 = (double)xl[b * LS];
+            const double ar0 = alpha_raw(w0, MIX ? c_p0[b] : 0.0, w1, tp[b * ntm], c_sf[b], epsB, ai_x * c_sm[b]);
+            fl_x = fl_x || ar0 < kEps;
+            const double al0 = ar0 < kEps ? kEps : ar0;
+            A0_x += al0;
+            const DD db = lgamma_digamma_diff(al0, x0);
+            lsum_x += db.d;
+            dps[b * LS] = db.dp;
+        }
+    }
+#pragma unroll 1
+    for (int lik = 0; lik < 2; ++lik) {
+        if (lik == 1 && !use_bc) break;
+        if (!(lik ? on_bc : on_x)) continue;
+        const double* sf = c_sf + lik * B;
+        const double nn = lik ? n_bc : n_x;
+        const double a0 = lik ? *m_a0bc : *m_a0;
+        const double inv = lik ? inv_bc : inv_x;
+        const double ai = lik ? ai_bc : ai_x;
+        const double A0 = lik ? A0_bc : A0_x, lsum = lik ? lsum_bc : lsum_x;
+        const bool floored = lik ? fl_bc : fl_x;
+        // total term lgamma(A0 + n) - lgamma(A0): data unless a bin sits on its floor
+        // (DevArgs::tot_const); a lane's arithmetic does not depend on its wave's other lanes
+        DD d0;
+        d0.d = 0.0;
+        d0.dp = 0.0;
+        if (!c.tot_const) {
+            d0 = lgamma_digamma_diff(A0, nn);
+        } else if (__any(floored)) {
+            const DD dt = lgamma_digamma_diff(A0, nn), dc = lgamma_digamma_diff(a0, nn);
+            if (floored) {
+                d0.d = dt.d - dc.d;
+                d0.dp = dt.dp;
+            }
+        }
+        nll += d0.d - lsum;
+        // loop 2: with ga_b = d0.dp - dpsi_b (0 where alpha_b sits on its floor) and
+        // k_b = a0 m_b inv sf_b:  S_Q = sum ga_b k_b Q_b,  t_Q = sum sf_b Q_b,
+        // Wa = sum ga_b alpha_b;  d nll / d(weight of Q) = S_Q - Wa inv t_Q
+        double Wa = 0.0;
+        double S_mu = 0.0, S_y = 0.0, S_0 = 0.0, S_1 = 0.0;
+        double t_mu = 0.0, t_y = 0.0, t_0 = 0.0, t_1 = 0.0;
+#pragma unroll 1
+        for (int b = 0; b < (BEAN_GW_DIAG == 4 ? 1 : B); ++b) {
+            const double p0 = MIX ? c_p0[b] : 0.0;
+            const double p1 = tp[b * ntm], pmu = tp[(B + b) * ntm], py = tp[(2 * B + b) * ntm];
+            const double sfb = sf[b];
+            const double km = ai * c_sm[b];
+            const double araw = alpha_raw(w0, p0, w1, p1, sfb, epsB, km);
+            double dpb = dps[b * LS];
+            if (lik) {
+                const unsigned int* xu = reinterpret_cast<const unsigned int*>(xl);
+                dpb = __builtin_bit_cast(double, ((unsigned long long)xu[(B + b) * LS] << 32) |
+                                                     (unsigned long long)xu[b * LS]);
+            }
+            const double ga = araw < kEps ? 0.0 : d0.dp - dpb;
+            Wa += ga * araw;
+            const double cb = ga * km * sfb;
+            S_mu += cb * pmu;
+            t_mu += sfb * pmu;
+            S_y += cb * py;
+            t_y += sfb * py;
+            S_1 += cb * p1;
+            t_1 += sfb * p1;
+            if (MIX) {
+                S_0 += cb * p0;
+                t_0 += sfb * p0;
+            }
+        }
+        const double W = Wa * inv;
+        a_mu += w1 * (S_mu - W * t_mu);
+        a_y += w1 * (S_y - W * t_y);
+        g0 += S_0 - W * t_0;
+        g1 += S_1 - W * t_1;
+    }
+    double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
+    W2_ROW_STORE(row + kW2Gmu * RG, a_mu);
+    W2_ROW_STORE(row + kW2Gy * RG, a_y);
+    if (MIX) {
+        const double cp0 = *m_cp0, cp1 = *m_cp1;
+        const bool cl0 = cp0 < 1e-5, cl1 = cp1 < 1e-5;
+        const double cq0 = cl0 ? 1e-5 : cp0, cq1 = cl1 ? 1e-5 : cp1;
+        // d loss / d pi through the likelihood
+        double gpi0 = g0, gpi1 = g1;
+        if (ACC) {
+            gpi0 = 0.0;
+            gpi1 = (g1 - g0) * dpe1_dpi1;
+            W2_ROW_STORE(row + kW2Gnoise * RG, (g1 - g0) * dpe1_dl);
+        }
+        // digamma of the concentrations, tabulated by k_param (DevArgs::dgq): issued here, used
+        // by the implicit-gradient calls below
+        const double dgS = c.dgq[3 * (long)G + g], dg0 = c.dgq[4 * (long)G + g], dg1 = c.dgq[5 * (long)G + g];
+        const double lpi0 = flog(pi0), lpi1 = flog(pi1);
+        const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
+        if (rgm) {
+            // Multinomial(probs = pi) on control allele counts (model.py:470-474):
+            // torch renormalises the probabilities and clamps them to [eps, 1 - eps]
+            const double s = pi0 + pi1;
+            const double ls = s == 1.0 ? 0.0 : flog(s);
+            const double rs = s == 1.0 ? 1.0 : frcp(s);
+            const double cnt0 = *m_cnt0, cnt1 = *m_cnt1;
+            const double pr0 = pi0 * rs, pr1 = pi1 * rs;
+            const bool in0 = pr0 > kProbEps && pr0 < 1.0 - kProbEps;
+            const bool in1 = pr1 > kProbEps && pr1 < 1.0 - kProbEps;
+            const double lg0 = in0 ? lpi0 - ls : flog(fmin(fmax(pr0, kProbEps), 1.0 - kProbEps));
+            const double lg1 = in1 ? lpi1 - ls : flog(fmin(fmax(pr1, kProbEps), 1.0 - kProbEps));
+            nll -= cnt0 * lg0;
+            nll -= cnt1 * lg1;
+            if (in0) gpi0 -= cnt0 * rpi0;
+            if (in1) gpi1 -= cnt1 * rpi1;
+            // - log p(pi): Dirichlet(c_p) under the repguide mask (model.py:454-463); its
+            // normaliser is per guide (k_param)
+            gpi0 -= (cp0 - 1.0) * rpi0;
+            gpi1 -= (cp1 - 1.0) * rpi1;
+            nll -= (cp0 - 1.0) * lpi0 + (cp1 - 1.0) * lpi1;
+        }
+        // + log q(pi): Dirichlet(c_q), unmasked in the guide (model.py:839-847)
+        gpi0 += (cq0 - 1.0) * rpi0;
+        gpi1 += (cq1 - 1.0) * rpi1;
+        nll += (cq0 - 1.0) * lpi0 + (cq1 - 1.0) * lpi1;
+        const double proj = pi0 * gpi0 + pi1 * gpi1;
+        const double total = cq0 + cq1;
+        double path0 = 0.0, path1 = 0.0;
+        // torch's approximation switches formula on x <= 0.5 / x >= 0.5: a lane takes its SMALLER
+        // component in the first pass and the larger one in the second, so that a pass runs one side's
+        // formulas for the whole wave (in component order every pass ran both sides': 13 % of
+        // the kernel).  Same calls, same arguments, same bits.
+        const int first = pi0 <= pi1 ? 0 : 1;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int a = pass ^ first;
+            if (a ? cl1 : cl0) continue;
+#if BEAN_GW_DIAG == 2
+            const double v = (a ? pi1 : pi0) * ((a ? gpi1 : gpi0) - proj);
+#else
+            const double v = dirichlet_grad_one_pre(a ? pi1 : pi0, a ? cq1 : cq0, total, a ? dg1 : dg0, dgS) *
+                             ((a ? gpi1 : gpi0) - proj);
+#endif
+            path0 = a ? path0 : v;
+            path1 = a ? v : path1;
+        }
+        // d loss / d c_a of this replicate apart from the per-guide normaliser terms:
+        // (c_q unclamped) log pi_a + pathwise term, minus (masked) log pi_a of the model site
+        W2_ROW_STORE(row + kW2GA0 * RG, (cl0 ? 0.0 : lpi0 + path0) - (rgm ? lpi0 : 0.0));
+        W2_ROW_STORE(row + kW2GA1 * RG, (cl1 ? 0.0 : lpi1 + path1) - (rgm ? lpi1 : 0.0));
+    }
+    return nll;
+}
+
 // The work of one wave = 64 consecutive guides of one replicate.  Returns false for the padded tiles of
 // the XCD-aware grid; otherwise the wave's part of the loss in `tot` (valid in lane 0).
 template <int FAM, bool ACC, bool STEP>
@@ -198,263 +466,10 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     }
     __syncthreads();
 
-    if (valid) {
-        const long rgi = (long)r * G + g;
-        const long RG = (long)R * G;
-        const double* tp = tabs + tcol;  // this guide's column: tp[(which * B + b) * ntm]
-        const double* c_sf = cst;        // c_sf[lik * B + b], c_sm[b], c_p0[b]
-        const double* c_sm = cst + 2 * B;
-        const double* c_p0 = cst + 3 * B;
-        double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0;
-        double dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
-        if (MIX) {
-            const double al0 = (double)expf(api0), al1 = (double)expf(api1);
-            const double rs = frcp(al0 + al1) * pa0;
-            const double cp0 = al0 * rs, cp1 = al1 * rs;
-            ms[4 * 64] = cp0;  // needed again after the likelihoods
-            ms[5 * 64] = cp1;
-            const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
-#if BEAN_GW_DIAG == 1
-            if (true) {
-                pi0 = 0.3 + 1e-3 * cq0;
-                pi1 = 0.7 - 1e-3 * cq1;
-            } else {
-#else
-            if (c.pi_in) {
-                pi0 = c.pi_in[rgi * 2];
-                pi1 = c.pi_in[rgi * 2 + 1];
-            } else {
-#endif
-                BEAN_STAMP_AT(1);
-                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
-                const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng, &philox_first);
-                const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
-                const double rs2 = frcp(gm0 + gm1);
-                pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
-                pi1 = fmin(fmax(gm1 * rs2, kDblMin), kOneMinus);
-            }
-            if (c.flags & kDumpPi) {
-                c.pi_out[rgi * 2] = pi0;
-                c.pi_out[rgi * 2 + 1] = pi1;
-            }
-            pe1 = pi1;
-            if (ACC) {
-                // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
-                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
-                const double s1 = pi1 * kacc;
-                const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
-                const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
-                const double l = flog(p1c * frcp(1.0 - p1c)) + c.lpn[g];
-                const double el = exp(l);
-                const double pn = el * frcp(1.0 + el);
-                const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
-                pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
-                dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
-                dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
-            }
-        }
-        const double w0 = MIX ? (ACC ? 1.0 - pe1 : pi0) : 0.0;  // weight of the wild-type component
-        const double w1 = MIX ? (ACC ? pe1 : pi1) : 1.0;        // weight of the edited component
-        const double epsB = kEps / (double)B;
-        double a_mu = 0.0, a_y = 0.0, g0 = 0.0, g1 = 0.0, nll = 0.0;
-        // pass 1 of both likelihoods: n = sum x_b (data) and S = sum_b e_b sf_b
-        double S_x = 0.0, S_bc = 0.0, n_x = 0.0, n_bc = 0.0;
-#pragma unroll 1
-        for (int b = 0; b < B; ++b) {
-            const double e = fma(w0, MIX ? c_p0[b] : 0.0, w1 * tp[b * ntm]);
-            S_x += e * c_sf[b];
-            S_bc += e * c_sf[B + b];
-            n_x += (double)xs[b * 64 + lane];
-            n_bc += (double)xs[(B + b) * 64 + lane];
-        }
-        // ---- loop 1 of BOTH likelihoods in one pass over the bins: the lgamma / digamma differences of
-        // X[b] and X_bcmatch[b] are independent dependency chains, evaluated side by side
-        // (lgamma_digamma_diff2).  The digamma differences are parked in LDS: those of X in dps[b], those
-        // of X_bcmatch as two 32-bit halves in the count slots of bin b, which are dead once read.
-        // The site is masked by (sum_b x > mask_thres) & repguide_mask (model.py:526-547): lane by lane.
-        const bool on_x = rgm && n_x > (double)c.mask_thres;
-        const bool on_bc = use_bc && rgm && n_bc > (double)c.mask_thres;
-        const double inv_x = frcp(S_x + kEps), inv_bc = frcp(S_bc + kEps);
-        const double ai_x = ms[0] * inv_x, ai_bc = ms[64] * inv_bc;
-        double A0_x = 0.0, A0_bc = 0.0, lsum_x = 0.0, lsum_bc = 0.0;
-        bool fl_x = false, fl_bc = false;
-        BEAN_STAMP_AT(2);
-        if (use_bc) {
-            unsigned int* xu = reinterpret_cast<unsigned int*>(xs);
-#pragma unroll 1
-            for (int b = 0; b < B; ++b) {
-                const double p0 = MIX ? c_p0[b] : 0.0, p1 = tp[b * ntm], smb = c_sm[b];
-                const double x0 = (double)xs[b * 64 + lane], x1 = (double)xs[(B + b) * 64 + lane];
-                const double ar0 = alpha_raw(w0, p0, w1, p1, c_sf[b], epsB, ai_x * smb);
-                const double ar1 = alpha_raw(w0, p0, w1, p1, c_sf[B + b], epsB, ai_bc * smb);
-                fl_x = fl_x || ar0 < kEps;
-                fl_bc = fl_bc || ar1 < kEps;
-                const double al0 = ar0 < kEps ? kEps : ar0, al1 = ar1 < kEps ? kEps : ar1;
-                A0_x += al0;
-                A0_bc += al1;
-                const DD2 dd = lgamma_digamma_diff2(al0, x0, al1, x1);
-                lsum_x += dd.a.d;
-                lsum_bc += dd.b.d;
-                dps[b * 64] = dd.a.dp;
-                const unsigned long long bits = __builtin_bit_cast(unsigned long long, dd.b.dp);
-                xu[b * 64 + lane] = (unsigned int)bits;
-                xu[(B + b) * 64 + lane] = (unsigned int)(bits >> 32);
-            }
-        } else {
-#pragma unroll 1
-            for (int b = 0; b < B; ++b) {
-                const double x0 = (double)xs[b * 64 + lane];
-                const double ar0 = alpha_raw(w0, MIX ? c_p0[b] : 0.0, w1, tp[b * ntm], c_sf[b], epsB, ai_x * c_sm[b]);
-                fl_x = fl_x || ar0 < kEps;
-                const double al0 = ar0 < kEps ? kEps : ar0;
-                A0_x += al0;
-                const DD db = lgamma_digamma_diff(al0, x0);
-                lsum_x += db.d;
-                dps[b * 64] = db.dp;
-            }
-        }
-#pragma unroll 1
-        for (int lik = 0; lik < 2; ++lik) {
-            if (lik == 1 && !use_bc) break;
-            if (lik == 1) BEAN_STAMP_AT(5);
-            if (!(lik ? on_bc : on_x)) continue;
-            const double* sf = c_sf + lik * B;
-            const double nn = lik ? n_bc : n_x;
-            const double a0 = ms[lik * 64];
-            const double inv = lik ? inv_bc : inv_x;
-            const double ai = lik ? ai_bc : ai_x;
-            const double A0 = lik ? A0_bc : A0_x, lsum = lik ? lsum_bc : lsum_x;
-            const bool floored = lik ? fl_bc : fl_x;
-            if (lik == 0) BEAN_STAMP_AT(3);
-            // total term lgamma(A0 + n) - lgamma(A0): data unless a bin sits on its floor
-            // (DevArgs::tot_const); a lane's arithmetic does not depend on its wave's other lanes
-            DD d0;
-            d0.d = 0.0;
-            d0.dp = 0.0;
-            if (!c.tot_const) {
-                d0 = lgamma_digamma_diff(A0, nn);
-            } else if (__any(floored)) {
-                const DD dt = lgamma_digamma_diff(A0, nn), dc = lgamma_digamma_diff(a0, nn);
-                if (floored) {
-                    d0.d = dt.d - dc.d;
-                    d0.dp = dt.dp;
-                }
-            }
-            nll += d0.d - lsum;
-            // loop 2: with ga_b = d0.dp - dpsi_b (0 where alpha_b sits on its floor) and
-            // k_b = a0 m_b inv sf_b:  S_Q = sum ga_b k_b Q_b,  t_Q = sum sf_b Q_b,
-            // Wa = sum ga_b alpha_b;  d nll / d(weight of Q) = S_Q - Wa inv t_Q
-            double Wa = 0.0;
-            double S_mu = 0.0, S_y = 0.0, S_0 = 0.0, S_1 = 0.0;
-            double t_mu = 0.0, t_y = 0.0, t_0 = 0.0, t_1 = 0.0;
-#pragma unroll 1
-            for (int b = 0; b < (BEAN_GW_DIAG == 4 ? 1 : B); ++b) {
-                const double p0 = MIX ? c_p0[b] : 0.0;
-                const double p1 = tp[b * ntm], pmu = tp[(B + b) * ntm], py = tp[(2 * B + b) * ntm];
-                const double sfb = sf[b];
-                const double km = ai * c_sm[b];
-                const double araw = alpha_raw(w0, p0, w1, p1, sfb, epsB, km);
-                double dpb = dps[b * 64];
-                if (lik) {
-                    const unsigned int* xu = reinterpret_cast<const unsigned int*>(xs);
-                    dpb = __builtin_bit_cast(double, ((unsigned long long)xu[(B + b) * 64 + lane] << 32) |
-                                                         (unsigned long long)xu[b * 64 + lane]);
-                }
-                const double ga = araw < kEps ? 0.0 : d0.dp - dpb;
-                Wa += ga * araw;
-                const double cb = ga * km * sfb;
-                S_mu += cb * pmu;
-                t_mu += sfb * pmu;
-                S_y += cb * py;
-                t_y += sfb * py;
-                S_1 += cb * p1;
-                t_1 += sfb * p1;
-                if (MIX) {
-                    S_0 += cb * p0;
-                    t_0 += sfb * p0;
-                }
-            }
-            if (lik == 0) BEAN_STAMP_AT(4);
-            const double W = Wa * inv;
-            a_mu += w1 * (S_mu - W * t_mu);
-            a_y += w1 * (S_y - W * t_y);
-            g0 += S_0 - W * t_0;
-            g1 += S_1 - W * t_1;
-        }
-        BEAN_STAMP_AT(6);
-        double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
-        W2_ROW_STORE(row + kW2Gmu * RG, a_mu);
-        W2_ROW_STORE(row + kW2Gy * RG, a_y);
-        if (MIX) {
-            const double cp0 = ms[4 * 64], cp1 = ms[5 * 64];
-            const bool cl0 = cp0 < 1e-5, cl1 = cp1 < 1e-5;
-            const double cq0 = cl0 ? 1e-5 : cp0, cq1 = cl1 ? 1e-5 : cp1;
-            // d loss / d pi through the likelihood
-            double gpi0 = g0, gpi1 = g1;
-            if (ACC) {
-                gpi0 = 0.0;
-                gpi1 = (g1 - g0) * dpe1_dpi1;
-                W2_ROW_STORE(row + kW2Gnoise * RG, (g1 - g0) * dpe1_dl);
-            }
-            // digamma of the concentrations, tabulated by k_param (DevArgs::dgq): issued here, used
-            // by the implicit-gradient calls below
-            const double dgS = c.dgq[3 * (long)G + g], dg0 = c.dgq[4 * (long)G + g], dg1 = c.dgq[5 * (long)G + g];
-            const double lpi0 = flog(pi0), lpi1 = flog(pi1);
-            const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
-            if (rgm) {
-                // Multinomial(probs = pi) on control allele counts (model.py:470-474):
-                // torch renormalises the probabilities and clamps them to [eps, 1 - eps]
-                const double s = pi0 + pi1;
-                const double ls = s == 1.0 ? 0.0 : flog(s);
-                const double rs = s == 1.0 ? 1.0 : frcp(s);
-                const double cnt0 = ms[2 * 64], cnt1 = ms[3 * 64];
-                const double pr0 = pi0 * rs, pr1 = pi1 * rs;
-                const bool in0 = pr0 > kProbEps && pr0 < 1.0 - kProbEps;
-                const bool in1 = pr1 > kProbEps && pr1 < 1.0 - kProbEps;
-                const double lg0 = in0 ? lpi0 - ls : flog(fmin(fmax(pr0, kProbEps), 1.0 - kProbEps));
-                const double lg1 = in1 ? lpi1 - ls : flog(fmin(fmax(pr1, kProbEps), 1.0 - kProbEps));
-                nll -= cnt0 * lg0;
-                nll -= cnt1 * lg1;
-                if (in0) gpi0 -= cnt0 * rpi0;
-                if (in1) gpi1 -= cnt1 * rpi1;
-                // - log p(pi): Dirichlet(c_p) under the repguide mask (model.py:454-463); its
-                // normaliser is per guide (k_param)
-                gpi0 -= (cp0 - 1.0) * rpi0;
-                gpi1 -= (cp1 - 1.0) * rpi1;
-                nll -= (cp0 - 1.0) * lpi0 + (cp1 - 1.0) * lpi1;
-            }
-            // + log q(pi): Dirichlet(c_q), unmasked in the guide (model.py:839-847)
-            gpi0 += (cq0 - 1.0) * rpi0;
-            gpi1 += (cq1 - 1.0) * rpi1;
-            nll += (cq0 - 1.0) * lpi0 + (cq1 - 1.0) * lpi1;
-            const double proj = pi0 * gpi0 + pi1 * gpi1;
-            const double total = cq0 + cq1;
-            double path0 = 0.0, path1 = 0.0;
-            // torch's approximation switches formula on x <= 0.5 / x >= 0.5: a lane takes its SMALLER
-            // component in the first pass and the larger one in the second, so that a pass runs one side's
-            // formulas for the whole wave (in component order every pass ran both sides': 13 % of
-            // the kernel).  Same calls, same arguments, same bits.
-            const int first = pi0 <= pi1 ? 0 : 1;
-#pragma unroll 1
-            for (int pass = 0; pass < 2; ++pass) {
-                const int a = pass ^ first;
-                if (a ? cl1 : cl0) continue;
-#if BEAN_GW_DIAG == 2
-                const double v = (a ? pi1 : pi0) * ((a ? gpi1 : gpi0) - proj);
-#else
-                const double v = dirichlet_grad_one_pre(a ? pi1 : pi0, a ? cq1 : cq0, total, a ? dg1 : dg0, dgS) *
-                                 ((a ? gpi1 : gpi0) - proj);
-#endif
-                path0 = a ? path0 : v;
-                path1 = a ? v : path1;
-            }
-            // d loss / d c_a of this replicate apart from the per-guide normaliser terms:
-            // (c_q unclamped) log pi_a + pathwise term, minus (masked) log pi_a of the model site
-            W2_ROW_STORE(row + kW2GA0 * RG, (cl0 ? 0.0 : lpi0 + path0) - (rgm ? lpi0 : 0.0));
-            W2_ROW_STORE(row + kW2GA1 * RG, (cl1 ? 0.0 : lpi1 + path1) - (rgm ? lpi1 : 0.0));
-        }
-        loss = nll;
-    }
+    if (valid)
+        loss = guide_pair_math<FAM, ACC, STEP, 64>(c, ctr, r, g, rgm, api0, api1, pa0, &philox_first, tabs + tcol, ntm, cst,
+                                                   cst + 2 * B, cst + 3 * B, xs + lane, dps, ms, ms + 64, ms + 2 * 64,
+                                                   ms + 3 * 64, ms + 4 * 64, ms + 5 * 64);
     tot_o = wave_sum(loss);
     BEAN_STAMP_AT(7);
     BEAN_STAMP_CLK(2);

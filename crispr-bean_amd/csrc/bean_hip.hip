@@ -58,6 +58,15 @@ struct bean_hip_ctx {
     bool profile;
     bool profile_param;  // profile mode 2: time k_param<FINISH, ADAM, PREP> instead of the guide kernel
     std::vector<hipEvent_t> ev;  // start/stop pairs
+    // one launch per call for the variant sorting families (bean_tile_svi.hpp): target-aligned tiles
+    bool tile_svi;            // eligible shape and not switched off (BEAN_HIP_STEP=pair)
+    bool tile_ready;          // tile table built by bean_hip_prepare
+    int* tile_tab;            // device: tile_g0[n_tiles + 1], tile_t0[n_tiles + 1]
+    int n_tiles, tile_ntm, tile_gbm, tile_blocks;
+    float* step_sizes;        // device: ClippedAdam step sizes of the steps of one call
+    DevArgs* dargs_dev;       // device copy of DevArgs for k_svi_tile's out-of-line pieces
+    uint64_t step_sizes_cap;
+    std::vector<uint64_t> ev_steps;  // profile mode: SVI steps covered by each timed launch
     // RCCL communicator of a guide-sharded fit (bean_hip_comm_init) and graphs of 2^k exchanged steps
     ncclComm_t comm;
     int comm_world;
@@ -281,6 +290,13 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->graph_seed = 0;
     c->comm = nullptr;
     c->comm_world = 0;
+    c->tile_svi = false;
+    c->tile_ready = false;
+    c->tile_tab = nullptr;
+    c->n_tiles = c->tile_ntm = c->tile_gbm = c->tile_blocks = 0;
+    c->step_sizes = nullptr;
+    c->step_sizes_cap = 0;
+    c->dargs_dev = nullptr;
     c->loss_acc = nullptr;
     c->profile = false;
     c->profile_param = false;
@@ -364,6 +380,15 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         c->fused_step = c->wave2 && !d.wide_targets && s->max_target_len <= 64 && s->n_sample_covariates == 0 &&
                         (s->family == BEAN_FAMILY_MIXTURE_NORMAL || s->family == BEAN_FAMILY_NORMAL) &&
                         (sm && !strcmp(sm, "fused"));
+    }
+    {
+        // OPT-IN (BEAN_HIP_STEP=tile): ONE launch per call, a workgroup per tile of targets
+        // (bean_tile_svi.hpp).  Bit-identical to the two launches per step and measured slower (see the header).
+        const char* sm = getenv("BEAN_HIP_STEP");
+        const int gb = s->n_reps <= 64 ? kTileThreads / s->n_reps : 0;
+        c->tile_svi = c->wave2 && !d.wide_targets && s->n_sample_covariates == 0 && !c->fused_step &&
+                      (s->family == BEAN_FAMILY_MIXTURE_NORMAL || s->family == BEAN_FAMILY_NORMAL) &&
+                      gb >= 1 && s->max_target_len <= gb && (sm && !strcmp(sm, "tile"));
     }
     const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G
                                            : (c->tiling_wide ? (uint64_t)tq_num(d.A) * Rr * G : 0);
@@ -494,6 +519,9 @@ extern "C" int bean_hip_destroy(bean_hip_ctx* c) {
     (void)bean_hip_comm_destroy(c);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->workspace) (void)hipFree(c->workspace);
+    if (c->tile_tab) (void)hipFree(c->tile_tab);
+    if (c->step_sizes) (void)hipFree(c->step_sizes);
+    if (c->dargs_dev) (void)hipFree(c->dargs_dev);
     if (c->loss_acc) (void)hipFree(c->loss_acc);
     delete c;
     return 0;
@@ -589,6 +617,47 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
         if (nt < 1 || nt > 64) return fail("bean_hip_prepare: guides are not sorted by target (BEAN_BUF_GUIDE_TO_TARGET)");
         if (nt != c->d.tile_targets) drop_graph(c);
         c->d.tile_targets = nt;
+    }
+    c->tile_ready = false;
+    if (c->tile_svi) {
+        // tiles of whole targets with at most kTileThreads / R guides: built on the host from the target
+        // offsets (4 (T + 1) bytes read back once, next to the 4 bytes above)
+        const int T = c->d.T, G = c->d.G, gb = kTileThreads / c->d.R;
+        std::vector<int> toff((size_t)T + 1);
+        HIP_OK(hipMemcpyAsync(toff.data(), c->d.toff, sizeof(int) * ((size_t)T + 1), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        std::vector<int> tg0, tt0;
+        int ntm = 1, gbm = 1;
+        bool ok = toff[0] == 0 && toff[T] == G;
+        for (int t = 0; ok && t < T;) {
+            int t1 = t, g0 = toff[t];
+            while (t1 < T && toff[t1 + 1] - g0 <= gb && toff[t1 + 1] > toff[t1]) ++t1;
+            if (t1 == t) {  // an empty target or one longer than a tile: the two-launch path handles it
+                ok = false;
+                break;
+            }
+            tg0.push_back(g0);
+            tt0.push_back(t);
+            if (t1 - t > ntm) ntm = t1 - t;
+            if (toff[t1] - g0 > gbm) gbm = toff[t1] - g0;
+            t = t1;
+        }
+        if (ok && !tg0.empty()) {
+            tg0.push_back(G);
+            tt0.push_back(T);
+            const size_t n1 = tg0.size();
+            if (c->tile_tab) (void)hipFree(c->tile_tab);
+            c->tile_tab = nullptr;
+            HIP_OK(hipMalloc((void**)&c->tile_tab, 2 * n1 * sizeof(int)));
+            HIP_OK(hipMemcpyAsync(c->tile_tab, tg0.data(), n1 * sizeof(int), hipMemcpyHostToDevice, stream));
+            HIP_OK(hipMemcpyAsync(c->tile_tab + n1, tt0.data(), n1 * sizeof(int), hipMemcpyHostToDevice, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            c->n_tiles = (int)n1 - 1;
+            c->tile_ntm = ntm;
+            c->tile_gbm = gbm;
+            c->tile_blocks = 0;
+            c->tile_ready = true;
+        }
     }
     c->prepared = true;
     return 0;
@@ -1103,6 +1172,71 @@ static int capture_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n, hipGra
     return 0;
 }
 
+
+// ---- one launch per call: bean_tile_svi.hpp
+template <int FAM, bool ACC>
+static int launch_svi_tile_t(bean_hip_ctx* c, hipStream_t stream, uint64_t step0, uint64_t slot0, uint64_t n_steps,
+                             bool prep_last) {
+    const DevArgs& d = c->d;
+    const size_t lds = svi_tile_lds(d.B, d.R, c->tile_ntm, c->tile_gbm);
+    if (c->tile_blocks == 0) {
+        int per_cu = 0, dev = 0, n_cu = 0;
+        HIP_OK(hipFuncSetAttribute((const void*)k_svi_tile<FAM, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_svi_tile<FAM, ACC>, kTileThreads, lds));
+        HIP_OK(hipGetDevice(&dev));
+        HIP_OK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (per_cu < 1) return fail("k_svi_tile does not fit on a compute unit (LDS " + std::to_string(lds) + " bytes)");
+        c->tile_blocks = per_cu * n_cu;
+        if (getenv("BEAN_HIP_VERBOSE"))
+            fprintf(stderr, "k_svi_tile: %d tiles (<= %d targets, %d guides), LDS %zu B, %d workgroups per CU x %d CUs\n",
+                    c->n_tiles, c->tile_ntm, c->tile_gbm, lds, per_cu, n_cu);
+    }
+    const int blocks = c->n_tiles < c->tile_blocks ? c->n_tiles : c->tile_blocks;
+    const int* tg0 = c->tile_tab;
+    const int* tt0 = c->tile_tab + (c->n_tiles + 1);
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
+    if (prof) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        hipExtLaunchKernelGGL((k_svi_tile<FAM, ACC>), dim3(blocks), dim3(kTileThreads), lds, stream, e0, e1, 0, d, (const DevArgs*)c->dargs_dev,
+                              tg0, tt0,
+                              c->n_tiles, c->tile_ntm, c->tile_gbm, (unsigned long long)step0, (unsigned long long)slot0,
+                              (int)n_steps, prep_last ? 1 : 0, (const float*)c->step_sizes);
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+        c->ev_steps.push_back(n_steps);
+    } else {
+        hipLaunchKernelGGL((k_svi_tile<FAM, ACC>), dim3(blocks), dim3(kTileThreads), lds, stream, d, (const DevArgs*)c->dargs_dev, tg0, tt0,
+                           c->n_tiles,
+                           c->tile_ntm, c->tile_gbm, (unsigned long long)step0, (unsigned long long)slot0, (int)n_steps,
+                           prep_last ? 1 : 0, (const float*)c->step_sizes);
+    }
+    return 0;
+}
+
+static int launch_svi_tile(bean_hip_ctx* c, hipStream_t stream, uint64_t step0, uint64_t n_steps) {
+    const DevArgs& d = c->d;
+    if (n_steps > c->step_sizes_cap) {
+        if (c->step_sizes) (void)hipFree(c->step_sizes);
+        c->step_sizes = nullptr;
+        c->step_sizes_cap = 0;
+        const uint64_t cap = n_steps < 256 ? 256 : n_steps;
+        HIP_OK(hipMalloc((void**)&c->step_sizes, cap * sizeof(float)));
+        c->step_sizes_cap = cap;
+    }
+    hipLaunchKernelGGL(k_step_sizes, dim3((unsigned)((n_steps + 255) / 256)), dim3(256), 0, stream, d,
+                       (unsigned long long)step0, (int)n_steps, c->step_sizes);
+    if (!c->dargs_dev) HIP_OK(hipMalloc((void**)&c->dargs_dev, sizeof(DevArgs)));
+    // (the kernel-argument copy and this one are the same bytes: c->d as it is now)
+    hipLaunchKernelGGL(k_put_args, dim3(1), dim3(64), 0, stream, d, c->dargs_dev);
+    if (d.family == kMixture) {
+        if (d.flags & kAcc) return launch_svi_tile_t<kMixture, true>(c, stream, step0, step0, n_steps, false);
+        return launch_svi_tile_t<kMixture, false>(c, stream, step0, step0, n_steps, false);
+    }
+    return launch_svi_tile_t<kNormal, false>(c, stream, step0, step0, n_steps, false);
+}
+
 extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
                                 int32_t graph_chunk, void* stream_) {
     if (!c) return fail("bean_hip_svi_run: null handle");
@@ -1114,7 +1248,10 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
     hipStream_t stream = (hipStream_t)stream_;
     if ((!c->graphs.empty() || !c->graphs_fused.empty()) && (c->graph_seed != seed)) drop_graph(c);
     c->d.seed = seed;
-    const bool use_graph = graph_chunk > 0 && stream != nullptr && !c->profile;
+    const bool tile_candidate = c->tile_svi && c->tile_ready && !c->profile_param && !c->d.eps_mu_in && !c->d.eps_sd_in &&
+                                !c->d.pi_in && !c->d.eps_noise_in && !c->d.eps_mu_out && !c->d.eps_sd_out &&
+                                !c->d.eps_noise_out && !(c->d.flags & kDumpPi);
+    const bool use_graph = graph_chunk > 0 && stream != nullptr && !c->profile && !tile_candidate;
     // one launch per step unless per-step noise is injected or dumped, or k_param itself is being timed
     const DevArgs& dd = c->d;
     const bool fused = c->fused_step && !c->profile_param && !dd.eps_mu_in && !dd.eps_sd_in && !dd.pi_in &&
@@ -1153,6 +1290,18 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
             }
             c->graph_seed = seed;
         }
+    }
+    // one launch for all the steps of the call (bean_tile_svi.hpp) unless per-step noise is injected or
+    // dumped, k_param is being timed, or the shape is not eligible
+    const bool tile = c->tile_svi && c->tile_ready && !c->profile_param && !dd.eps_mu_in && !dd.eps_sd_in && !dd.pi_in &&
+                      !dd.eps_noise_in && !dd.eps_mu_out && !dd.eps_sd_out && !dd.eps_noise_out && !(dd.flags & kDumpPi);
+    if (tile) {
+        launch_set_step(c, stream, first_step, first_step, n_steps);
+        launch_param<false, false, true>(c, stream);  // draws and tables of the first step
+        if (launch_svi_tile(c, stream, first_step, n_steps)) return -1;
+        launch_finalize(c, stream, first_step, n_steps, false);
+        HIP_OK(hipGetLastError());
+        return 0;
     }
     launch_set_step(c, stream, first_step, first_step, n_steps);
     launch_param<false, false, true>(c, stream);
@@ -1436,6 +1585,7 @@ extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
         return c->tiling_wide ? "k_guide_tiling_wide"
                               : (c->tiling_rep ? "k_guide_tiling_rep" : (c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling"));
     if (c && c->d.survival) return c->surv_wave ? "k_guide_survival_wave" : "k_guide_survival";
+    if (c && c->wave_guide && c->tile_svi && c->tile_ready) return "k_svi_tile";
     if (c && c->wave_guide) return c->wave2 ? (c->fused_step ? "k_step_wave2" : "k_guide_wave2") : "k_guide_wave";
     return "k_lik";
 }
@@ -1457,10 +1607,12 @@ extern "C" int bean_hip_get_profile(bean_hip_ctx* c, double* avg_ms, uint64_t* l
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
         total += ms;
-        ++n;
+        // a launch of k_svi_tile covers all the steps of its call: the average is per SVI step
+        n += (c->ev_steps.size() * 2 == c->ev.size()) ? c->ev_steps[i / 2] : 1;
     }
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->ev.clear();
+    c->ev_steps.clear();
     *avg_ms = n ? total / (double)n : 0.0;
     *launches = n;
     return 0;

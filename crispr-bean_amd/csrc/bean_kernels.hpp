@@ -3556,3 +3556,4 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
 #include "bean_step_v2.hpp"
 #include "bean_survival_v2.hpp"
 #include "bean_tiling_v2.hpp"
+#include "bean_tile_svi.hpp"

@@ -255,6 +255,10 @@ def test_cli_uniform_edit_fit_negctrl_on_a_screen_with_sample_covariates(tmp_pat
 
     scr = _screen_with_covariates(n_targets=60, seed=3)
     scr.guides["target_group"] = np.where(np.arange(len(scr.guides)) < 45, "NegCtrl", "Variant")
+    # a replicate x guide mask must name the regrouped (replicate, covariate) replicates, here as in the
+    # reference (data_class.py:165-177 asserts its columns against samples["_rc"].unique())
+    rc = [f"{rep}.{b}" for rep in ("r1", "r2", "r3") for b in ("0", "1")]
+    scr.uns["repguide_mask"] = pd.DataFrame(1, index=scr.guides.index, columns=rc)
     path = str(tmp_path / "cov_screen.h5ad")
     h5ad_io.write_screen(scr, path)
     out = str(tmp_path / "out")
