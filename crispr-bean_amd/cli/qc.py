@@ -3,7 +3,8 @@
 The reference executes a notebook through papermill and converts it to an HTML report; here the same
 masking logic runs as a function (``bean_amd.qc.qc_masks``) and the masked screen is written to
 ``--out-screen-path``; the per-sample metrics go to ``<out-report-prefix>.samples.csv`` instead of a
-rendered report."""
+rendered report.  Every flag of the reference's parser is honoured (missing-sample dummies, the ``edits``
+re-derivation window and its switches, reporter geometry)."""
 from __future__ import annotations
 
 import argparse
@@ -102,6 +103,12 @@ def main(args):
     elif "tiling" not in bdata.uns:
         raise ValueError("Ambiguous assignment if the screen is a tiling screen. Provide `--tiling=True` or "
                          "`tiling=False`.")
+    # bean/qc/utils.py:19-32: a variant screen of a base editor needs the target position column
+    base_change = bdata.uns.get("target_base_changes") or bdata.uns.get("target_base_change")
+    if not bdata.uns["tiling"] and base_change and args.target_pos_col not in bdata.guides.columns:
+        raise ValueError(f"Specified --target-pos-col `{args.target_pos_col}` does not exist in "
+                         f"ReporterScreen.guides.columns ({bdata.guides.columns}). Please check your input. "
+                         f"(--tiling {args.tiling}, ReporterScreen.tiling: {bdata.uns['tiling']})")
     out = qc_masks(
         bdata, replicate_col=rep, condition_col=args.condition_col,
         count_correlation_thres=args.count_correlation_thres, edit_rate_thres=args.edit_rate_thres,
@@ -109,6 +116,10 @@ def main(args):
         lfc_cond1=lfc[0], lfc_cond2=lfc[1], control_condition=args.control_condition,
         base_edit_data=not args.no_editing, remove_bad_replicates=args.remove_bad_replicates,
         edit_start_pos=args.edit_start_pos, edit_end_pos=args.edit_end_pos,
+        recalculate_edits=not args.dont_recalculate_edits, target_pos_col=args.target_pos_col,
+        rel_pos_is_reporter=args.rel_pos_is_reporter, reporter_length=args.reporter_length,
+        reporter_right_flank_length=args.reporter_right_flank_length,
+        ignore_missing_samples=args.ignore_missing_samples,
     )
     write_screen(out, args.out_screen_path)
     out.samples.to_csv(f"{args.out_report_prefix}.samples.csv")

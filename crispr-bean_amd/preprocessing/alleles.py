@@ -64,6 +64,19 @@ def nt_edit_abs(edit_str: str, uid: Optional[str] = None) -> Tuple[str, int]:
     return f"{pre}{int(pos)}:{ref}>{alt}", int(pos)
 
 
+def parse_nt_edit(edit_str: str) -> Optional[Tuple[int, str, str]]:
+    """``(rel_pos, ref_base, alt_base)`` of a nucleotide edit string as ``Edit.from_str`` reads it
+    (``Edit.py:36-67``: ``[uid!][chrom:]pos:rel_pos:strand:ref>alt``, bases as written, i.e. on the
+    guide's strand), or None for anything else (amino-acid edits)."""
+    s = edit_str.split("!")[1] if "!" in edit_str else edit_str
+    if not _NT_EDIT.fullmatch(s):
+        return None
+    parts = s.split(":")
+    rel_pos, change = parts[-3], parts[-1]
+    ref, alt = change.split(">")
+    return int(rel_pos), ref, alt
+
+
 def aa_edit_abs(edit_str: str) -> Tuple[str, int]:
     """``AminoAcidEdit.from_str(s).get_abs_edit()`` (``AminoAcidEdit.py:52-72``):
     ``[gene:]A<pos>:ref>alt``."""
