@@ -115,15 +115,23 @@ def sources():
 # they hold are compile-time constants.  libbean_hip.so holds 8 of each (the fast path);
 # libbean_hip_a16.so holds 16 of each and is loaded for the screens that need it.
 AMAX_BUILDS = (8, 16)
+# A third build of the same source, libbean_hip_ab.so (-DBEAN_AB_KERNELS): the default library plus every
+# superseded or opt-in kernel form (first wave form, split form, block forms, the one-launch step, the
+# tile-persistent loop) that the BEAN_HIP_* switches select - the A/B references of DESIGN.md and of the
+# bit-identity tests.  The product libraries contain the default kernels only.
+AB = "ab"
+ALL_BUILDS = (8, 16, AB)
 
 
-def lib_path(amax: int = 8) -> str:
+def lib_path(amax=8) -> str:
     if amax == 8:
         return LIB_PATH
+    if amax == AB:
+        return os.path.join(LIB_DIR, "libbean_hip_ab.so")
     return os.path.join(LIB_DIR, f"libbean_hip_a{amax}.so")
 
 
-def is_stale(amax: int = 8) -> bool:
+def is_stale(amax=8) -> bool:
     path = lib_path(amax)
     if not os.path.exists(path):
         return True
@@ -131,7 +139,7 @@ def is_stale(amax: int = 8) -> bool:
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build_library(force: bool = False, verbose: bool = False, amax: int = 8) -> str:
+def build_library(force: bool = False, verbose: bool = False, amax=8) -> str:
     """Compile ``csrc/bean_hip.hip`` for gfx950 into ``lib/libbean_hip[_a16].so``."""
     path = lib_path(amax)
     if not force and not is_stale(amax):
@@ -140,8 +148,8 @@ def build_library(force: bool = False, verbose: bool = False, amax: int = 8) -> 
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libbean_hip.so")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ([] if amax == 8 else [f"-DBEAN_AMAX={amax}", f"-DBEAN_BMAX={amax}"]) + [
-        os.path.join(CSRC, "bean_hip.hip"), "-o", path]
+    extra = [] if amax == 8 else (["-DBEAN_AB_KERNELS"] if amax == AB else [f"-DBEAN_AMAX={amax}", f"-DBEAN_BMAX={amax}"])
+    cmd = [hipcc] + HIPCC_FLAGS + extra + [os.path.join(CSRC, "bean_hip.hip"), "-o", path]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -154,7 +162,7 @@ _lib = None
 _libs = {}
 
 
-def load(amax: int = 8):
+def load(amax=8):
     """Load the in-tree library (the build that holds ``amax`` alleles per guide); raises if it has
     not been built."""
     global _lib

@@ -286,6 +286,17 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
 #if BEAN_AMAX > 8
         c->tiling_wave = true;  // this build has no block form
 #endif
+#ifndef BEAN_AB_KERNELS
+        // the product build holds the default kernels only; the superseded forms these switches select
+        // live in libbean_hip_ab.so (-DBEAN_AB_KERNELS; HipSVI(..., lib_variant="ab"))
+        const char* stp = getenv("BEAN_HIP_STEP");
+        if (!c->fused_guide || !c->wave2 || !c->surv_wave || !c->tiling_wave ||
+            (stp && (!strcmp(stp, "fused") || !strcmp(stp, "tile")))) {
+            delete c;
+            return fail("bean_hip_create: BEAN_HIP_GUIDE / _SURVIVAL / _TILING=block / _STEP select A/B reference kernels, "
+                        "which this build does not contain (build with -DBEAN_AB_KERNELS: libbean_hip_ab.so)");
+        }
+#endif
     }
     c->graph_seed = 0;
     c->comm = nullptr;
@@ -372,6 +383,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         const char* tc = getenv("BEAN_HIP_TOT_CONST");  // =0: the total terms are evaluated every step (A/B)
         d.tot_const = ((c->wave2 || c->surv_wave || c->tiling_wave || c->tiling_rep || c->tiling_wide) && !(tc && !strcmp(tc, "0"))) ? 1 : 0;
     }
+#ifdef BEAN_AB_KERNELS
     {
         // one launch per step (bean_step_v2.hpp), opt-in (BEAN_HIP_STEP=fused; measured slower than the
         // two-launch path, see the header): the variant sorting families of k_guide_wave2 whose
@@ -390,6 +402,10 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
                       (s->family == BEAN_FAMILY_MIXTURE_NORMAL || s->family == BEAN_FAMILY_NORMAL) &&
                       gb >= 1 && s->max_target_len <= gb && (sm && !strcmp(sm, "tile"));
     }
+#else
+    c->fused_step = false;
+    c->tile_svi = false;
+#endif
     const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G
                                            : (c->tiling_wide ? (uint64_t)tq_num(d.A) * Rr * G : 0);
     const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G
@@ -618,6 +634,7 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
         if (nt != c->d.tile_targets) drop_graph(c);
         c->d.tile_targets = nt;
     }
+#ifdef BEAN_AB_KERNELS
     c->tile_ready = false;
     if (c->tile_svi) {
         // tiles of whole targets with at most kTileThreads / R guides: built on the host from the target
@@ -659,6 +676,7 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
             c->tile_ready = true;
         }
     }
+#endif
     c->prepared = true;
     return 0;
 }
@@ -719,6 +737,7 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
 #undef BEAN_LAUNCH_PARAM
 }
 
+#ifdef BEAN_AB_KERNELS  // block forms and the split form: A/B references
 template <int B>
 static void launch_guide_b(bean_hip_ctx* c, hipStream_t stream, dim3 grid, dim3 block, size_t lds) {
     const DevArgs& d = c->d;
@@ -792,6 +811,8 @@ static void launch_guide_split(bean_hip_ctx* c, hipStream_t stream) {
     }
 }
 
+#endif  // BEAN_AB_KERNELS
+
 // sorting variant families, one wave per (guide tile, replicate), second form (bean_guide_v2.hpp)
 static void launch_guide_wave2(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
@@ -827,6 +848,7 @@ static void launch_guide_wave2(bean_hip_ctx* c, hipStream_t stream) {
     }
 }
 
+#ifdef BEAN_AB_KERNELS
 // sorting variant families, one wave per (guide tile, replicate)
 static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
@@ -861,6 +883,8 @@ static void launch_guide_wave(bean_hip_ctx* c, hipStream_t stream) {
         hipLaunchKernelGGL((k_guide_wave<kNormal, false>), grid, block, lds, stream, d);
     }
 }
+
+#endif  // BEAN_AB_KERNELS
 
 // tiling families, one wave per (guide tile, replicate), then the sum over replicates
 static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
@@ -926,6 +950,7 @@ static void launch_guide_tiling_rep(bean_hip_ctx* c, hipStream_t stream) {
 #undef BEAN_LAUNCH_TREP
 }
 
+#ifdef BEAN_AB_KERNELS
 // survival variant families, one wave per (guide tile, replicate) (bean_survival_v2.hpp)
 // One SVI step in one launch (bean_step_v2.hpp); `flip` alternates the step-counter buffers.
 static void launch_step_wave2(bean_hip_ctx* c, hipStream_t stream, int flip) {
@@ -960,6 +985,9 @@ static void launch_step_wave2(bean_hip_ctx* c, hipStream_t stream, int flip) {
     }
 }
 
+#endif  // BEAN_AB_KERNELS
+
+// survival variant families, one wave per (guide tile, replicate) (bean_survival_v2.hpp)
 static void launch_guide_survival_wave(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     const int tiles = (d.G + 63) / 64;
@@ -994,16 +1022,22 @@ static void launch_guide_survival_wave(bean_hip_ctx* c, hipStream_t stream) {
 
 static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
+#ifdef BEAN_AB_KERNELS
     if (!c->fused_guide && !d.survival && d.family != kMultiMixture) {
         launch_guide_split(c, stream);
         return;
     }
+#endif
     if (c->wave_guide) {
-        if (c->wave2) launch_guide_wave2(c, stream);
-        else launch_guide_wave(c, stream);
+#ifdef BEAN_AB_KERNELS
+        if (!c->wave2) {
+            launch_guide_wave(c, stream);
+            return;
+        }
+#endif
+        launch_guide_wave2(c, stream);
         return;
     }
-    const int nw = waves_per_block(c);
     if (c->surv_wave) {
         launch_guide_survival_wave(c, stream);
         return;
@@ -1044,6 +1078,8 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         }
         return;
     }
+#ifdef BEAN_AB_KERNELS  // block forms
+    const int nw = waves_per_block(c);
     const dim3 grid((d.G + 63) / 64), block(64 * nw);
     const size_t lds = ((size_t)nw * kNumPart * 64 + 16) * sizeof(double);
     const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
@@ -1082,6 +1118,7 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         c->ev.push_back(e0);
         c->ev.push_back(e1);
     }
+#endif
 }
 
 static void launch_finalize(bean_hip_ctx* c, hipStream_t stream, uint64_t first, uint64_t n, bool cur) {
@@ -1143,7 +1180,11 @@ static void enqueue_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n) {
 // Capture 2^k {k_param, guide} pairs into an executable graph.  On any failure the stream is taken
 // out of capture mode before returning.
 static void enqueue_fused(bean_hip_ctx* c, hipStream_t stream, uint64_t n, int flip0 = 0) {
+#ifdef BEAN_AB_KERNELS
     for (uint64_t i = 0; i < n; ++i) launch_step_wave2(c, stream, (int)((i + flip0) & 1));
+#else
+    (void)c; (void)stream; (void)n; (void)flip0;
+#endif
 }
 
 static int capture_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n, hipGraphExec_t* out, bool fused = false) {
@@ -1172,6 +1213,7 @@ static int capture_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n, hipGra
     return 0;
 }
 
+#ifdef BEAN_AB_KERNELS
 
 // ---- one launch per call: bean_tile_svi.hpp
 template <int FAM, bool ACC>
@@ -1237,6 +1279,8 @@ static int launch_svi_tile(bean_hip_ctx* c, hipStream_t stream, uint64_t step0, 
     return launch_svi_tile_t<kNormal, false>(c, stream, step0, step0, n_steps, false);
 }
 
+#endif  // BEAN_AB_KERNELS
+
 extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
                                 int32_t graph_chunk, void* stream_) {
     if (!c) return fail("bean_hip_svi_run: null handle");
@@ -1295,6 +1339,7 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
     // dumped, k_param is being timed, or the shape is not eligible
     const bool tile = c->tile_svi && c->tile_ready && !c->profile_param && !dd.eps_mu_in && !dd.eps_sd_in && !dd.pi_in &&
                       !dd.eps_noise_in && !dd.eps_mu_out && !dd.eps_sd_out && !dd.eps_noise_out && !(dd.flags & kDumpPi);
+#ifdef BEAN_AB_KERNELS
     if (tile) {
         launch_set_step(c, stream, first_step, first_step, n_steps);
         launch_param<false, false, true>(c, stream);  // draws and tables of the first step
@@ -1303,6 +1348,9 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
         HIP_OK(hipGetLastError());
         return 0;
     }
+#else
+    (void)tile;
+#endif
     launch_set_step(c, stream, first_step, first_step, n_steps);
     launch_param<false, false, true>(c, stream);
     if (fused) {

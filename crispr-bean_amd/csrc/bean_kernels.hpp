@@ -1617,6 +1617,13 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     }
 }
 
+#ifndef BEAN_WAVE_EU
+#define BEAN_WAVE_EU 4
+#endif
+#ifndef BEAN_GUIDE_WAVES_PER_EU
+#define BEAN_GUIDE_WAVES_PER_EU 2
+#endif
+#ifdef BEAN_AB_KERNELS  // superseded forms, kept as A/B references: libbean_hip_ab.so only (-DBEAN_AB_KERNELS)
 // --------------------------------------------------------------------- k_guide
 // Dirichlet-Multinomial observation term of one (rep, guide):
 // returns -log p and accumulates d(-log p)/d e[b] into ge.
@@ -2313,6 +2320,7 @@ void k_pi_terms(DevArgs c) {
     if (threadIdx.x == 0) loss_add(c, c.ctrB->slot, tot);
 }
 
+#endif  // BEAN_AB_KERNELS
 // ------------------------------------------------------------ survival kernels
 // survival NormalModel: sq[r] = sum_g q_0[r, g] * gq[r, g] (fixed order: strided partials, block tree)
 __global__ __launch_bounds__(1024) void k_sum_q(DevArgs c) {
@@ -2329,6 +2337,7 @@ __global__ __launch_bounds__(1024) void k_sum_q(DevArgs c) {
     if (threadIdx.x == 0) c.sq[r] = tot;
 }
 
+#ifdef BEAN_AB_KERNELS
 // Survival analogue of k_guide (survival_model.py:133-424): component "bin
 // probabilities" are exp(mu_a * t_b) with mu = [u_g, u_g + mu_t]; the control
 // Multinomial sees the alleles after selection up to the control timepoint; the
@@ -2562,6 +2571,7 @@ void k_guide_survival(DevArgs c) {
     }
 }
 
+#endif  // BEAN_AB_KERNELS
 // ------------------------------------------------------------------- k_allele
 // Tiling: per allele slot (g, a >= 1): mu_a = sum of its edits' mu, sigma_a =
 // l2 norm of their sd (model.py:618-622) as a CSR gather, then the bin
@@ -2645,7 +2655,7 @@ __global__ __launch_bounds__(256) void k_allele(DevArgs c) {
     }
 }
 
-#if BEAN_AMAX <= 8  // the block form is the A/B reference of the default build only
+#if defined(BEAN_AB_KERNELS) && BEAN_AMAX <= 8  // the block form: an A/B reference of the default allele count only
 // ------------------------------------------------------------- k_guide_tiling
 // MultiMixtureNormal per (rep, guide): A-component Dirichlet draw, mixture over
 // the guide's alleles, both DirMult terms, Multinomial on control allele counts,
@@ -3553,7 +3563,11 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
 }  // namespace bean
 
 #include "bean_guide_v2.hpp"
+#ifdef BEAN_AB_KERNELS  // opt-in steppers, both bit-identical to the default path and measured slower
 #include "bean_step_v2.hpp"
+#endif
 #include "bean_survival_v2.hpp"
 #include "bean_tiling_v2.hpp"
+#ifdef BEAN_AB_KERNELS
 #include "bean_tile_svi.hpp"
+#endif

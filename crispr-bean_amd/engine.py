@@ -62,6 +62,7 @@ class HipSVI:
         t0_totals: Optional[torch.Tensor] = None,
         loss_owner: bool = True,
         alpha_prior: float = 1.0,
+        lib_variant: Optional[str] = None,
     ):
         if family not in _lib.FAMILY:
             raise ValueError(f"unknown model family {family!r}")
@@ -78,6 +79,12 @@ class HipSVI:
         n_al = int(getattr(data, "n_max_alleles", 2)) if family == "MultiMixtureNormal" else 2
         if (8 < n_al <= 16) or data.n_condits > 8:
             amax = 16
+        if lib_variant is not None:
+            # "ab": libbean_hip_ab.so, the default kernels plus the superseded / opt-in forms the BEAN_HIP_*
+            # switches select (A/B measurements, bit-identity tests); 8 alleles / conditions only
+            if lib_variant != _lib.AB or amax != 8:
+                raise ValueError("lib_variant must be 'ab' (and the screen must fit the 8-allele / 8-condition build)")
+            amax = _lib.AB
         self.lib = _lib.load(amax)
         self.device = torch.device(device if device is not None else "cuda:0")
         self.family = family

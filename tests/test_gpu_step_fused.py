@@ -16,11 +16,12 @@ DEV = "cuda:0"
 def _fit(monkeypatch, mode, family, data, steps, eng_kw, chunks=None):
     from bean_amd import engine
 
-    if mode == "pair":
+    if mode == "pair":  # the product library
         monkeypatch.delenv("BEAN_HIP_STEP", raising=False)
-    else:
+        eng = engine.HipSVI(family, data.to(DEV), num_steps=steps, **eng_kw)
+    else:  # the opt-in kernel lives in the A/B library (libbean_hip_ab.so)
         monkeypatch.setenv("BEAN_HIP_STEP", "fused")
-    eng = engine.HipSVI(family, data.to(DEV), num_steps=steps, **eng_kw)
+        eng = engine.HipSVI(family, data.to(DEV), num_steps=steps, lib_variant="ab", **eng_kw)
     assert data.n_targets >= 64  # fewer targets: k_param's one-block-per-target mode, two launches
     assert eng.dominant_kernel == ("k_guide_wave2" if mode == "pair" else "k_step_wave2")
     for n in (chunks or [steps]):
@@ -82,8 +83,21 @@ def test_targets_longer_than_a_tile_take_the_pair_path(monkeypatch):
 
     monkeypatch.setenv("BEAN_HIP_STEP", "fused")
     data = make_sorting_variant_screen(6500, 2, seed=80, guides_per_target=65)
-    eng = engine.HipSVI("MixtureNormal", data.to(DEV), num_steps=10)
+    eng = engine.HipSVI("MixtureNormal", data.to(DEV), num_steps=10, lib_variant="ab")
     assert eng.dominant_kernel == "k_guide_wave2"
     eng.run(5)
     assert np.all(np.isfinite(eng.losses()))
     eng.close()
+
+
+def test_product_library_refuses_the_ab_switches(monkeypatch):
+    """libbean_hip.so holds the default kernels only: a switch that selects a superseded form is an error
+    that names the A/B library, not a silent fallback."""
+    from bean_amd import engine
+
+    data = make_sorting_variant_screen(1000, 2, seed=1)
+    for key, val in (("BEAN_HIP_STEP", "fused"), ("BEAN_HIP_STEP", "tile"), ("BEAN_HIP_GUIDE", "wave1")):
+        monkeypatch.setenv(key, val)
+        with pytest.raises(RuntimeError, match="libbean_hip_ab.so"):
+            engine.HipSVI("MixtureNormal", data.to(DEV), num_steps=10)
+        monkeypatch.delenv(key)

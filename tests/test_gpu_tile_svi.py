@@ -23,8 +23,8 @@ def _engine(family, data, pair, **kw):
         os.environ.pop("BEAN_HIP_STEP", None)
     else:
         os.environ["BEAN_HIP_STEP"] = "tile"
-    try:
-        eng = engine.HipSVI(family, data.to(DEV), num_steps=2000, **kw)
+    try:  # the tile kernel lives in the A/B library; the reference path is the product library
+        eng = engine.HipSVI(family, data.to(DEV), num_steps=2000, **({} if pair else {"lib_variant": "ab"}), **kw)
     finally:
         if old is None:
             os.environ.pop("BEAN_HIP_STEP", None)
@@ -98,7 +98,7 @@ def test_a_target_longer_than_a_tile_keeps_the_two_launch_path():
     data = make_sorting_variant_screen(600, 5, seed=2, guides_per_target=60)  # 60 guides > 256 / 5
     os.environ["BEAN_HIP_STEP"] = "tile"
     try:
-        eng = engine.HipSVI("MixtureNormal", data.to(DEV), num_steps=50)
+        eng = engine.HipSVI("MixtureNormal", data.to(DEV), num_steps=50, lib_variant="ab")
     finally:
         os.environ.pop("BEAN_HIP_STEP", None)
     assert eng.dominant_kernel == "k_guide_wave2"
