@@ -231,15 +231,19 @@ __device__ __forceinline__ double uniform_ld(const double* p, int i) {
 // Every wave / block adds its part of the step's loss with INTEGER atomics: the part is split exactly
 // into a multiple of 2^-10 and a remainder rounded to 2^-40, so the sum does not depend on the order
 // in which the parts arrive and the loss history is bitwise reproducible (a float64 atomicAdd is not).
-// Range |loss| < 2^52, resolution 2^-40.  One address would serialise the chip's ~4000 waves at ~12 ns
+// Range: |part| < 2^33 (kLossPartMax), |loss| < 2^52; resolution 2^-40.  One address would serialise the chip's ~4000 waves at ~12 ns
 // per atomic (tens of microseconds per launch - measured: it dominated the guide kernel), so a slot is
 // kLossSub accumulators in separate 64-byte lines and a part goes to the one its block id selects;
 // integer sums make the choice irrelevant for the result.  k_loss_finalize adds them up into the
 // double in loss_hist.
 constexpr int kLossWords = 8;   // int64 words per accumulator line: 2^-10 units, 2^-40 units, poison count
+// Largest part a wave / block may add: its 2^-10-unit word is < 2^43, so 2^20 parts (a 13 M (replicate, guide)
+// screen has that many waves) cannot wrap the int64 sum; a part beyond it - a diverging fit - poisons the slot
+// and the reported loss is NaN (the host halts the fit at the next report), instead of a finite wrong value.
+constexpr double kLossPartMax = 8589934592.0;  // 2^33
 constexpr int kLossSub = 64;    // accumulator lines per loss_hist slot
 __device__ __forceinline__ void fixed_add(long long* acc, double v) {
-    if (!(fabs(v) < 4.0e15)) {  // NaN / inf / out of range: poison the slot (k_loss_finalize reports NaN)
+    if (!(fabs(v) < kLossPartMax)) {  // NaN / inf / out of range: poison the slot (k_loss_finalize reports NaN)
         atomicAdd((unsigned long long*)acc + 2, 1ull);
         return;
     }
@@ -277,7 +281,7 @@ __device__ __forceinline__ void wave_loss_out(const DevArgs& c, unsigned long lo
         return;
     }
     long long* o = c.lpart + 3 * wave;
-    if (!(fabs(v) < 4.0e15)) {
+    if (!(fabs(v) < kLossPartMax)) {
         o[0] = 0;
         o[1] = 0;
         o[2] = 1;
@@ -1557,7 +1561,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 // this block's prior / entropy terms and its share of the guide kernel's loss parts in
                 // one set of integer atomics
                 long long a = lp3[0], b = lp3[1], d = lp3[2];
-                if (fabs(tot) < 4.0e15) {
+                if (fabs(tot) < kLossPartMax) {
                     const double hi = rint(tot * 1024.0);
                     a += (long long)hi;
                     b += (long long)rint((tot - hi * (1.0 / 1024.0)) * 1099511627776.0);

@@ -52,7 +52,7 @@ void k_step_wave2(DevArgs c, int flip) {
     if (lane == 0) {
         // this wave's part of the loss as the three integer words of fixed_add (see wave_loss_out)
         long long w0 = 0, w1 = 0, w2 = 1;
-        if (fabs(tot) < 4.0e15) {
+        if (fabs(tot) < kLossPartMax) {
             const double hi = rint(tot * 1024.0);
             w0 = (long long)hi;
             w1 = (long long)rint((tot - hi * (1.0 / 1024.0)) * 1099511627776.0);
@@ -287,7 +287,7 @@ void k_step_wave2(DevArgs c, int flip) {
                 d += w[u][2];
             }
         }
-        if (fabs(lsum) < 4.0e15) {
+        if (fabs(lsum) < kLossPartMax) {
             const double hi = rint(lsum * 1024.0);
             a += (long long)hi;
             b += (long long)rint((lsum - hi * (1.0 / 1024.0)) * 1099511627776.0);

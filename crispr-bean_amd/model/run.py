@@ -97,8 +97,9 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
     Returns ``(param_store, {"loss": [float] * num_steps, "params": {name: cpu
     tensor}})`` where ``param_store[name]`` and ``params[name]`` are the
     constrained values, exactly the structure the reference returns.
-    A non-finite loss raises ``ValueError`` after dumping the parameters to
-    ``tmp_result.pkl``, as the reference does on a ``ValueError`` inside the loop.
+    A non-finite loss halts the fit at the end of its report window (100 steps) and raises
+    ``ValueError`` after dumping the parameters to ``tmp_result.pkl``, as the reference does on a
+    ``ValueError`` inside the loop (there at the failing step itself).
 
     When ``torch.distributed`` is initialised with more than one rank the guides
     are sharded on target boundaries (``parallel.run_sharded``): every rank fits
@@ -142,9 +143,10 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
             while done < num_steps:
                 k = min(report_every, num_steps - done)
                 eng.run(k, seed=seed)
-                if verbose:
-                    torch.cuda.synchronize(eng.device)
-                    report(done, float(eng.loss_hist[done]))
+                # the reference halts at the failing step (run.py:375-390); here at the end of its report window
+                window = eng.loss_hist[done:done + k]
+                parallel.check_window_finite(window, done)
+                report(done, float(window[0]))
                 done += k
             losses = eng.losses()
             constrained = eng.constrained()

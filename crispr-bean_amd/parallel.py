@@ -118,6 +118,15 @@ class _Group:
         return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
 
 
+def check_window_finite(window: torch.Tensor, first_step: int) -> None:
+    """Raise ``FloatingPointError`` naming the first non-finite loss of a report window (one small
+    device-to-host read per window).  In a sharded fit the window is the all-reduced one, identical on
+    every rank: all ranks raise together, none is left waiting in a collective."""
+    bad = ~torch.isfinite(window)
+    if bool(bad.any()):
+        raise FloatingPointError(f"non-finite loss at iteration {first_step + int(torch.nonzero(bad)[0])}")
+
+
 PER_TARGET = ("mu_loc", "mu_scale", "sd_loc", "sd_scale")
 PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale", "q0", "initial_abundance")
 REPLICATED = ("mu_cov_loc", "mu_cov_scale")  # shared by every guide: identical on every rank
@@ -184,6 +193,11 @@ def run_sharded(
                 grp.all_reduce_sum(window)
         else:
             grp.all_reduce_sum(window)
+        try:
+            check_window_finite(window, done)
+        except FloatingPointError:
+            eng.steps_done = done + k
+            raise
         if on_report is not None:
             on_report(done, float(window[0]))
         done += k
