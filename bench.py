@@ -265,6 +265,15 @@ class Leg:
         if self.exchanged:
             x = self.eng.exchange_buffers()
             self.exchange = "per step: " + ", ".join(f"all-reduce {k} ({v.numel()} f64)" for k, v in x.items())
+            # RCCL ranks: the library steps with its own communicator (kernels + ncclAllReduce enqueued natively);
+            # gloo rehearsals keep the Python stepping loop
+            native = False
+            try:
+                native = self.eng.init_native_comm()
+            except Exception as exc:  # noqa: BLE001  (never lose the run over the faster path)
+                print(f"[bench] native RCCL stepping unavailable: {exc}", file=sys.stderr)
+            self.exchange += "; stepping: " + ("library-owned RCCL communicator, no host in the loop" if native
+                                               else "Python loop + torch.distributed.all_reduce")
 
     def run_steps(self, n):
         import torch

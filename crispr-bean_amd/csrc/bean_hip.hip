@@ -1042,7 +1042,7 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         launch_guide_survival_wave(c, stream);
         return;
     }
-    if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
+    if (d.family == kMultiMixture && !c->tiling_rep) {  // allele-level tables of this step's draw (k_guide_tiling_rep forms its own)
         const long n = (long)(d.A - 1) * d.G;
         hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
     }

@@ -2580,11 +2580,11 @@ void k_guide_survival(DevArgs c) {
 // Tiling: per allele slot (g, a >= 1): mu_a = sum of its edits' mu, sigma_a =
 // l2 norm of their sd (model.py:618-622) as a CSR gather, then the bin
 // probabilities and their derivatives.  Tables are laid out (B, A-1, G).
-__global__ __launch_bounds__(256) void k_allele(DevArgs c) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// One allele slot (g, a1): shared by k_allele (one thread per slot of the screen) and by the head of
+// k_guide_tiling_rep (the slots of the workgroup's own guides).
+__device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int g) {
     const int A1 = c.A - 1;
-    if (idx >= (long)A1 * c.G) return;
-    const int a1 = (int)(idx / c.G), g = (int)(idx % c.G);
+    const long idx = (long)a1 * c.G + g;
     const long slot = (long)g * A1 + a1;
     const bool valid = c.amask[(long)g * c.A + a1 + 1] != 0;
     if (c.survival) {
@@ -2657,6 +2657,13 @@ __global__ __launch_bounds__(256) void k_allele(DevArgs c) {
         c.tabPmu[o] = dmu;
         c.tabPy[o] = dsig;  // d/d sigma_a here (chain to y_e in k_param)
     }
+}
+
+__global__ __launch_bounds__(256) void k_allele(DevArgs c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int A1 = c.A - 1;
+    if (idx >= (long)A1 * c.G) return;
+    allele_slot_tables(c, (int)(idx / c.G), (int)(idx % c.G));
 }
 
 #if defined(BEAN_AB_KERNELS) && BEAN_AMAX <= 8  // the block form: an A/B reference of the default allele count only
