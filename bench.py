@@ -139,6 +139,24 @@ def cpu_baseline(family, data, loss_fn, loss_kw, init_fn, seconds_budget=20.0):
     }
 
 
+def kernel_resources(kernel_name, lds_dynamic):
+    """Register / scratch figures of the dominant kernel from the shipped code object's metadata
+    (scripts/kernel_resources.py), next to the dynamic LDS the library requests for it."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import kernel_resources as kr
+
+        recs = [r for r in kr.kernels(os.path.join(ROOT, "crispr-bean_amd", "lib", "libbean_hip.so"))
+                if r["kernel"] == "bean::" + kernel_name]
+        r = recs[0]
+        return {"kernel": kernel_name, "vgpr": r.get("vgpr_count"), "agpr": r.get("agpr_count"), "sgpr": r.get("sgpr_count"),
+                "vgpr_spills": r.get("vgpr_spill_count"), "scratch_bytes_per_lane": r.get("private_segment_fixed_size"),
+                "lds_static_bytes": r.get("group_segment_fixed_size"), "lds_dynamic_bytes": lds_dynamic,
+                "source": "code object notes of libbean_hip.so (scripts/kernel_resources.py)"}
+    except Exception as exc:  # noqa: BLE001  (llvm tools absent: the figures are a report, not a dependency)
+        return {"error": str(exc), "lds_dynamic_bytes": lds_dynamic}
+
+
 def _newest(pattern):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     return files[-1] if files else None
@@ -331,7 +349,7 @@ class Leg:
         prof.run(eng_steps, seed=101, graph_chunk=0)
         torch.cuda.synchronize(self.dev)
         k_ms, k_n = prof.get_profile()
-        out = (k_ms, k_n, prof.step_bytes, prof.dominant_kernel)
+        out = (k_ms, k_n, prof.step_bytes, prof.dominant_kernel, prof.dominant_lds_bytes, prof.dominant_kernel_variant)
         prof.close()
         return out
 
@@ -422,7 +440,7 @@ def main():
     weak = Leg(args, args.config, False, weak_guides, rank, world, dev, total)
     dt_weak = weak.timed(args.steps, args.warmup)
     losses = weak.eng.losses()
-    k_ms, k_n, step_bytes, kernel_name = weak.kernel_profile()
+    k_ms, k_n, step_bytes, kernel_name, lds_dyn, kernel_variant = weak.kernel_profile()
     strong_obj = None
     if want_strong:
         if same_leg:
@@ -495,6 +513,7 @@ def main():
                 "algorithmic_bytes_per_launch": step_bytes,
                 "kernel_ms": k_ms,
                 "kernel_launches_timed": k_n,
+                "kernel_resources": kernel_resources(kernel_variant, lds_dyn),
                 "measured_on": f"the weak leg's screen ({weak_guides} guides on this rank)",
             },
         }

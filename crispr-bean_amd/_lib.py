@@ -99,6 +99,8 @@ SYMBOLS = [
     ("bean_hip_svi_run_exchanged", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_int32, c_void_p]),
     ("bean_hip_step_bytes", c_uint64, [c_void_p]),
     ("bean_hip_dominant_kernel", c_char_p, [c_void_p]),
+    ("bean_hip_dominant_lds_bytes", c_uint64, [c_void_p]),
+    ("bean_hip_dominant_kernel_variant", c_char_p, [c_void_p]),
     ("bean_hip_set_profile", c_int32, [c_void_p, c_int32]),
     ("bean_hip_get_profile", c_int32, [c_void_p, POINTER(c_double), POINTER(c_uint64)]),
     ("bean_hip_test_special", c_int32,

@@ -1042,7 +1042,7 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         launch_guide_survival_wave(c, stream);
         return;
     }
-    if (d.family == kMultiMixture && !c->tiling_rep) {  // allele-level tables of this step's draw (k_guide_tiling_rep forms its own)
+    if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
         const long n = (long)(d.A - 1) * d.G;
         hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
     }
@@ -1636,6 +1636,35 @@ extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
     if (c && c->wave_guide && c->tile_svi && c->tile_ready) return "k_svi_tile";
     if (c && c->wave_guide) return c->wave2 ? (c->fused_step ? "k_step_wave2" : "k_guide_wave2") : "k_guide_wave";
     return "k_lik";
+}
+
+extern "C" const char* bean_hip_dominant_kernel_variant(const bean_hip_ctx* c) {
+    static thread_local std::string name;
+    if (!c) return "";
+    const DevArgs& d = c->d;
+    const char* acc = (d.flags & kAcc) ? "true" : "false";
+    const char* surv = d.survival ? "true" : "false";
+    const std::string base = bean_hip_dominant_kernel(c);
+    if (d.family == kMultiMixture) name = base + "<" + acc + ", " + surv + ">";
+    else if (base == "k_guide_wave2" || base == "k_guide_survival_wave" || base == "k_step_wave2" || base == "k_svi_tile" ||
+             base == "k_guide_wave")
+        name = base + "<" + (d.family == kMixture ? "2" : "0") + ", " + (d.family == kMixture ? acc : "false") + ">";
+    else name = base;
+    return name.c_str();
+}
+
+extern "C" uint64_t bean_hip_dominant_lds_bytes(const bean_hip_ctx* c) {
+    if (!c) return 0;
+    const DevArgs& d = c->d;
+    const bool acc = (d.flags & kAcc) != 0;
+    if (d.family == kMultiMixture) {
+        if (c->tiling_wide) return 0;
+        const uint64_t nt = c->tiling_rep ? 64ull * c->tiling_rep_w : 64ull;
+        return (uint64_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * nt * sizeof(double) + (uint64_t)2 * d.B * nt * sizeof(float);
+    }
+    if (d.survival) return c->surv_wave ? guide_survival_wave_lds(d.B) : 0;
+    if (c->wave_guide && c->wave2) return guide_wave2_lds(d.B, d.tile_targets);
+    return 0;
 }
 
 extern "C" int bean_hip_set_profile(bean_hip_ctx* c, int32_t enable) {

@@ -19,7 +19,9 @@
 //     concentrations (alpha_a, c_q a: 32 VGPRs) are needed by the sampler at the start and by the
 //     Dirichlet terms at the end, and are RECOMPUTED there from alpha_pi instead of held across the
 //     likelihoods; a row is reduced and stored where it is formed instead of collected in an array.
-//   * the allele tables (k_allele) of the workgroup's guides are formed at the head of the kernel.
+//   * (forming the allele tables - k_allele, 17 us - at the head of this kernel was measured too: the step
+//     takes the same 183 us, the kernel 160 instead of 148 + 17, and its traffic then includes the 42 MB
+//     table round trip; k_allele stays a launch of its own.)
 //   * why not simply one wave = 12 guides x 5 replicates: 60 of 64 lanes, i.e. 4 167 waves for 50k guides
 //     against the chip's 4 096 wave slots (256 CUs x 16): a second round of 71 waves, measured + 50 %
 //     (205 us against 137).  The launch must stay inside one round at this size, so lanes cannot idle.
@@ -92,18 +94,6 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
         }
     };
 
-    // ---- the allele tables of this workgroup's guides (k_allele's work, which was a launch of its own:
-    // 17 us at config 3): slot q = a1 * (guides of the workgroup) + guide, so that neighbouring threads write
-    // neighbouring table entries; the tables are read back below by the threads of the same guides only
-    {
-        const long gfirst = (long)blockIdx.x * Gw;
-        const int ngb = (int)((long)G - gfirst < Gw ? (long)G - gfirst : Gw);
-        for (int q = lane; q < ngb * A1; q += NT) {
-            const int a1 = q / ngb;
-            allele_slot_tables(c, a1, (int)gfirst + (q - a1 * ngb));
-        }
-        __syncthreads();  // (release / acquire at workgroup scope: the table stores are visible to the loads below)
-    }
     // counts of both likelihoods: one batch of loads, then LDS
     {
         float xv[2][kBMax];

@@ -624,6 +624,16 @@ class HipSVI:
     def dominant_kernel(self) -> str:
         return self.lib.bean_hip_dominant_kernel(self._h).decode()
 
+    @property
+    def dominant_kernel_variant(self) -> str:
+        """The template instantiation launched for this shape, as spelt in the code object."""
+        return self.lib.bean_hip_dominant_kernel_variant(self._h).decode()
+
+    @property
+    def dominant_lds_bytes(self) -> int:
+        """Dynamic LDS per workgroup the library requests for the dominant kernel at this shape."""
+        return int(self.lib.bean_hip_dominant_lds_bytes(self._h))
+
     def constrained(self) -> Dict[str, torch.Tensor]:
         """Constrained parameter values, as ``pyro.get_param_store()[name]``."""
         torch.cuda.synchronize(self.device)

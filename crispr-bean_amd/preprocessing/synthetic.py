@@ -198,6 +198,7 @@ def make_sorting_tiling_screen(
     with_accessibility: bool = False,
     edits_per_guide: float = 0.6,
     mask_fraction: float = 0.0,
+    alleles_mean: float = 3.0,
 ) -> ScreenTensors:
     """Tiling sorting screen (BASELINE config 3): every guide produces up to
     ``n_max_alleles - 1`` edited alleles, each a set of 1-3 edits drawn from a
@@ -216,7 +217,7 @@ def make_sorting_tiling_screen(
     E = max(int(G * edits_per_guide) + 10, 12)
     mu_e = np.where(rng.random(E) < 0.1, rng.normal(0.0, 1.0, E), 0.0)
     sd_e = np.ones(E)
-    n_al = np.minimum(1 + rng.poisson(3.0, G), A1)
+    n_al = np.minimum(1 + rng.poisson(alleles_mean, G), A1)  # alleles_mean >> 3: an unfiltered allele table
     base = np.minimum((np.arange(G) * (E - 10) / max(G, 1)).astype(np.int64), E - 10)
     ptr = np.zeros(G * A1 + 1, dtype=np.int64)
     idx = []
@@ -228,7 +229,7 @@ def make_sorting_tiling_screen(
         seen = set()
         k = 0
         for _ in range(int(n_al[g])):
-            ne = int(rng.integers(1, 4))
+            ne = int(rng.integers(1, 4 if alleles_mean <= 10 else 5))
             es = tuple(sorted(base[g] + rng.choice(10, size=ne, replace=False)))
             if es in seen:
                 continue

@@ -293,6 +293,13 @@ int bean_hip_svi_run_exchanged(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_
  * the name of the dominant kernel. */
 uint64_t bean_hip_step_bytes(const bean_hip_ctx* ctx);
 const char* bean_hip_dominant_kernel(const bean_hip_ctx* ctx);
+/* Dynamic LDS (bytes per workgroup) the library requests when it launches that kernel for this shape -
+ * the figure that, with the code object's register counts, decides how many waves a CU holds (profilers
+ * report the static segment only). */
+uint64_t bean_hip_dominant_lds_bytes(const bean_hip_ctx* ctx);
+/* ... and the template instantiation that is launched for this shape, as it is spelt in the code object
+ * (e.g. "k_guide_wave2<2, false>"), to look its register counts up there. */
+const char* bean_hip_dominant_kernel_variant(const bean_hip_ctx* ctx);
 
 /* Time (ms, HIP events on `stream`) of the dominant kernel averaged over the
  * launches issued since the previous call; enable with profile != 0 in

@@ -25,6 +25,35 @@ for f in glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recursiv
     keep = [rows[0]] + [r for r in rows[1:] if "bean::" in r[0]]
     with open(f"profiles/{tag}_kernel_stats{suf}.csv", "w", newline="") as out:
         csv.writer(out).writerows(keep)
+# register / scratch / LDS columns from the code object (what occupancy is decided by), not from the profiler's
+# VGPR_Count / LDS_Block_Size (granulated allocation of one register file; static LDS segment only)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+try:
+    import kernel_resources as _kr
+
+    _lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "crispr-bean_amd", "lib", "libbean_hip.so")
+    RES = {r["kernel"]: r for r in _kr.kernels(_lib)}
+except Exception as exc:  # noqa: BLE001
+    print("code-object notes unavailable:", exc)
+    RES = {}
+LDS_DYN = None
+try:
+    bj = json.loads(open(os.path.join(root, "bench_kt.json")).read().strip().splitlines()[-1])
+    LDS_DYN = (bj["roofline"]["kernel"], bj["roofline"].get("kernel_resources", {}).get("lds_dynamic_bytes"))
+except Exception:  # noqa: BLE001
+    pass
+
+
+def resources(k):
+    r = RES.get(k)
+    if not r:
+        return ""
+    dyn = f" + {LDS_DYN[1]} B dynamic (requested by the library)" if LDS_DYN and LDS_DYN[1] is not None and ("bean::" + LDS_DYN[0]) in k else ""
+    return (f"code object: vgpr {r.get('vgpr_count')} agpr {r.get('agpr_count')} sgpr {r.get('sgpr_count')} "
+            f"vgpr_spills {r.get('vgpr_spill_count')} scratch {r.get('private_segment_fixed_size')} B/lane "
+            f"lds {r.get('group_segment_fixed_size')} B static{dyn}")
+
+
 lines, traffic, calib = [], {}, {}
 dominant = None
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
@@ -40,8 +69,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
                        row["LDS_Block_Size"], row["Workgroup_Size"], row["Grid_Size"])
         lines.append(f"== {sub}: mean per dispatch")
         for k, cs in sorted(agg.items()):
-            lines.append(f"{k}  [vgpr {meta[k][0]} agpr {meta[k][1]} sgpr {meta[k][2]} scratch {meta[k][3]} "
-                         f"lds {meta[k][4]} wg {meta[k][5]} grid {meta[k][6]}]")
+            lines.append(f"{k}  [{resources(k) or 'code object: n/a'}; wg {meta[k][5]} grid {meta[k][6]}]")
             for c, v in sorted(cs.items()):
                 lines.append(f"    {c:24s} n={len(v):5d} mean={sum(v) / len(v):.6g}")
                 if "k_guide" in k and c in ("FETCH_SIZE", "WRITE_SIZE"):

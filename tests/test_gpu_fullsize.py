@@ -33,6 +33,9 @@ def engine():
     return eng
 
 
+ELEM_RTOL, ELEM_ATOL = 1e-5, 1e-7  # per-element gradient check of the float64-mode comparison
+
+
 def _compare_full(engine, family, data, loss_fn, oracle_kw=None, eng_kw=None, mask_key=None, modes=("f64", "ref"),
                   ref_tol=(1e-6, 2e-5), loose=()):
     oracle_kw, eng_kw = oracle_kw or {}, eng_kw or {}
@@ -64,6 +67,14 @@ def _compare_full(engine, family, data, loss_fn, oracle_kw=None, eng_kw=None, ma
             # oracle's own mixed-dtype and float64 evaluations differ by 1.8e-3 there
             tol = 5e-3 if (k in loose and mode == "ref") else tg
             assert err <= tol * (ref.abs().max().item() + 1e-30), (mode, k, err, ref.abs().max().item())
+            if mode == "f64":
+                # and element by element (a bound relative to the LARGEST entry lets a small gradient be off
+                # by a large factor): the kernels emit float32 gradients, so rtol is a few float32 ulps and
+                # atol covers entries that are small by cancellation of terms of the tensor's typical size
+                got = g.cpu().double().reshape(-1)
+                bound = ELEM_RTOL * ref.abs() + ELEM_ATOL * ref.abs().max()
+                worst = ((got - ref).abs() - bound).max().item()
+                assert worst <= 0.0, (mode, k, "per-element", worst, ref.abs().max().item())
     eng.close()
     return loss
 
