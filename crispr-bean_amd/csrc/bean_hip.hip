@@ -457,6 +457,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (n_ctr) {
         d.tile_ctr = (int*)w;
         d.bnd_ctr = d.tile_ctr + (n_ctr - 3 * B - 2);
+        d.n_arrival_ctr = (int)(2 * (n_ctr - 3 * B - 2));  // ints: two per double of this region
         w += n_ctr - 3 * B - 2;
         d.ue_z = w; w += 2 * B;
         d.ue_idx = (int*)w; w += B + 2;  // 2 B + 1 ints

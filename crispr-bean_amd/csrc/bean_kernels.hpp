@@ -149,6 +149,7 @@ struct DevArgs {
     // sum_b d alpha_b = 0.  A (replicate, guide) with a floored bin adds the difference to that constant.
     int tot_const;
     int *tile_ctr, *bnd_ctr;           // fused step kernel: arrivals per 64-guide tile / per tile boundary
+    int n_arrival_ctr;                 // ... their number (tile_ctr[0 .. n) covers both arrays; k_set_step zeroes them)
     // distinct finite bin edges (k_prepare): ue_z[n] their z values, n in ue_idx[2 B]; ue_idx[b] /
     // ue_idx[B + b]: the upper / lower edge of bin b in that list, -1 where the edge is infinite.  The
     // four sort bins + bulk of a standard screen have 10 edges, 4 of them distinct and finite.
@@ -3509,6 +3510,11 @@ __global__ __launch_bounds__(256) void k_set_step(DevArgs c, unsigned long long 
         c.loss_acc[slot * kLossSub * kLossWords + i] = 0;
         if (i < n) c.loss_hist[slot + i] = 0.0;
     }
+    // the arrival counters of the fused step kernel / the q0 totals return to zero by themselves when a launch
+    // completes; an aborted capture or a failed launch would leave them non-zero for every later call
+    if (c.tile_ctr)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n_arrival_ctr; i += gridDim.x * blockDim.x) c.tile_ctr[i] = 0;
+    if (c.q0_ctr && blockIdx.x == 0 && threadIdx.x == 1) *c.q0_ctr = 0;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     StepCtr s;
     s.step = step;
