@@ -436,6 +436,11 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
             xs[(0 * B + bb) * 64 + lane] = xv[0][b];
             xs[(1 * B + bb) * 64 + lane] = xv[1][b];
         }
+        for (int b = kBMax; b < B; ++b) {  // more conditions than the register batch holds (B <= kBCap)
+            const long xo = ((long)r * B + b) * G + gc;
+            xs[(0 * B + b) * 64 + lane] = c.X[xo];
+            xs[(1 * B + b) * 64 + lane] = use_bc ? c.Xbc[xo] : 0.f;
+        }
 #pragma unroll
         for (int q = 0; q < kTabLoads; ++q)
             if (wbv[q] >= 0) tabs[wbv[q] * ntm + j] = tv[q];
@@ -450,9 +455,8 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
         {
             const int kq = lane >> 3, bq = lane & 7;
             if (kq < 4 && bq < B) cst[kq * B + bq] = cv;
-            if (B > 8) {  // the 16-condition build: bins 8 .. B - 1
-                const int b2 = 8 + bq;
-                if (kq < 4 && b2 < B) {
+            for (int b2 = 8 + bq; b2 < B; b2 += 8) {  // bins 8 .. B - 1
+                if (kq < 4) {
                     const double* src = kq == 0 ? c.sf + r * B : (kq == 1 ? (use_bc ? c.sf_bc : c.sf) + r * B
                                                                           : (kq == 2 ? c.smask + r * B : c.P0));
                     cst[kq * B + b2] = (MIX || kq != 3) ? src[b2] : 0.0;

@@ -240,9 +240,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         return fail("bean_hip_create: unknown family");
     if (s->n_reps < 1 || s->n_guides < 1 || s->n_targets < 1)
         return fail("bean_hip_create: R, G, T must be >= 1");
-    if (s->n_condits < 1 || s->n_condits > kBMax)
-        return fail("bean_hip_create: n_condits must be in [1, " + std::to_string(kBMax) +
-                    "] (libbean_hip.so holds 8 conditions, libbean_hip_a16.so 16)");
+    if (s->n_condits < 1 || s->n_condits > kBCap)
+        return fail("bean_hip_create: n_condits must be in [1, " + std::to_string(kBCap) +
+                    "] (libbean_hip.so holds 8 conditions, libbean_hip_a16.so 32)");
     if (s->family == BEAN_FAMILY_MIXTURE_NORMAL && s->n_max_alleles != 2)
         return fail("bean_hip_create: MixtureNormal requires n_max_alleles == 2");
     if (is_tiling(*s)) {
@@ -376,6 +376,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         // BEAN_HIP_TILING_W (1, 2 or 4; experiments only) overrides the number of waves per workgroup
         const int w_env = getenv("BEAN_HIP_TILING_W") ? atoi(getenv("BEAN_HIP_TILING_W")) : 0;
         c->tiling_rep_w = (w_env == 1 || w_env == 2 || w_env == 4) ? w_env : tiling_rep_waves(s->n_reps);
+        if (s->n_condits > 16) c->tiling_rep_w = 1;  // LDS: (3 B + ...) x 64 W doubles per workgroup
     }
     d.wide_alleles = c->tiling_wide ? 1 : 0;
     d.trow_summed = (c->tiling_wave || c->tiling_rep) ? 1 : 0;
@@ -634,6 +635,28 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
         if (nt < 1 || nt > 64) return fail("bean_hip_prepare: guides are not sorted by target (BEAN_BUF_GUIDE_TO_TARGET)");
         if (nt != c->d.tile_targets) drop_graph(c);
         c->d.tile_targets = nt;
+    }
+    {
+        // more than 64 KB of dynamic LDS per workgroup (many conditions): the kernel has to be told
+        const DevArgs& d = c->d;
+        const bool acc = (d.flags & kAcc) != 0;
+        size_t lds = 0;
+        const void* fn = nullptr;
+        if (c->wave_guide && c->wave2) {
+            lds = guide_wave2_lds(d.B, d.tile_targets);
+            fn = d.family == kMixture ? (acc ? (const void*)k_guide_wave2<kMixture, true> : (const void*)k_guide_wave2<kMixture, false>)
+                                      : (const void*)k_guide_wave2<kNormal, false>;
+        } else if (c->tiling_rep || c->tiling_wave) {
+            const size_t nt = c->tiling_rep ? 64u * c->tiling_rep_w : 64u;
+            lds = (size_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * nt * sizeof(double) + (size_t)2 * d.B * nt * sizeof(float);
+            if (c->tiling_rep)
+                fn = d.survival ? (acc ? (const void*)k_guide_tiling_rep<true, true> : (const void*)k_guide_tiling_rep<false, true>)
+                                : (acc ? (const void*)k_guide_tiling_rep<true, false> : (const void*)k_guide_tiling_rep<false, false>);
+            else
+                fn = d.survival ? (acc ? (const void*)k_guide_tiling_wave<true, true> : (const void*)k_guide_tiling_wave<false, true>)
+                                : (acc ? (const void*)k_guide_tiling_wave<true, false> : (const void*)k_guide_tiling_wave<false, false>);
+        }
+        if (fn && lds > 65536) HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
 #ifdef BEAN_AB_KERNELS
     c->tile_ready = false;

@@ -217,7 +217,11 @@ constexpr int kWaveMisc = 6;  // k_guide_wave: per-guide values staged in LDS (c
 #ifndef BEAN_BMAX
 #define BEAN_BMAX 8
 #endif
-constexpr int kBMax = BEAN_BMAX;  // n_condits <= kBMax (bean_hip_create): 8 in libbean_hip.so, 16 in libbean_hip_a16.so
+constexpr int kBMax = BEAN_BMAX;  // conditions whose counts a wave loads in one register batch: 8 in libbean_hip.so, 16 in libbean_hip_a16.so
+// n_condits <= kBCap (bean_hip_create).  The default build stays at its batch (the fast path); the 16-condition
+// build stages further conditions one by one (every per-condition value is a thread-private LDS column and the
+// loops over conditions are rolled), up to what 64 KB of LDS per wave hold.
+constexpr int kBCap = BEAN_BMAX <= 8 ? 8 : 32;
 enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2 * kAMax,
              kTGsig = 2 + 2 * kAMax + (kAMax - 1), kTNumPart = 2 + 2 * kAMax + 2 * (kAMax - 1) };
 
@@ -3046,6 +3050,11 @@ void k_guide_tiling_wave(DevArgs c) {
                     const int bb = b < B ? b : B - 1;
                     xs[(0 * B + bb) * 64] = xv[0][b];
                     xs[(1 * B + bb) * 64] = xv[1][b];
+                }
+                for (int b = kBMax; b < B; ++b) {  // more conditions than the register batch holds (B <= kBCap)
+                    const long xo = ((long)r * B + b) * G + g;
+                    xs[(0 * B + b) * 64] = c.X[xo];
+                    xs[(1 * B + b) * 64] = use_bc ? c.Xbc[xo] : 0.f;
                 }
             }
             // ---- concentrations of the guide's Dirichlet

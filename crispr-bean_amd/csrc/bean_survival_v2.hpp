@@ -100,12 +100,16 @@ void k_guide_survival_wave(DevArgs c) {
             xs[(0 * B + bb) * 64 + lane] = xv[0][b];
             xs[(1 * B + bb) * 64 + lane] = xv[1][b];
         }
+        for (int b = kBMax; b < B; ++b) {  // more timepoints than the register batch holds (B <= kBCap)
+            const long xo = ((long)r * B + b) * G + gc;
+            xs[(0 * B + b) * 64 + lane] = c.X[xo];
+            xs[(1 * B + b) * 64 + lane] = use_bc ? c.Xbc[xo] : 0.f;
+        }
         {
             const int kq = lane >> 3, bq = lane & 7;
             if (kq < 4 && bq < B) cst[kq * B + bq] = cv;
-            if (B > 8) {  // the 16-condition build: timepoints 8 .. B - 1
-                const int b2 = 8 + bq;
-                if (kq < 4 && b2 < B) {
+            for (int b2 = 8 + bq; b2 < B; b2 += 8) {  // timepoints 8 .. B - 1
+                if (kq < 4) {
                     const double* src = kq == 0 ? c.sf + r * B : (kq == 1 ? (use_bc ? c.sf_bc : c.sf) + r * B
                                                                           : (kq == 2 ? c.smask + r * B : c.time));
                     cst[kq * B + b2] = src[b2];

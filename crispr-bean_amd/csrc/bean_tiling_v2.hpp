@@ -109,6 +109,11 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
             xs[(0 * B + bb) * NT] = xv[0][b];
             xs[(1 * B + bb) * NT] = xv[1][b];
         }
+        for (int b = kBMax; b < B; ++b) {  // more conditions than the register batch holds (B <= kBCap)
+            const long xo = ((long)r * B + b) * G + g;
+            xs[(0 * B + b) * NT] = c.X[xo];
+            xs[(1 * B + b) * NT] = use_bc ? c.Xbc[xo] : 0.f;
+        }
     }
     const double pa0 = c.pi_a0[g];
     // ---- draw: the concentrations of the guide's Dirichlet live only until the draw is done

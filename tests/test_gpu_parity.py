@@ -175,7 +175,7 @@ def test_ragged_shapes(engine, n_guides, n_reps):
     _compare(engine, "MixtureNormal", data, {})
 
 
-@pytest.mark.parametrize("n_bins", [1, 2, 3, 5, 7, 8, 11, 15])  # > 7 bins (+ bulk): the 16-condition build
+@pytest.mark.parametrize("n_bins", [1, 2, 3, 5, 7, 8, 11, 15, 19, 31])  # > 7 bins (+ bulk): the 16-condition build, which stages conditions 17 ... 32 one by one
 def test_bin_counts(engine, n_bins):
     edges = np.linspace(0, 1, n_bins + 1)
     bins = tuple((float(edges[i]), float(edges[i + 1])) for i in range(n_bins))
@@ -425,6 +425,10 @@ def _compare_tiling(engine, data, kw, seed=7, step=2):
     (dict(n_guides=120, n_reps=2, n_max_alleles=4,
           bins=tuple((i / 10, (i + 1) / 10) for i in range(10))), {}),  # 10 bins + bulk
     (dict(n_guides=100, n_reps=3, n_max_alleles=16, with_accessibility=True), dict(scale_by_accessibility=True)),
+    (dict(n_guides=80, n_reps=2, n_max_alleles=4,
+          bins=tuple((i / 20, (i + 1) / 20) for i in range(20))), {}),  # 20 bins + bulk (> 16 conditions)
+    (dict(n_guides=70, n_reps=2, n_max_alleles=6, with_accessibility=True,
+          bins=tuple((i / 31, (i + 1) / 31) for i in range(31))), dict(scale_by_accessibility=True)),  # 32 conditions, > 64 KB LDS
 ])
 def test_tiling_elbo_and_gradients_match_oracle(engine, gen_kw, kw):
     data = make_sorting_tiling_screen(seed=4, **gen_kw)
@@ -583,6 +587,7 @@ def _compare_survival(engine, family, data, kw, seed=7, step=2):
     (dict(n_guides=300, n_reps=2), dict(mu_negctrl=(0.05, 0.2))),
     (dict(n_guides=65, n_reps=1, times=(0.0, 2.0, 4.0, 6.0, 8.0, 10.0, 12.0, 14.0)), {}),
     (dict(n_guides=120, n_reps=2, times=tuple(float(t) for t in range(0, 22, 2))), {}),  # 11 timepoints
+    (dict(n_guides=90, n_reps=2, times=tuple(float(t) for t in range(0, 23))), {}),  # 23 timepoints (> 16)
 ])
 def test_survival_mixture_matches_oracle(engine, gen_kw, kw):
     data = make_survival_variant_screen(seed=4, **gen_kw)
