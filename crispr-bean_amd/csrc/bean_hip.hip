@@ -317,6 +317,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.A = s->n_max_alleles; d.C = s->n_ctrl; d.E = s->n_edits;
     d.family = s->family; d.flags = s->flags; d.mask_thres = s->mask_thres;
     d.wide_targets = (!is_tiling(*s) && (s->n_targets < 64 || s->max_target_len > 256)) ? 1 : 0;
+    d.lpt = (is_survival(*s) && !is_tiling(*s)) ? kLanesPerTargetSurv : kLanesPerTarget;
     d.g_off = s->guide_offset; d.t_off = s->target_offset;
     d.G_tot = s->n_guides_total > 0 ? s->n_guides_total : s->n_guides;
     d.sd_prior_scale = s->sd_prior_scale; d.lr0 = s->initial_lr; d.log_lrd = log(s->lrd);
@@ -340,15 +341,13 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->sq_ws = nullptr;
     c->cov_sum_ws = nullptr;
     const uint64_t Rr = d.R;
-    // guide blocks of k_param: kParamBlock guides each; in the survival families with a
-    // Dirichlet-over-all-guides site kParamBlock / q0_npar, the other lanes join for the site's gamma
-    // draws (one lane group per replicate pair, at most 4 groups: see q0_draws_and_totals)
-    {
-        const int npairs = (s->n_reps + 1) / 2;
-        d.q0_npar = (surv_mix || surv_norm) ? (npairs >= 4 ? 4 : (npairs >= 2 ? 2 : 1)) : 1;
-        d.q0_gpb = kParamBlock / d.q0_npar;
-    }
-    const uint64_t n_gblk = (G + d.q0_gpb - 1) / d.q0_gpb;
+    // guide blocks of k_param: kParamBlock guides each.  The survival families with a
+    // Dirichlet-over-all-guides site have q0 blocks as well (after the alpha_pi blocks of MixtureNormal),
+    // kParamBlock guides each: parameter update, gamma draws and normalisers of that site
+    // (q0_draws_and_totals)
+    d.q0_blocks = (surv_mix || surv_norm) ? 1 : 0;
+    d.q0_blk0 = surv_mix ? (int)((G + kParamBlock - 1) / kParamBlock) : 0;
+    const uint64_t n_gblk = (G + kParamBlock - 1) / kParamBlock;
     d.n_gamma_blocks = (int)n_gblk;
     const uint64_t n_surv = (surv_mix ? 2 * G + Rr * G + n_gblk * (Rr + 1) + (Rr + 1) : 0) +
                             (surv_norm ? 2 * Rr * G + n_gblk * (Rr + 1) + (Rr + 1) + Rr : 0) +
@@ -708,11 +707,13 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
 // ------------------------------------------------------------------ launches
 static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_blocks) {
     const DevArgs& d = c->d;
-    n_target_blocks = d.wide_targets ? d.T : (int)(((long)d.T * kLanesPerTarget + kParamBlock - 1) / kParamBlock);
+    n_target_blocks = d.wide_targets ? d.T : (int)(((long)d.T * d.lpt + kParamBlock - 1) / kParamBlock);
     int guide_blocks = 0;
     if (d.family == kMultiMixture)  // kAMax lanes per guide, or one wave per guide on the wide path
         guide_blocks = (int)(((long)d.G * (d.wide_alleles ? 64 : kAMax) + kParamBlock - 1) / kParamBlock);
-    else if (d.family == kMixture || d.surv_q0lik) guide_blocks = (d.G + d.q0_gpb - 1) / d.q0_gpb;
+    else if (d.surv_q0lik) guide_blocks = d.n_gamma_blocks;
+    else if (d.family == kMixture)  // the alpha_pi blocks + (survival) the q0 blocks
+        guide_blocks = (d.G + kParamBlock - 1) / kParamBlock + (d.q0_blocks ? d.n_gamma_blocks : 0);
     n_blocks = n_target_blocks + guide_blocks;
 }
 
@@ -732,7 +733,7 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
                        d.rows_v2 && !d.rrow && !d.surv_q0lik && !d.not_loss_owner && d.lpart &&
                        (d.dgq || d.family != kMixture);
     const bool kind2 = d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
-                       d.rows_v2 && !d.rrow && d.lpart;
+                       d.rows_v2 && !d.rrow && d.lpart && d.lpt == kLanesPerTargetSurv;
     const bool kind3 = d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov &&
                        !d.lpart && d.trow_summed && !d.surv_q0lik;
     // BEAN_HIP_PARAM_KIND=0 forces the generic build (the test that the specialised builds change nothing)

@@ -68,6 +68,16 @@ namespace bean {
 #else
 #define BEAN_STAMP_KP(slot) do {} while (0)
 #endif
+#if defined(BEAN_STAMP) && BEAN_STAMP == 5  // k_param's block roles on the 100 MHz real-time clock (one record per block)
+#define BEAN_STAMP_RT(rec, slot)                                                                 \
+    do {                                                                                         \
+        unsigned long long u_;                                                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u_)::"memory");          \
+        if (threadIdx.x == 0) c.dbg[(long)(rec) * 8 + (slot)] = u_;                              \
+    } while (0)
+#else
+#define BEAN_STAMP_RT(rec, slot) do {} while (0)
+#endif
 
 constexpr double kEps = 1e-5;         // epsilon of get_alpha (utils.py:11)
 // utils.py:133; the reference builds Normal(0, 0.655) from Python floats, i.e. float32 tensors
@@ -196,8 +206,10 @@ struct DevArgs {
     double *gq;                      // (R, G) d loss / d q_0[r, g]
     double *sq;                      // (R) sum_g q_0[r, g] * gq[r, g]
     int n_gamma_blocks;
-    int* q0_ctr;                     // arrivals of k_param's guide blocks (last one forms gsum), zero between launches
-    int q0_gpb, q0_npar;             // survival: guides per guide block of k_param (kParamBlock / q0_npar) and lane groups drawing in parallel
+    int* q0_ctr;                     // arrivals of k_param's q0 blocks (last one forms gsum), zero between launches
+    int q0_blocks;                   // survival: k_param has q0 blocks (n_gamma_blocks of them, kParamBlock guides each)
+    int q0_blk0;                     // survival: k_param's guide-part blocks ahead of its q0 blocks (MixtureNormal: the alpha_pi blocks)
+    int lpt;                         // k_param, thin mode: lanes per target (kLanesPerTarget, or 4: survival variant families)
 };
 
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
@@ -695,25 +707,31 @@ __device__ __forceinline__ void write_phi_entry(const DevArgs& c, int t, int b, 
 //   C  tables    group map again: one lane per bin edge
 // with the hand-over through LDS.  Wide mode (few or very long targets): one target per block.
 constexpr int kTargetsPerBlock = kParamBlock / kLanesPerTarget;
+// The survival variant families have no table to fill and ~15 (guide, replicate) rows per target: with
+// kLanesPerTargetSurv lanes per target a block takes 64 targets instead of 16 (BASELINE config 5: 313
+// target blocks instead of 1 250, and k_param's three kinds of blocks are resident together).
+constexpr int kLanesPerTargetSurv = 4;
+constexpr int kTargetsPerBlockMax = kParamBlock / kLanesPerTargetSurv;
 
 // owner map: the target whose parameters this thread updates (phase B)
-__device__ __forceinline__ void target_of_thread(const DevArgs& c, int& t, bool& active) {
+__device__ __forceinline__ void target_of_thread(const DevArgs& c, int& t, bool& active, unsigned bid) {
     if (c.wide_targets) {
-        t = blockIdx.x;
+        t = bid;
         active = threadIdx.x == 0;
     } else {
-        t = blockIdx.x * kTargetsPerBlock + threadIdx.x;
-        active = (int)threadIdx.x < kTargetsPerBlock && t < c.T;
+        const int tpb = kParamBlock / c.lpt;
+        t = bid * tpb + threadIdx.x;
+        active = (int)threadIdx.x < tpb && t < c.T;
     }
 }
 // group map: the target this thread's lane group sums rows / tabulates edges for (phases A and C)
-__device__ __forceinline__ void target_of_group(const DevArgs& c, int& t, bool& lead) {
+__device__ __forceinline__ void target_of_group(const DevArgs& c, int& t, bool& lead, unsigned bid) {
     if (c.wide_targets) {
-        t = blockIdx.x;
+        t = bid;
         lead = threadIdx.x == 0;
     } else {
-        t = (blockIdx.x * blockDim.x + threadIdx.x) / kLanesPerTarget;
-        lead = t < c.T && (threadIdx.x & (kLanesPerTarget - 1)) == 0;
+        t = (bid * blockDim.x + threadIdx.x) / c.lpt;
+        lead = t < c.T && (threadIdx.x & (c.lpt - 1)) == 0;
     }
 }
 
@@ -789,7 +807,8 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
     if (c.wrow) {
         // wave form: the (guide, replicate) rows of the target are spread over its lane
         // group and summed by a fixed shuffle tree (deterministic, shard independent)
-        const int lg = threadIdx.x & (kLanesPerTarget - 1);
+        const int lpt = c.lpt;
+        const int lg = threadIdx.x & (lpt - 1);
         double a = 0.0, b = 0.0;
         if (t < c.T) {
             const int g0 = c.toff[t], ng = c.toff[t + 1] - g0;
@@ -798,27 +817,35 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
             // a chain of memory round trips, and k_param is made of those); i / ng without the integer
             // division (exact for i < 2^20); the order of the additions is unchanged
             const float rng = 1.0f / (float)ng;
-            for (int i0 = lg; i0 < n; i0 += 4 * kLanesPerTarget) {
+            for (int i0 = lg; i0 < n; i0 += 4 * lpt) {
                 double xa[4], xb[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * kLanesPerTarget;
+                    const int i = i0 + u * lpt;
                     xa[u] = xb[u] = 0.0;
                     if (i < n) {
                         const int r = (int)(((float)i + 0.5f) * rng), g = g0 + (i - r * ng);
                         xa[u] = c.wrow[((long)kPGmu * c.R + r) * c.G + g];
-                        xb[u] = c.wrow[((long)kPGy * c.R + r) * c.G + g];
+                        if (!c.survival) xb[u] = c.wrow[((long)kPGy * c.R + r) * c.G + g];  // (survival: no sd latent)
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (i0 + u * kLanesPerTarget < n) {
+                    if (i0 + u * lpt < n) {
                         a += xa[u];
                         b += xb[u];
                     }
             }
         }
-        group16_allsum(a, b);
+        if (lpt == kLanesPerTarget) {
+            group16_allsum(a, b);
+        } else {  // kLanesPerTargetSurv = 4 lanes: xor 2, xor 1 as quad permutations
+            static_assert(kLanesPerTargetSurv == 4, "one DPP quad per target");
+            a += dpp_f64<0x4e, 0xf>(a);  // quad_perm:[2,3,0,1]
+            b += dpp_f64<0x4e, 0xf>(b);
+            a += dpp_f64<0xb1, 0xf>(a);  // quad_perm:[1,0,3,2]
+            b += dpp_f64<0xb1, 0xf>(b);
+        }
         gmu = a;
         gy = b;
     }
@@ -831,7 +858,7 @@ __global__ __launch_bounds__(kParamBlock) void k_target_reduce(DevArgs c, double
     __shared__ double scratch[16];
     int t;
     bool lead;
-    target_of_group(c, t, lead);
+    target_of_group(c, t, lead, blockIdx.x);
     double gmu, gy;
     target_grad_sums(c, t, lead, scratch, gmu, gy);
     if (lead) {
@@ -996,7 +1023,7 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
             for (int a = 0; a < 2; ++a)
                 gc[a] = -nrg * (dgS_p - dg_p[a]) + (cl[a] ? 0.0 : Rf * (dgS_q - dg_q[a])) + GA_[a];
         }
-        loss_fin = -lp + lq;
+        loss_fin += -lp + lq;
         const double dot = (gc[0] * al0 + gc[1] * al1) / s;
         emit_grad_pre<ADAM>(c, 4, 2 * g, pa0 / s * (gc[0] - dot) * al0, ak, up[0], um[0], uv[0]);
         emit_grad_pre<ADAM>(c, 4, 2 * g + 1, pa0 / s * (gc[1] - dot) * al1, ak, up[1], um[1], uv[1]);
@@ -1057,40 +1084,30 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
     }
 }
 
-// Survival, tail of k_param's guide part (PREP): the Gamma draws of the Dirichlet-over-all-guides site
+// Survival, k_param's q0 blocks (PREP): the Gamma draws of the Dirichlet-over-all-guides site
 // (survival MixtureNormal q0, survival NormalModel initial_abundance) of the step just prepared, from
 // the concentration the lane has just updated, and their normalisers.
 //   gam[r, g]          one lane per guide draws its R gammas, two per rejection loop;
 //   gpart[block, j]    block sums (j < R: gammas of replicate j; j = R: the concentrations);
-//   gsum[j]            the guide block that arrives LAST adds the partials of all blocks, in the fixed
-//                      order (strided partials, block tree) the separate reduction launch used: same bits.
+//   gsum[j]            the q0 block that arrives LAST adds the partials of all blocks, in a fixed
+//                      order (strided partials, wave tree).
 // These were two more launches per step (k_q0_draws 13 us, k_sum_parts 6 us at BASELINE config 5) whose
 // only product is R + 1 sums.  Hand-over as in the fused step kernel (bean_step_v2.hpp): agent-scope
 // stores, s_waitcnt, one relaxed agent-scope atomic per block; no fence.
 // torch draws this site in float32 (the concentration is a float32 parameter): the gamma underflows
-// to 0 and is floored at FLT_MIN (ATen _s_dirichlet_cpu).
+// to 0 and is floored at FLT_MIN (ATen _s_dirichlet_cpu); sample_gamma_pair_floor32 uses that floor to
+// leave the rejection loop out where U^(1/alpha) has already decided the result (with the
+// concentrations of 1 / n_guides the site starts from, ~90 % of the waves).
 __device__ __forceinline__ void q0_draws_and_totals(const DevArgs& c, int gb, int g, bool in, double conc,
-                                                    unsigned long long step, double* scratch) {
-    (void)scratch;
+                                                    unsigned long long step, unsigned rec) {
+    (void)rec;
     constexpr int kChunk = 16;                 // values reduced per barrier pair
     constexpr int kWaves = kParamBlock / 64;
     __shared__ double qs[kChunk][kWaves];      // wave sums of the current chunk of values
-    __shared__ double qc[kParamBlock];         // the block's updated concentrations
     __shared__ int is_last;
     const int R = c.R, np1 = c.R + 1;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // The block's q0_gpb guides were updated by its first q0_gpb lanes; the draws are spread over
-    // q0_npar lane groups (1, 2 or 4: whole waves), group k taking replicate pairs k, k + q0_npar, ...:
-    // a rejection loop with a 1e-5 concentration is a long dependent chain, and k_param has too few
-    // waves to hide one behind another.
-    const int gpb = c.q0_gpb, npar = c.q0_npar;
-    qc[threadIdx.x] = in ? conc : 0.0;
-    __syncthreads();
-    const int grp = (int)threadIdx.x / gpb, jl = (int)threadIdx.x - grp * gpb;
-    const int gg = gb * gpb + jl;
-    const bool live = grp < npar && gg < c.G;
-    const double cc = qc[jl];
-    (void)g;
+    BEAN_STAMP_RT(rec, 1);
     double* mine = c.gpart + (long)gb * np1;
     // value j of the block: j < R the gammas of replicate j, j = R the concentrations; wave sums go to
     // LDS, and once per chunk (or at the end) thread k adds the waves' parts of value k in fixed order
@@ -1106,34 +1123,33 @@ __device__ __forceinline__ void q0_draws_and_totals(const DevArgs& c, int gb, in
         j0 += n_in_chunk;
         n_in_chunk = 0;
     };
-    auto put = [&](bool mine_to_sum, double v) {  // mine_to_sum is uniform over the wave
-        const double t = mine_to_sum ? wave_sum(v) : 0.0;
+    auto put = [&](double v) {
+        const double t = wave_sum(v);
         if (lane == 0) qs[n_in_chunk][w] = t;
         if (++n_in_chunk == kChunk) flush();
     };
-    int pair = 0;
-    for (int r0 = 0; r0 < R; r0 += 2, ++pair) {
+    for (int r0 = 0; r0 < R; r0 += 2) {
         const int r1 = r0 + 1;
         const bool two = r1 < R;
-        const bool my_pair = grp < npar && pair % npar == grp;  // uniform over the wave (gpb is a multiple of 64)
         double gm0 = 0.0, gm1 = 0.0;
-        if (my_pair && live) {
+        if (in) {
             if (c.x0_in) {
-                gm0 = c.x0_in[(long)r0 * c.G + gg];  // injected draws: already normalised
-                if (two) gm1 = c.x0_in[(long)r1 * c.G + gg];
+                gm0 = c.x0_in[(long)r0 * c.G + g];  // injected draws: already normalised
+                if (two) gm1 = c.x0_in[(long)r1 * c.G + g];
             } else {
-                Rng rng(c.seed, kSiteQ0, (unsigned long long)r0 * c.G_tot + (c.g_off + gg), step * 256ull);
-                const GammaPair gp = sample_gamma_pair(cc, two ? cc : 1.0, rng);
+                Rng rng(c.seed, kSiteQ0, (unsigned long long)r0 * c.G_tot + (c.g_off + g), step * 256ull);
+                const GammaPair gp = sample_gamma_pair_floor32(conc, two ? conc : 0.0, rng);
                 gm0 = (double)fmaxf((float)gp.g0, 1.17549435e-38f);
                 gm1 = two ? (double)fmaxf((float)gp.g1, 1.17549435e-38f) : 0.0;
             }
-            c.gam[(long)r0 * c.G + gg] = gm0;
-            if (two) c.gam[(long)r1 * c.G + gg] = gm1;
+            c.gam[(long)r0 * c.G + g] = gm0;
+            if (two) c.gam[(long)r1 * c.G + g] = gm1;
         }
-        put(my_pair, gm0);
-        if (two) put(my_pair, gm1);
+        put(gm0);
+        if (two) put(gm1);
     }
-    put(grp == 0, grp == 0 && live ? cc : 0.0);
+    BEAN_STAMP_RT(rec, 3);
+    put(in ? conc : 0.0);
     if (n_in_chunk) flush();
     // this block's partials are out; count in, and the block that arrives last forms the totals:
     // wave i takes values i, i + 4, ...; lanes stride over the blocks' partials, fixed tree
@@ -1144,6 +1160,7 @@ __device__ __forceinline__ void q0_draws_and_totals(const DevArgs& c, int gb, in
         if (is_last) __hip_atomic_store(c.q0_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    BEAN_STAMP_RT(rec, 4);
     if (is_last) {
         for (int j = w; j < np1; j += kWaves) {
             double v = 0.0;
@@ -1165,6 +1182,7 @@ __device__ __forceinline__ void q0_draws_and_totals(const DevArgs& c, int gb, in
 template <bool FINISH, bool ADAM, bool PREP, int KIND = 0>
 __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_blocks) {
     if (KIND == 1) {
+        __builtin_assume(c.lpt == kLanesPerTarget);
         __builtin_assume(!c.survival);
         __builtin_assume(c.family != kMultiMixture);
         __builtin_assume(!c.wide_targets);
@@ -1179,6 +1197,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(c.dgq != nullptr || c.family != kMixture);
     }
     if (KIND == 2) {  // the survival variant families on the wave-form path (thin mode, unsharded parameters)
+        __builtin_assume(c.lpt == kLanesPerTargetSurv);
         __builtin_assume(c.survival != 0);
         __builtin_assume(c.family != kMultiMixture);
         __builtin_assume(!c.wide_targets);
@@ -1190,6 +1209,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(c.lpart != nullptr);
     }
     if (KIND == 3) {  // tiling (MultiMixtureNormal) in the register-resident wave form, thin mode
+        __builtin_assume(c.lpt == kLanesPerTarget);
         __builtin_assume(c.family == kMultiMixture);
         __builtin_assume(!c.wide_targets);
         __builtin_assume(!c.wide_alleles);
@@ -1199,18 +1219,32 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(c.trow_summed != 0);
         __builtin_assume(!c.surv_q0lik);
     }
+    // Block roles, in role order: target blocks, guide blocks, (survival q0 site) q0 blocks.  The q0
+    // blocks hold the kernel's longest chain (parameter update -> gamma draws -> block sums -> the last
+    // one's totals, ~15 us at BASELINE config 5 against ~10 us of an alpha_pi guide block and ~5 us of a
+    // target block), so they are dispatched first, the guide blocks next and the target blocks last.
+    // (As a tail of the guide blocks - this round's first form - the draws began when the alpha_pi update
+    // ended: k_param 33 us.  As blocks of their own that waited for a guide block's flag: 35 us.)
+    unsigned bid = blockIdx.x;
+    if (c.q0_blocks) {
+        const unsigned ntb = (unsigned)n_target_blocks, nq0 = (unsigned)c.n_gamma_blocks, ngd = (unsigned)c.q0_blk0;
+        if (blockIdx.x < nq0) bid = ntb + ngd + blockIdx.x;
+        else if (blockIdx.x < nq0 + ngd) bid = ntb + (blockIdx.x - nq0);
+        else bid = blockIdx.x - nq0 - ngd;
+    }
     __shared__ double scratch[16];
-    __shared__ double hand[4][kTargetsPerBlock];  // phase hand-over: gmu, gy (A -> B), mu, y (B -> C)
+    __shared__ double hand[4][kTargetsPerBlockMax];  // phase hand-over: gmu, gy (A -> B), mu, y (B -> C)
 #if BEAN_KP_DIAG == 1  // diagnostic builds (wrong results): time the target part alone ...
-    if ((int)blockIdx.x >= n_target_blocks) return;
+    if ((int)bid >= n_target_blocks) return;
 #elif BEAN_KP_DIAG == 2  // ... or the guide part alone
-    if ((int)blockIdx.x < n_target_blocks && blockIdx.x != 0) return;
+    if ((int)bid < n_target_blocks && bid != 0) return;
 #endif
 #if defined(BEAN_STAMP) && BEAN_STAMP == 2
     const int lane = threadIdx.x & 63;
-    const long wave_gid = (long)blockIdx.x * (kParamBlock / 64) + (threadIdx.x >> 6);
+    const long wave_gid = (long)bid * (kParamBlock / 64) + (threadIdx.x >> 6);
 #endif
     BEAN_STAMP_KP(0);
+    if (PREP && FINISH) BEAN_STAMP_RT(bid, 0);
     const StepCtr ctr = *c.ctrA;
     const unsigned long long s_fin = ctr.step;
     const unsigned long long s_prep = FINISH ? ctr.step + 1 : ctr.step;
@@ -1231,9 +1265,9 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     __shared__ long long lp3[3];
     const bool lp_early = FINISH && c.lpart != nullptr && !c.wide_targets && !c.tgrad;
     long long lw0 = 0, lw1 = 0, lw2 = 0;
-    if (lp_early && (int)blockIdx.x < n_target_blocks && threadIdx.x >= blockDim.x - 64) {
+    if (lp_early && (int)bid < n_target_blocks && threadIdx.x >= blockDim.x - 64) {
         const long per = (c.n_lpart + n_target_blocks - 1) / n_target_blocks;
-        const long e0 = (long)blockIdx.x * per, e1 = e0 + per < c.n_lpart ? e0 + per : c.n_lpart;
+        const long e0 = (long)bid * per, e1 = e0 + per < c.n_lpart ? e0 + per : c.n_lpart;
         for (long i = e0 + (threadIdx.x & 63); i < e1; i += 64) {
             lw0 += c.lpart[3 * i];
             lw1 += c.lpart[3 * i + 1];
@@ -1241,31 +1275,75 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         }
     }
 
-    if ((int)blockIdx.x < n_target_blocks) {
+    if (c.survival && mixture && (int)bid >= n_target_blocks + c.q0_blk0) {
+        // survival MixtureNormal: the Dirichlet(q0) site over ALL guides and the per-guide
+        // baseline growth draw (survival_model.py:259-274,306-311,660-669)
+        const int gb = (int)bid - n_target_blocks - c.q0_blk0;
+        const int g = gb * kParamBlock + threadIdx.x;
+        const bool in = g < c.G;
+        float q0u = in ? c.p[7][g] : 0.f;
+        if (FINISH && in) {
+            float q0m = 0.f, q0v = 0.f;
+            if (ADAM) {
+                q0m = c.m[7][g];
+                q0v = c.v[7][g];
+            }
+            const double q0 = (double)expf(q0u);
+            emit_grad_pre<ADAM>(c, 7, g, part_row(c, kPQ0, g) * q0, ak, q0u, q0m, q0v);
+            // - log p(mu_negctrl): Normal(m0, s0) built from Python floats => float32 tensors
+            const float s0f = (float)c.neg_scale;
+            const double du = c.u_g[g] - (double)(float)c.neg_loc;
+            loss_fin += du * du / (2.0 * (double)(s0f * s0f)) + (double)logf(s0f) + kHalfLog2PiC;
+        }
+        if (PREP) {
+            double q0 = 0.0;
+            if (in) {
+                q0 = (double)expf(q0u);
+                double eps;
+                if (c.eps_u_in) {
+                    eps = c.eps_u_in[g];
+                } else {
+                    rocrand_state_philox4x32_10 st;
+                    rocrand_init(c.seed, ((unsigned long long)kSiteAux << 48) + (unsigned long long)(c.g_off + g),
+                                 s_prep * 4ull, &st);
+                    eps = (double)rocrand_normal(&st);
+                }
+                c.eps_u[g] = eps;
+                c.u_g[g] = (double)(float)c.neg_loc + eps * (double)(float)c.neg_scale;
+                if (c.eps_u_out) c.eps_u_out[g] = eps;
+            }
+            q0_draws_and_totals(c, gb, g, in, q0, s_prep, bid);
+        }
+    }
+    if ((int)bid < n_target_blocks) {
         // ------------------------------------------------ target part
         int t;
         bool active;
         double gmu = 0.0, gy = 0.0, tab_mu = 0.0, tab_y = 0.0;
-        target_of_thread(c, t, active);
+        target_of_thread(c, t, active, bid);
         // sorting families: the target's parameters, moments and last draw are loaded BEFORE the
         // gradient sums (independent of them), not after
-        const bool sorting_t = active && !c.survival;
         float pf[4] = {0.f, 0.f, 0.f, 0.f}, mf[4] = {0.f, 0.f, 0.f, 0.f}, vf[4] = {0.f, 0.f, 0.f, 0.f};
         double eps1_f = 0.0, eps2_f = 0.0, mu_f = 0.0, y_f = 0.0;
-        if (sorting_t) {
+        if (active) {
+            const int n_lat = c.survival ? 2 : 4;  // survival: mu only (loc, scale)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                pf[i] = c.p[i][t];
-                if (FINISH && ADAM) {
-                    mf[i] = c.m[i][t];
-                    vf[i] = c.v[i][t];
+                if (i < n_lat) {
+                    pf[i] = c.p[i][t];
+                    if (FINISH && ADAM) {
+                        mf[i] = c.m[i][t];
+                        vf[i] = c.v[i][t];
+                    }
                 }
             }
             if (FINISH) {
                 eps1_f = c.eps_mu[t];
-                eps2_f = c.eps_sd[t];
                 mu_f = c.mu_t[t];
-                y_f = c.y_t[t];
+                if (!c.survival) {
+                    eps2_f = c.eps_sd[t];
+                    y_f = c.y_t[t];
+                }
             }
         }
         if (FINISH) {
@@ -1282,12 +1360,12 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 // phase A (group map) -> phase B (owner map) through LDS
                 int tg;
                 bool lead;
-                target_of_group(c, tg, lead);
+                target_of_group(c, tg, lead, bid);
                 double a, b;
                 target_grad_sums(c, tg, lead, scratch, a, b);
                 if (lead) {
-                    hand[0][threadIdx.x / kLanesPerTarget] = a;
-                    hand[1][threadIdx.x / kLanesPerTarget] = b;
+                    hand[0][threadIdx.x / c.lpt] = a;
+                    hand[1][threadIdx.x / c.lpt] = b;
                 }
                 __syncthreads();
                 if (active) {
@@ -1309,9 +1387,10 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         BEAN_STAMP_KP(1);
         if (active && c.survival) {
             // survival families: mu only (no sd latent), growth tables are computed in k_guide_survival
-            float pl = c.p[0][t], psu = c.p[1][t];
+            // (parameters, moments and last draw loaded before the gradient sums, like the sorting families')
+            float pl = pf[0], psu = pf[1];
             if (FINISH) {
-                const double eps1 = c.eps_mu[t], mu = c.mu_t[t];
+                const double eps1 = eps1_f, mu = mu_f;
                 const double s_mu = exp((double)psu);
                 double logp_mu, dlogp_mu;
                 if (c.flags & kPriorNormalMu) {
@@ -1327,12 +1406,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 const double logq_mu = -0.5 * eps1 * eps1 - (double)psu - kHalfLog2PiC;
                 loss_fin = -logp_mu + logq_mu;
                 const double Gmu = gmu - dlogp_mu;
-                emit_grad<ADAM>(c, 0, t, Gmu, ak);
-                emit_grad<ADAM>(c, 1, t, Gmu * eps1 * s_mu - 1.0, ak);
-                if (ADAM) {
-                    pl = c.p[0][t];
-                    psu = c.p[1][t];
-                }
+                emit_grad_pre<ADAM>(c, 0, t, Gmu, ak, pl, mf[0], vf[0]);
+                emit_grad_pre<ADAM>(c, 1, t, Gmu * eps1 * s_mu - 1.0, ak, psu, mf[1], vf[1]);
             }
             if (PREP) {
                 double eps1;
@@ -1419,7 +1494,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 }
                 __syncthreads();
                 const int grp = threadIdx.x / kLanesPerTarget;
-                t = (blockIdx.x * blockDim.x + threadIdx.x) / kLanesPerTarget;  // group map from here on
+                t = (bid * blockDim.x + threadIdx.x) / kLanesPerTarget;  // group map from here on
                 const double mu = hand[2][grp], y = hand[3][grp];
                 const int j = threadIdx.x & (kLanesPerTarget - 1);
                 const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
@@ -1441,7 +1516,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         if (c.survival) {
             // per-guide baseline growth mu_negctrl ~ N(m0, s0): sampled in the model only
             // (survival_model.py:479-483), i.e. a fresh prior draw each step
-            const int tid = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
+            const int tid = ((int)bid - n_target_blocks) * blockDim.x + threadIdx.x;
             // kAMax lanes per guide (param_guide_tiling) or one wave per guide (wide path): lane 0 acts
             const int lpg = c.wide_alleles ? 64 : kAMax;
             const int g = tid / lpg;
@@ -1469,18 +1544,17 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         }
     } else if (mixture) {
         // ------------------------------------------------- guide part
-        // survival: a guide block holds q0_gpb guides (its other lanes join for the gamma draws below)
-        const int gpb = c.survival ? c.q0_gpb : (int)blockDim.x;
-        const int g = ((int)blockIdx.x - n_target_blocks) * gpb + threadIdx.x;
-        if ((int)threadIdx.x < gpb && g < c.G) param_guide_mix<FINISH, ADAM, PREP, false>(c, g, ak, s_prep, loss_fin);
+        // (survival: the q0 blocks follow the alpha_pi blocks; their g is out of range here)
+        const int g = ((int)bid - n_target_blocks) * (int)blockDim.x + threadIdx.x;
+        if (g < c.G) param_guide_mix<FINISH, ADAM, PREP, false>(c, g, ak, s_prep, loss_fin);
     }
-    if (c.surv_q0lik && (int)blockIdx.x >= n_target_blocks) {
+    if (c.surv_q0lik && (int)bid >= n_target_blocks) {
         // survival NormalModel: Dirichlet(initial_abundance) site over ALL guides, drawn per
         // replicate and used by the likelihood (survival_model.py:62-67, 629-639).  The prior is
         // Dirichlet(1 / G), so unlike the MixtureNormal q0 site nothing cancels.
-        const int gb = (int)blockIdx.x - n_target_blocks;
-        const int g = gb * c.q0_gpb + threadIdx.x;
-        const bool in = (int)threadIdx.x < c.q0_gpb && g < c.G;
+        const int gb = (int)bid - n_target_blocks;
+        const int g = gb * kParamBlock + threadIdx.x;
+        const bool in = g < c.G;
         float iau = in ? c.p[7][g] : 0.f;
         if (FINISH && in) {
             const double ia = (double)expf(iau);
@@ -1513,45 +1587,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
             }
         }
         if (PREP) {
-            double ia = 0.0;
-            if (in) ia = (double)expf(iau);
-            q0_draws_and_totals(c, gb, g, in, ia, s_prep, scratch);
-        }
-    }
-    if (c.survival && mixture && (int)blockIdx.x >= n_target_blocks) {
-        // survival MixtureNormal: the Dirichlet(q0) site over ALL guides and the per-guide
-        // baseline growth draw (survival_model.py:259-274,306-311,660-669)
-        const int gb = (int)blockIdx.x - n_target_blocks;
-        const int g = gb * c.q0_gpb + threadIdx.x;
-        const bool in = (int)threadIdx.x < c.q0_gpb && g < c.G;
-        float q0u = in ? c.p[7][g] : 0.f;
-        if (FINISH && in) {
-            const double q0 = (double)expf(q0u);
-            emit_grad<ADAM>(c, 7, g, part_row(c, kPQ0, g) * q0, ak);
-            if (ADAM) q0u = c.p[7][g];
-            // - log p(mu_negctrl): Normal(m0, s0) built from Python floats => float32 tensors
-            const float s0f = (float)c.neg_scale;
-            const double du = c.u_g[g] - (double)(float)c.neg_loc;
-            loss_fin += du * du / (2.0 * (double)(s0f * s0f)) + (double)logf(s0f) + kHalfLog2PiC;
-        }
-        if (PREP) {
-            double q0 = 0.0;
-            if (in) {
-                q0 = (double)expf(q0u);
-                double eps;
-                if (c.eps_u_in) {
-                    eps = c.eps_u_in[g];
-                } else {
-                    rocrand_state_philox4x32_10 st;
-                    rocrand_init(c.seed, ((unsigned long long)kSiteAux << 48) + (unsigned long long)(c.g_off + g),
-                                 s_prep * 4ull, &st);
-                    eps = (double)rocrand_normal(&st);
-                }
-                c.eps_u[g] = eps;
-                c.u_g[g] = (double)(float)c.neg_loc + eps * (double)(float)c.neg_scale;
-                if (c.eps_u_out) c.eps_u_out[g] = eps;
-            }
-            q0_draws_and_totals(c, gb, g, in, q0, s_prep, scratch);
+            q0_draws_and_totals(c, gb, g, in, in ? (double)expf(iau) : 0.0, s_prep, bid);
         }
     }
     if (FINISH) {
@@ -1559,10 +1595,10 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         // terms are counted by one rank only
         // (sorting NormalModel with sample covariates: the replicated parameters are mu_cov's, handled by
         // k_cov_step; its per-target parameters are shard-local and count on every rank)
-        if ((int)blockIdx.x < n_target_blocks && c.not_loss_owner && !c.n_cov) loss_fin = 0.0;
+        if ((int)bid < n_target_blocks && c.not_loss_owner && !c.n_cov) loss_fin = 0.0;
         const double tot = block_sum(loss_fin, scratch);
         if (threadIdx.x == 0) {
-            if (lp_early && (int)blockIdx.x < n_target_blocks) {
+            if (lp_early && (int)bid < n_target_blocks) {
                 // this block's prior / entropy terms and its share of the guide kernel's loss parts in
                 // one set of integer atomics
                 long long a = lp3[0], b = lp3[1], d = lp3[2];
@@ -1573,7 +1609,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 } else {
                     d += 1;
                 }
-                long long* acc = c.loss_acc + ((long)ctr.slot * kLossSub + (blockIdx.x & (kLossSub - 1))) * kLossWords;
+                long long* acc = c.loss_acc + ((long)ctr.slot * kLossSub + (bid & (kLossSub - 1))) * kLossWords;
                 atomicAdd((unsigned long long*)acc, (unsigned long long)a);
                 atomicAdd((unsigned long long*)acc + 1, (unsigned long long)b);
                 if (d) atomicAdd((unsigned long long*)acc + 2, (unsigned long long)d);
@@ -1582,10 +1618,10 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
             }
         }
         // other modes: the first blocks take 256 loss parts each
-        if (c.lpart && !lp_early && (long)blockIdx.x * blockDim.x < c.n_lpart) {
+        if (c.lpart && !lp_early && (long)bid * blockDim.x < c.n_lpart) {
             __shared__ long long isum[3][16];
             long long ph = 0, pl = 0, pb = 0;
-            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < c.n_lpart; i += (long)gridDim.x * blockDim.x) {
+            for (long i = (long)bid * blockDim.x + threadIdx.x; i < c.n_lpart; i += (long)gridDim.x * blockDim.x) {
                 ph += c.lpart[3 * i];
                 pl += c.lpart[3 * i + 1];
                 pb += c.lpart[3 * i + 2];
@@ -1607,7 +1643,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                     b += isum[1][i];
                     d += isum[2][i];
                 }
-                long long* acc = c.loss_acc + ((long)ctr.slot * kLossSub + (blockIdx.x & (kLossSub - 1))) * kLossWords;
+                long long* acc = c.loss_acc + ((long)ctr.slot * kLossSub + (bid & (kLossSub - 1))) * kLossWords;
                 atomicAdd((unsigned long long*)acc, (unsigned long long)a);
                 atomicAdd((unsigned long long*)acc + 1, (unsigned long long)b);
                 if (d) atomicAdd((unsigned long long*)acc + 2, (unsigned long long)d);
@@ -1616,7 +1652,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     }
     (void)loss_prep;
     BEAN_STAMP_KP(7);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (PREP && FINISH) BEAN_STAMP_RT(bid, 7);
+    if (bid == 0 && threadIdx.x == 0) {
         StepCtr nxt;
         nxt.step = s_prep;
         nxt.slot = slot_prep;

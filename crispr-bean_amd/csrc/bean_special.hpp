@@ -522,6 +522,12 @@ struct GammaPair {
 // and a wave only iterates until its slowest lane has accepted both.
 // `first`: the Philox block at the generator's first counter, where the caller has computed it ahead
 // (every lane consumes that block first, as the boost's uniforms or as the inputs of its first round).
+// FLOOR32: the caller keeps max((float)g, FLT_MIN) of each draw (a site torch samples in float32).  A
+// boosted component whose U^(1/alpha) is below FLT_MIN / 128 gives that floor whatever its
+// Marsaglia-Tsang factor turns out to be (the factor is at most d v <= 5/3 (1 + 6.66 / sqrt(6))^3 = 86
+// with the 32-bit Box-Muller radius), so it skips the rejection loop: same result, and with
+// concentrations of 1 / n_guides most waves skip it altogether.
+template <bool FLOOR32 = false>
 __device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1, Rng rng, const uint4* first = nullptr) {
     double scale0 = 1.0, scale1 = 1.0;
     if (a0 < 1.0 || a1 < 1.0) {
@@ -533,18 +539,38 @@ __device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1,
         } else {
             u = uniform_pair(rng);
         }
+        // FLOOR32: log U / alpha < log(FLT_MIN / 128) = -92.19 decides the floor; a float32 log with a margin
+        // settles it for nearly every lane without the float64 log and exp (the value of a floored
+        // scale does not matter: 0 stands for it)
+        bool fl0 = false, fl1 = false;
+        if (FLOOR32) {
+            fl0 = (double)__logf((float)u.a) < -92.5 * a0 - 1e-5;
+            fl1 = (double)__logf((float)u.b) < -92.5 * a1 - 1e-5;
+        }
         if (a0 < 1.0) {
-            scale0 = a0 == 0.0 ? 0.0 : exp(flog(u.a) * frcp(a0 == 0.0 ? 1.0 : a0));
+            if (fl0) scale0 = 0.0;
+            else scale0 = a0 == 0.0 ? 0.0 : exp(flog(u.a) * frcp(a0));
             a0 += 1.0;
         }
         if (a1 < 1.0) {
-            scale1 = a1 == 0.0 ? 0.0 : exp(flog(u.b) * frcp(a1 == 0.0 ? 1.0 : a1));
+            if (fl1) scale1 = 0.0;
+            else scale1 = a1 == 0.0 ? 0.0 : exp(flog(u.b) * frcp(a1));
             a1 += 1.0;
+        }
+    }
+    bool done0 = false, done1 = false;
+    if (FLOOR32) {
+        done0 = scale0 < 9.18e-41;  // FLT_MIN / 128
+        done1 = scale1 < 9.18e-41;
+        if (done0 && done1) {
+            GammaPair out;
+            out.g0 = out.g1 = 0.0;  // floored by the caller
+            out.k = rng.k;
+            return out;
         }
     }
     const double d0 = a0 - 1.0 / 3.0, d1 = a1 - 1.0 / 3.0;
     const double c0 = frcp(sqrt(9.0 * d0)), c1 = frcp(sqrt(9.0 * d1));
-    bool done0 = false, done1 = false;
     double g0 = d0, g1 = d1;
 #pragma unroll 1
     for (int it = 0; it < 64 && !(done0 && done1); ++it) {  // >= 95 % acceptance per round
@@ -583,6 +609,9 @@ __device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1,
 // out-of-line copy for the kernels whose call sites have many live registers
 __device__ BEAN_NOINLINE GammaPair sample_gamma_pair(double a0, double a1, Rng rng) {
     return sample_gamma_pair_inl(a0, a1, rng);
+}
+__device__ BEAN_NOINLINE GammaPair sample_gamma_pair_floor32(double a0, double a1, Rng rng) {
+    return sample_gamma_pair_inl<true>(a0, a1, rng);
 }
 
 // single draw (second component unused)
