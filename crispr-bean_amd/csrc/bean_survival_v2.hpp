@@ -21,15 +21,22 @@
 
 namespace bean {
 
-constexpr int kSvMisc = 4;  // per-guide values staged in LDS: a0, a0_bc, c_p (2)
-
+// LDS per wave: the per-timepoint constants and the two growth columns only (6.3 KB at six timepoints).
+// The counts and the per-guide constants used to be staged there too (11.4 KB: 14 single-wave workgroups
+// per CU, fewer than the 16 its 128 VGPRs allow); the counts are read from global memory where they are
+// used (coalesced rows, twice per step).  BASELINE config 5: 92.7 -> 85.8 us per step.  The kernel is
+// VALU-bound (SQ_INSTS_VALU x 4 cycles / 1 024 SIMDs = 39 us) and its 4 689 waves still do not fit the
+// 4 096 slots of four waves per SIMD; five waves per SIMD (96 VGPRs: 52 spilled) measured 88.2 us, six
+// (80 VGPRs: 78 spilled) 96.3 us.
 __host__ __device__ inline size_t guide_survival_wave_lds(int B) {
-    return ((size_t)4 * B + (size_t)2 * B * 64 + (size_t)kSvMisc * 64) * sizeof(double) +
-           (size_t)2 * B * 64 * sizeof(float);
+    return ((size_t)4 * B + (size_t)2 * B * 64) * sizeof(double);
 }
 
+#ifndef BEAN_SURV_EU
+#define BEAN_SURV_EU 4
+#endif
 template <int FAM, bool ACC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BEAN_SURV_EU)))
 void k_guide_survival_wave(DevArgs c) {
     constexpr bool MIX = FAM == kMixture;
     extern __shared__ double sls[];
@@ -45,21 +52,22 @@ void k_guide_survival_wave(DevArgs c) {
     const StepCtr ctr = *c.ctrB;
     double loss = 0.0;
 
-    // LDS: [4][B] sf, sf_bc, sample mask, time | [B][64] P0 | [B][64] P1 | [kSvMisc][64] | [2][B][64] counts
+    // LDS: [4][B] sf, sf_bc, sample mask, time | [B][64] P0 | [B][64] P1
     double* cst = sls;
     double* p0s = cst + 4 * B + lane;              // exp(u t_b)          at p0s[b * 64]
     double* p1s = cst + 4 * B + B * 64 + lane;     // exp((u + mu_t) t_b) at p1s[b * 64]
-    double* ms = cst + 4 * B + 2 * B * 64 + lane;  // ms[q * 64]
-    float* xs = (float*)(cst + 4 * B + 2 * B * 64 + kSvMisc * 64);
     const bool use_bc = (c.flags & kUseBc) != 0;
     const bool q0lik = !MIX && c.surv_q0lik;
     bool rgm = false, negc = false;
     uint4 philox_first = make_uint4(0u, 0u, 0u, 0u);
     float api0 = 0.f, api1 = 0.f, p7 = 0.f;
-    double pa0 = 0.0, mu_t = 0.0, u = 0.0, gam = 0.0, lobs = 0.0;
+    double pa0 = 0.0, mu_t = 0.0, u = 0.0, gam = 0.0, lobs = 0.0, a00 = 0.0, a01 = 0.0;
+    double n_x = 0.0, n_bc = 0.0;
     {
         const int gc = valid ? g : G - 1;
         const long rgc = (long)r * G + gc;
+        // totals of the guide's counts over the timepoints (the loads in flight together; the likelihood
+        // loop reads the counts again, one coalesced row per timepoint)
         float xv[2][kBMax];
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
@@ -78,7 +86,8 @@ void k_guide_survival_wave(DevArgs c) {
         // survival NormalModel: mu of negative-control guides is forced to 0 (survival_model.py:59-60)
         negc = q0lik && c.negctrl && c.negctrl[gc] != 0;
         mu_t = c.mu_t[c.g2t[gc]];
-        const double a00 = c.a0[gc], a01 = use_bc ? c.a0_bc[gc] : 0.0;
+        a00 = c.a0[gc];
+        a01 = use_bc ? c.a0_bc[gc] : 0.0;
         // the pi draw's first Philox block, under the latency of the loads above (as in k_guide_wave2)
         if (MIX && !c.pi_in) philox_first = philox_block(c.seed, ((unsigned long long)kSitePi << 48) +
                                                                    ((unsigned long long)r * c.G_tot + (c.g_off + gc)),
@@ -96,14 +105,15 @@ void k_guide_survival_wave(DevArgs c) {
         }
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
-            const int bb = b < B ? b : B - 1;
-            xs[(0 * B + bb) * 64 + lane] = xv[0][b];
-            xs[(1 * B + bb) * 64 + lane] = xv[1][b];
+            if (b < B) {
+                n_x += (double)xv[0][b];
+                n_bc += (double)xv[1][b];
+            }
         }
         for (int b = kBMax; b < B; ++b) {  // more timepoints than the register batch holds (B <= kBCap)
             const long xo = ((long)r * B + b) * G + gc;
-            xs[(0 * B + b) * 64 + lane] = c.X[xo];
-            xs[(1 * B + b) * 64 + lane] = use_bc ? c.Xbc[xo] : 0.f;
+            n_x += (double)c.X[xo];
+            n_bc += use_bc ? (double)c.Xbc[xo] : 0.0;
         }
         {
             const int kq = lane >> 3, bq = lane & 7;
@@ -116,8 +126,6 @@ void k_guide_survival_wave(DevArgs c) {
                 }
             }
         }
-        ms[0 * 64] = a00;
-        ms[1 * 64] = a01;
     }
     __syncthreads();
 
@@ -141,8 +149,6 @@ void k_guide_survival_wave(DevArgs c) {
             const double al0 = (double)expf(api0), al1 = (double)expf(api1);
             const double rs = frcp(al0 + al1) * pa0;
             const double cp0 = al0 * rs, cp1 = al1 * rs;
-            ms[2 * 64] = cp0;
-            ms[3 * 64] = cp1;
             const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
             if (c.pi_in) {
                 pi0 = c.pi_in[rgi * 2];
@@ -187,24 +193,22 @@ void k_guide_survival_wave(DevArgs c) {
         const double w1 = MIX ? (ACC ? pe1 : pi1) : (q0lik ? x0 : 1.0);
         const double epsB = kEps / (double)B;
         double g0 = 0.0, g1 = 0.0, dmu = 0.0, nll = 0.0;
-        double S_x = 0.0, S_bc = 0.0, n_x = 0.0, n_bc = 0.0;
+        double S_x = 0.0, S_bc = 0.0;
 #pragma unroll 1
         for (int b = 0; b < B; ++b) {
             const double e = fma(w0, MIX ? p0s[b * 64] : 0.0, w1 * p1s[b * 64]);
             S_x += e * c_sf[b];
             S_bc += e * c_sf[B + b];
-            n_x += (double)xs[b * 64 + lane];
-            n_bc += (double)xs[(B + b) * 64 + lane];
         }
 #pragma unroll 1
         for (int lik = 0; lik < 2; ++lik) {
             if (lik == 1 && !use_bc) break;
             const double nn = lik ? n_bc : n_x;
             if (!(rgm && nn > (double)c.mask_thres)) continue;
-            const float* xp = xs + lik * B * 64 + lane;
+            const float* xp = (lik ? c.Xbc : c.X) + (long)r * B * G + g;  // timepoint b at xp[b * G]
             const double* sf = c_sf + lik * B;
             const double S = lik ? S_bc : S_x;
-            const double a0 = ms[lik * 64];
+            const double a0 = lik ? a01 : a00;
             const double inv = frcp(S + kEps);
             const double ai = a0 * inv;
             double A0 = 0.0;
@@ -237,7 +241,7 @@ void k_guide_survival_wave(DevArgs c) {
                 const double km = ai * c_sm[b];
                 const double araw = alpha_raw(w0, p0, w1, p1, sfb, epsB, km);
                 const bool floored = araw < kEps;
-                const DD db = lgamma_digamma_diff_inl(floored ? kEps : araw, (double)xp[b * 64]);
+                const DD db = lgamma_digamma_diff_inl(floored ? kEps : araw, (double)xp[(long)b * G]);
                 lsum += db.d;
                 const double ga = floored ? 0.0 : d0.dp - db.dp;
                 Wa += ga * araw;
@@ -272,7 +276,10 @@ void k_guide_survival_wave(DevArgs c) {
             row[kPQ0 * RG] = lx;
         }
         if (MIX) {
-            const double cp0 = ms[2 * 64], cp1 = ms[3 * 64];
+            // the concentrations again (as before the draw: same expression, same bits)
+            const double al0 = (double)expf(api0), al1 = (double)expf(api1);
+            const double rs = frcp(al0 + al1) * pa0;
+            const double cp0 = al0 * rs, cp1 = al1 * rs;
             const bool cl0 = cp0 < 1e-5, cl1 = cp1 < 1e-5;
             const double cq0 = cl0 ? 1e-5 : cp0, cq1 = cl1 ? 1e-5 : cp1;
             double gpi0 = g0, gpi1 = g1;
