@@ -317,7 +317,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.A = s->n_max_alleles; d.C = s->n_ctrl; d.E = s->n_edits;
     d.family = s->family; d.flags = s->flags; d.mask_thres = s->mask_thres;
     d.wide_targets = (!is_tiling(*s) && (s->n_targets < 64 || s->max_target_len > 256)) ? 1 : 0;
-    d.lpt = (is_survival(*s) && !is_tiling(*s)) ? kLanesPerTargetSurv : kLanesPerTarget;
+    d.lpt = (is_survival(*s) || is_tiling(*s)) ? kLanesPerTargetNarrow : kLanesPerTarget;
     d.g_off = s->guide_offset; d.t_off = s->target_offset;
     d.G_tot = s->n_guides_total > 0 ? s->n_guides_total : s->n_guides;
     d.sd_prior_scale = s->sd_prior_scale; d.lr0 = s->initial_lr; d.log_lrd = log(s->lrd);
@@ -647,7 +647,7 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
                                       : (const void*)k_guide_wave2<kNormal, false>;
         } else if (c->tiling_rep || c->tiling_wave) {
             const size_t nt = c->tiling_rep ? 64u * c->tiling_rep_w : 64u;
-            lds = (size_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * nt * sizeof(double) + (size_t)2 * d.B * nt * sizeof(float);
+            lds = guide_tiling_lds(d.B, acc, nt, !c->tiling_rep);
             if (c->tiling_rep)
                 fn = d.survival ? (acc ? (const void*)k_guide_tiling_rep<true, true> : (const void*)k_guide_tiling_rep<false, true>)
                                 : (acc ? (const void*)k_guide_tiling_rep<true, false> : (const void*)k_guide_tiling_rep<false, false>);
@@ -733,9 +733,9 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
                        d.rows_v2 && !d.rrow && !d.surv_q0lik && !d.not_loss_owner && d.lpart &&
                        (d.dgq || d.family != kMixture);
     const bool kind2 = d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
-                       d.rows_v2 && !d.rrow && d.lpart && d.lpt == kLanesPerTargetSurv;
+                       d.rows_v2 && !d.rrow && d.lpart && d.lpt == kLanesPerTargetNarrow;
     const bool kind3 = d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov &&
-                       !d.lpart && d.trow_summed && !d.surv_q0lik;
+                       !d.lpart && d.trow_summed && !d.surv_q0lik && d.lpt == kLanesPerTargetNarrow;
     // BEAN_HIP_PARAM_KIND=0 forces the generic build (the test that the specialised builds change nothing)
     static const bool generic_only = getenv("BEAN_HIP_PARAM_KIND") && !strcmp(getenv("BEAN_HIP_PARAM_KIND"), "0");
     const int kind = generic_only ? 0 : (kind1 ? 1 : (kind2 ? 2 : (kind3 ? 3 : 0)));
@@ -916,8 +916,7 @@ static void launch_guide_tiling_wave(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
     const bool acc = (d.flags & kAcc) != 0;
     const dim3 grid((unsigned)(((d.G + 63) / 64 + 7) / 8 * 8) * (unsigned)d.R), block(64);
-    const size_t lds = (size_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * 64 * sizeof(double) +
-                       (size_t)2 * d.B * 64 * sizeof(float);
+    const size_t lds = guide_tiling_lds(d.B, acc, 64, true);
     const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     if (prof) {  // events with the kernel's own timestamps, as in launch_guide_wave
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -950,8 +949,7 @@ static void launch_guide_tiling_rep(bean_hip_ctx* c, hipStream_t stream) {
     const int nt = 64 * waves;
     const int gw = nt / d.R;  // guides per workgroup (R <= kTilingRepMaxR = 64, so >= 1)
     const dim3 grid((unsigned)((d.G + gw - 1) / gw)), block(nt);
-    const size_t lds = (size_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * nt * sizeof(double) +
-                       (size_t)2 * d.B * nt * sizeof(float);
+    const size_t lds = guide_tiling_lds(d.B, acc, (size_t)nt, false);
     const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {  // events with the kernel's own timestamps
@@ -1685,7 +1683,7 @@ extern "C" uint64_t bean_hip_dominant_lds_bytes(const bean_hip_ctx* c) {
     if (d.family == kMultiMixture) {
         if (c->tiling_wide) return 0;
         const uint64_t nt = c->tiling_rep ? 64ull * c->tiling_rep_w : 64ull;
-        return (uint64_t)(3 * d.B + (acc ? 3 * kAMax : 0)) * nt * sizeof(double) + (uint64_t)2 * d.B * nt * sizeof(float);
+        return guide_tiling_lds(d.B, acc, (size_t)nt, !c->tiling_rep);
     }
     if (d.survival) return c->surv_wave ? guide_survival_wave_lds(d.B) : 0;
     if (c->wave_guide && c->wave2) return guide_wave2_lds(d.B, d.tile_targets);

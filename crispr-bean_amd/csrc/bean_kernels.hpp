@@ -209,7 +209,7 @@ struct DevArgs {
     int* q0_ctr;                     // arrivals of k_param's q0 blocks (last one forms gsum), zero between launches
     int q0_blocks;                   // survival: k_param has q0 blocks (n_gamma_blocks of them, kParamBlock guides each)
     int q0_blk0;                     // survival: k_param's guide-part blocks ahead of its q0 blocks (MixtureNormal: the alpha_pi blocks)
-    int lpt;                         // k_param, thin mode: lanes per target (kLanesPerTarget, or 4: survival variant families)
+    int lpt;                         // k_param, thin mode: lanes per target (kLanesPerTarget; kLanesPerTargetNarrow: survival and tiling families)
 };
 
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
@@ -564,10 +564,10 @@ __device__ __forceinline__ double allele_group_sum(double v) {
 // Guide part of k_param for the tiling families: kAMax lanes per guide, lane a owns allele a (its
 // two lgamma/digamma pairs and its alpha_pi update); lane 0 also owns the guide's noise parameters.
 template <bool FINISH, bool ADAM, bool PREP>
-__device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int n_target_blocks,
+__device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int guide_block,
                                                    unsigned long long s_prep, AdamCoef ak,
                                                    double& loss_fin) {
-    const int tid = ((int)blockIdx.x - n_target_blocks) * blockDim.x + threadIdx.x;
+    const int tid = guide_block * blockDim.x + threadIdx.x;
     const int g = tid / kAMax, a = tid % kAMax;
     const bool acc_on = (c.flags & kAcc) != 0;
     const bool fit_noise = acc_on && (c.flags & kFitNoise);
@@ -707,11 +707,12 @@ __device__ __forceinline__ void write_phi_entry(const DevArgs& c, int t, int b, 
 //   C  tables    group map again: one lane per bin edge
 // with the hand-over through LDS.  Wide mode (few or very long targets): one target per block.
 constexpr int kTargetsPerBlock = kParamBlock / kLanesPerTarget;
-// The survival variant families have no table to fill and ~15 (guide, replicate) rows per target: with
-// kLanesPerTargetSurv lanes per target a block takes 64 targets instead of 16 (BASELINE config 5: 313
-// target blocks instead of 1 250, and k_param's three kinds of blocks are resident together).
-constexpr int kLanesPerTargetSurv = 4;
-constexpr int kTargetsPerBlockMax = kParamBlock / kLanesPerTargetSurv;
+// The survival families and the tiling families have no table to fill and few rows per target (~15
+// (guide, replicate) rows; the handful of alleles that carry an edit): with kLanesPerTargetNarrow lanes
+// per target a block takes 64 targets instead of 16.  BASELINE config 5: 313 target blocks instead of
+// 1 250, and k_param's three kinds of blocks are resident together; config 3: k_param 32 -> 27 us.
+constexpr int kLanesPerTargetNarrow = 4;
+constexpr int kTargetsPerBlockMax = kParamBlock / kLanesPerTargetNarrow;
 
 // owner map: the target whose parameters this thread updates (phase B)
 __device__ __forceinline__ void target_of_thread(const DevArgs& c, int& t, bool& active, unsigned bid) {
@@ -751,6 +752,19 @@ __device__ __forceinline__ void group16_allsum(double& a, double& b) {
     b += dpp_f64<0x121, 0xf>(b);
 }
 
+// ... or of kLanesPerTargetNarrow = 4 lanes: xor 2, xor 1 as quad permutations
+__device__ __forceinline__ void group_allsum(int lpt, double& a, double& b) {
+    static_assert(kLanesPerTargetNarrow == 4, "one DPP quad per target");
+    if (lpt == kLanesPerTarget) {
+        group16_allsum(a, b);
+    } else {
+        a += dpp_f64<0x4e, 0xf>(a);  // quad_perm:[2,3,0,1]
+        b += dpp_f64<0x4e, 0xf>(b);
+        a += dpp_f64<0xb1, 0xf>(a);  // quad_perm:[1,0,3,2]
+        b += dpp_f64<0xb1, 0xf>(b);
+    }
+}
+
 // Likelihood gradient of one target w.r.t. its drawn mu_t / y_t: the guide -> target segmented
 // sum (a8), in a fixed order.  Valid in the `active` thread.
 __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool active, double* scratch,
@@ -777,11 +791,12 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
         // runtime layout of the wide path (bean_tiling_wide.hpp: 2 + 2 A, 2 + 2 A + (A - 1))
         const int q_gmu = c.wide_alleles ? 2 + 2 * c.A : (int)kTGmu;
         const int q_gsig = c.wide_alleles ? 2 + 2 * c.A + A1 : (int)kTGsig;
-        const int lg = threadIdx.x & (kLanesPerTarget - 1);
+        const int lpt = c.lpt;
+        const int lg = threadIdx.x & (lpt - 1);
         double a = 0.0, b = 0.0;
         if (t < c.T) {
             const double sd = c.survival ? 0.0 : exp(c.y_t[t]);  // survival: no sd latent
-            for (int k = c.e2a_ptr[t] + lg; k < c.e2a_ptr[t + 1]; k += kLanesPerTarget) {
+            for (int k = c.e2a_ptr[t] + lg; k < c.e2a_ptr[t + 1]; k += lpt) {
                 const int slot = c.e2a_idx[k];
                 const int a1 = slot % A1, gs = slot / A1;
                 const long o = (long)a1 * c.G + gs;
@@ -790,7 +805,7 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
                 if (!c.survival) b += trow_sum(c, q_gsig + a1, gs) * sd * sd / c.sig_a[o];
             }
         }
-        group16_allsum(a, b);
+        group_allsum(lpt, a, b);
         gmu = a;
         gy = b;
         return;
@@ -837,15 +852,7 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
                     }
             }
         }
-        if (lpt == kLanesPerTarget) {
-            group16_allsum(a, b);
-        } else {  // kLanesPerTargetSurv = 4 lanes: xor 2, xor 1 as quad permutations
-            static_assert(kLanesPerTargetSurv == 4, "one DPP quad per target");
-            a += dpp_f64<0x4e, 0xf>(a);  // quad_perm:[2,3,0,1]
-            b += dpp_f64<0x4e, 0xf>(b);
-            a += dpp_f64<0xb1, 0xf>(a);  // quad_perm:[1,0,3,2]
-            b += dpp_f64<0xb1, 0xf>(b);
-        }
+        group_allsum(lpt, a, b);
         gmu = a;
         gy = b;
     }
@@ -1197,7 +1204,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(c.dgq != nullptr || c.family != kMixture);
     }
     if (KIND == 2) {  // the survival variant families on the wave-form path (thin mode, unsharded parameters)
-        __builtin_assume(c.lpt == kLanesPerTargetSurv);
+        __builtin_assume(c.lpt == kLanesPerTargetNarrow);
         __builtin_assume(c.survival != 0);
         __builtin_assume(c.family != kMultiMixture);
         __builtin_assume(!c.wide_targets);
@@ -1209,7 +1216,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(c.lpart != nullptr);
     }
     if (KIND == 3) {  // tiling (MultiMixtureNormal) in the register-resident wave form, thin mode
-        __builtin_assume(c.lpt == kLanesPerTarget);
+        __builtin_assume(c.lpt == kLanesPerTargetNarrow);
         __builtin_assume(c.family == kMultiMixture);
         __builtin_assume(!c.wide_targets);
         __builtin_assume(!c.wide_alleles);
@@ -1224,7 +1231,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     // one's totals, ~15 us at BASELINE config 5 against ~10 us of an alpha_pi guide block and ~5 us of a
     // target block), so they are dispatched first, the guide blocks next and the target blocks last.
     // (As a tail of the guide blocks - this round's first form - the draws began when the alpha_pi update
-    // ended: k_param 33 us.  As blocks of their own that waited for a guide block's flag: 35 us.)
+    // ended: k_param 33 us.  As blocks of their own that waited for a guide block's flag: 35 us.  Without a
+    // q0 site the order of guide and target blocks makes no difference: measured on configs 1 and 3.)
     unsigned bid = blockIdx.x;
     if (c.q0_blocks) {
         const unsigned ntb = (unsigned)n_target_blocks, nq0 = (unsigned)c.n_gamma_blocks, ngd = (unsigned)c.q0_blk0;
@@ -1511,8 +1519,9 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         }
         BEAN_STAMP_KP(4);
     } else if (c.family == kMultiMixture) {
-        if (c.wide_alleles) param_guide_tiling_wide<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
-        else param_guide_tiling<FINISH, ADAM, PREP>(c, n_target_blocks, s_prep, ak, loss_fin);
+        const int guide_block = (int)bid - n_target_blocks;
+        if (c.wide_alleles) param_guide_tiling_wide<FINISH, ADAM, PREP>(c, guide_block, s_prep, ak, loss_fin);
+        else param_guide_tiling<FINISH, ADAM, PREP>(c, guide_block, s_prep, ak, loss_fin);
         if (c.survival) {
             // per-guide baseline growth mu_negctrl ~ N(m0, s0): sampled in the model only
             // (survival_model.py:479-483), i.e. a fresh prior draw each step

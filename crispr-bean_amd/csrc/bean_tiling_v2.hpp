@@ -32,6 +32,14 @@
 
 namespace bean {
 
+// Dynamic LDS of the register-resident tiling guide kernels, nt threads per workgroup: three columns of B
+// doubles per thread (+ the accessibility pieces); k_guide_tiling_wave also stages the counts.
+__host__ __device__ inline size_t guide_tiling_lds(int B, bool acc, size_t nt, bool stages_counts) {
+    return (size_t)(3 * B + (acc ? 3 * kAMax : 0)) * nt * sizeof(double) +
+           (stages_counts ? (size_t)2 * B * nt * sizeof(float) : 0);
+}
+
+
 constexpr int kTilingRepMaxR = 64;  // more replicates than that: the wave form + k_sum_trow
 // waves per workgroup of k_guide_tiling_rep: of 1, 2, 4 the one that fills most lanes with (replicate,
 // guide) pairs, the smaller on a tie (R = 5: 60 / 64, 125 / 128, 255 / 256 -> 4; measured at config 3:
@@ -69,7 +77,6 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
     double* gs = tls + B * NT + lane;        // d nll / d e[b]    at gs[b * NT]
     double* ds = tls + 2 * B * NT + lane;    // digamma diffs     at ds[b * NT]
     double* ps = tls + 3 * B * NT + lane;    // ACC: pe, d pe / d pi, d pe / d l at ps[(k * kAMax + a) * NT]
-    float* xs = (float*)(tls + (3 * B + (ACC ? 3 * kAMax : 0)) * NT) + lane;  // xs[(lik * B + b) * NT]
 
     const bool rgm = c.rg[(long)r * G + g] != 0;
     // both pi sites, the Multinomial and the count likelihoods are masked by repguide_mask in tiling
@@ -94,7 +101,11 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
         }
     };
 
-    // counts of both likelihoods: one batch of loads, then LDS
+    // totals of the guide's counts over the conditions, both likelihoods: one batch of loads.  (The
+    // likelihood loop reads the counts again from global memory, one coalesced row per condition: staged
+    // in LDS they made the workgroup's 40 KB a quarter of the CU's LDS EXACTLY, and whenever the CU could
+    // not give all of it the grid ran as two rounds - steps of 181 or 280 us from one run to the next.)
+    double n_x = 0.0, n_bc = 0.0;
     {
         float xv[2][kBMax];
 #pragma unroll
@@ -105,14 +116,15 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
         }
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
-            const int bb = b < B ? b : B - 1;
-            xs[(0 * B + bb) * NT] = xv[0][b];
-            xs[(1 * B + bb) * NT] = xv[1][b];
+            if (b < B) {
+                n_x += (double)xv[0][b];
+                n_bc += (double)xv[1][b];
+            }
         }
         for (int b = kBMax; b < B; ++b) {  // more conditions than the register batch holds (B <= kBCap)
             const long xo = ((long)r * B + b) * G + g;
-            xs[(0 * B + b) * NT] = c.X[xo];
-            xs[(1 * B + b) * NT] = use_bc ? c.Xbc[xo] : 0.f;
+            n_x += (double)c.X[xo];
+            n_bc += use_bc ? (double)c.Xbc[xo] : 0.0;
         }
     }
     const double pa0 = c.pi_a0[g];
@@ -210,14 +222,12 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
 #pragma unroll 1
         for (int lik = 0; lik < 2; ++lik) {
             if (lik == 1 && !use_bc) break;
-            const float* xp = xs + lik * B * NT;
+            const float* xp = (lik ? c.Xbc : c.X) + (long)r * B * G + g;  // condition b at xp[b * G]
             const double* sf = (lik ? c.sf_bc : c.sf) + r * B;
-            double nn = 0.0, S = 0.0;
+            const double nn = lik ? n_bc : n_x;
+            double S = 0.0;
 #pragma unroll 1
-            for (int b = 0; b < B; ++b) {
-                nn += (double)xp[b * NT];
-                S += es[b * NT] * sf[b];
-            }
+            for (int b = 0; b < B; ++b) S += es[b * NT] * sf[b];
             if (!(nn > (double)c.mask_thres)) continue;
             const double a0 = lik ? c.a0_bc[g] : c.a0[g];
             const double inv = frcp(S + kEps);
@@ -230,7 +240,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
                 anyfl = anyfl || floored;
                 const double al = floored ? kEps : araw;
                 A0 += al;
-                const DD db = lgamma_digamma_diff_inl(al, (double)xp[b * NT]);
+                const DD db = lgamma_digamma_diff_inl(al, (double)xp[(long)b * G]);
                 lsum += db.d;
                 ds[b * NT] = db.dp;
                 Ua += floored ? 0.0 : araw;

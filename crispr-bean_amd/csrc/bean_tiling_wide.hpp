@@ -332,9 +332,9 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
 // Same algebra as param_guide_tiling (Dirichlet normalisers of the A-component pi site, chain to alpha_pi
 // through the guide's and the model's concentration maps: model.py:938 and 646-651).
 template <bool FINISH, bool ADAM, bool PREP>
-__device__ __forceinline__ void param_guide_tiling_wide(const DevArgs& c, int n_target_blocks,
+__device__ __forceinline__ void param_guide_tiling_wide(const DevArgs& c, int guide_block,
                                                         unsigned long long s_prep, AdamCoef ak, double& loss_fin) {
-    const int g = ((int)blockIdx.x - n_target_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int g = guide_block * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const bool acc_on = (c.flags & kAcc) != 0;
     const bool fit_noise = acc_on && (c.flags & kFitNoise);
