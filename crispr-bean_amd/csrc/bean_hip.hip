@@ -317,7 +317,15 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.A = s->n_max_alleles; d.C = s->n_ctrl; d.E = s->n_edits;
     d.family = s->family; d.flags = s->flags; d.mask_thres = s->mask_thres;
     d.wide_targets = (!is_tiling(*s) && (s->n_targets < 64 || s->max_target_len > 256)) ? 1 : 0;
-    d.lpt = (is_survival(*s) || is_tiling(*s)) ? kLanesPerTargetNarrow : kLanesPerTarget;
+    // lanes per target of k_param's target part: 4 where a target has few rows to add (survival: ~15
+    // (guide, replicate) rows; tiling: the alleles carrying an edit - unless the table is unfiltered and an
+    // edit sits in dozens of them), 16 otherwise (sorting variant families: the Phi table's 2 B edges)
+    d.lpt = kLanesPerTarget;
+    if (is_tiling(*s)) {
+        if ((int64_t)s->n_a2e_nnz <= 16 * (int64_t)s->n_targets) d.lpt = kLanesPerTargetNarrow;
+    } else if (is_survival(*s)) {
+        d.lpt = kLanesPerTargetNarrow;
+    }
     d.g_off = s->guide_offset; d.t_off = s->target_offset;
     d.G_tot = s->n_guides_total > 0 ? s->n_guides_total : s->n_guides;
     d.sd_prior_scale = s->sd_prior_scale; d.lr0 = s->initial_lr; d.log_lrd = log(s->lrd);
