@@ -3629,6 +3629,16 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
         const DD2 d = lgamma_digamma_diff2(a[i], x[i], a[j], x[j]);
         o0[i] = d.a.d;
         o1[i] = d.a.dp;
+    } else if (op == 6 || op == 7) {
+        // the Dirichlet-over-all-guides site's gammas as k_param's q0 blocks form them (float32 floor): from
+        // the plain sampler (6) and from the one that leaves the rejection loop out where the boost factor
+        // has already put the draw on the floor (7) - the same values
+        unsigned long long seed;
+        memcpy(&seed, &x[0], 8);
+        Rng rng(seed, kSiteQ0, (unsigned long long)i, 0ull);
+        const GammaPair gp = op == 6 ? sample_gamma_pair(a[i], b[i], rng) : sample_gamma_pair_floor32(a[i], b[i], rng);
+        o0[i] = (double)fmaxf((float)gp.g0, 1.17549435e-38f);
+        o1[i] = (double)fmaxf((float)gp.g1, 1.17549435e-38f);
     }
 }
 

@@ -116,6 +116,26 @@ def test_dirichlet_sampler_distribution(engine, a, b):
         assert np.mean(p0 < 1e-100) > 0.99
 
 
+@pytest.mark.parametrize("a,b", [(1e-5, 1e-5), (1e-5, 0.0), (2e-3, 1e-5), (0.05, 0.3), (0.9, 1e-4), (3.0, 1e-5)])
+def test_float32_floor_sampler_returns_the_plain_samplers_values(engine, a, b):
+    """The survival q0 site (k_param's q0 blocks) keeps max((float)g, FLT_MIN) of each gamma; its sampler
+    leaves the rejection loop out where U^(1/alpha) < FLT_MIN / 128 has decided that already.  Same generator
+    position, same values as the plain sampler, draw for draw - including the draws that do NOT end on the
+    floor (alpha = 2e-3: 16 %, 0.05: 99 %)."""
+    n = 300_000
+    seed = np.zeros(n)
+    seed[:1] = np.frombuffer(np.uint64(4242).tobytes(), dtype=np.float64)
+    g0, g1 = engine.test_special(6, np.full(n, a), seed, np.full(n, b))
+    f0, f1 = engine.test_special(7, np.full(n, a), seed, np.full(n, b))
+    assert torch.equal(g0, f0) and torch.equal(g1, f1)
+    floor = np.float64(np.float32(1.17549435e-38))
+    frac = float((g0.cpu().numpy() == floor).mean())
+    if a <= 1e-5:
+        assert frac > 0.998
+    elif a >= 0.05:
+        assert frac < 0.05
+
+
 # ------------------------------------------------------------------ ELBO parity
 def _compare(engine, family, data, kw, seed=7, step=3, tol_loss=(1e-9, 1e-6), tol_grad=(5e-7, 2e-5),
              perturb=0.3, eng_kw=None):
@@ -569,8 +589,9 @@ def _compare_survival(engine, family, data, kw, seed=7, step=2):
         for k, g in grads.items():
             ref = ref_grads[k].double().reshape(-1)
             err = (g.cpu().double().reshape(-1) - ref).abs().max().item()
-            # torch evaluates the implicit gradient of the float32 Dirichlet(q0) site in float32
-            tol = 2e-4 if (k in ("q0", "initial_abundance") and mode == "ref") else tg
+            # torch evaluates the implicit gradient of the float32 Dirichlet(q0) site in float32 (the float64
+            # pass above holds the same gradient to 5e-7; 2.1e-4 at 2 600 guides)
+            tol = 3e-4 if (k in ("q0", "initial_abundance") and mode == "ref") else tg
             assert err <= tol * (ref.abs().max().item() + 1e-30), (mode, k, err)
     eng.set_noise(draws)
     loss_b, grads_b = eng.elbo_grad(step=step, seed=seed)
@@ -588,6 +609,8 @@ def _compare_survival(engine, family, data, kw, seed=7, step=2):
     (dict(n_guides=65, n_reps=1, times=(0.0, 2.0, 4.0, 6.0, 8.0, 10.0, 12.0, 14.0)), {}),
     (dict(n_guides=120, n_reps=2, times=tuple(float(t) for t in range(0, 22, 2))), {}),  # 11 timepoints
     (dict(n_guides=90, n_reps=2, times=tuple(float(t) for t in range(0, 23))), {}),  # 23 timepoints (> 16)
+    # 37 guides x 4 replicates = 148 rows per target: k_param's 4 lanes per target loop over them ten times
+    (dict(n_guides=2600, n_reps=4, guides_per_target=37), {}),
 ])
 def test_survival_mixture_matches_oracle(engine, gen_kw, kw):
     data = make_survival_variant_screen(seed=4, **gen_kw)
