@@ -1,5 +1,6 @@
-"""Diagnostic (-DBEAN_STAMP=5 build only, BEAN_HIP_LIB=<that build>): where k_param's block roles of the
-survival q0 site sit on the 100 MHz real-time clock (BASELINE config 5: 100k guides x 3 replicates).
+"""Diagnostic (-DBEAN_STAMP=5 build only, BEAN_HIP_LIB=<that build>): where k_param's block roles sit on the
+100 MHz real-time clock (default: BASELINE config 5, 100k guides x 3 replicates, with the survival q0 site;
+`metric [n_guides]`: the sorting metric shape).
 One record per block (role order: targets, alpha_pi blocks, q0 blocks): 0 start, 1 q0 updated,
 3 draws done, 4 counted in, 7 end."""
 import ctypes
@@ -13,16 +14,21 @@ import bean_amd  # noqa: F401
 from bean_amd import _lib, engine
 from bean_amd.preprocessing import synthetic as syn
 
-G, R = 100000, 3
-data = syn.make_survival_variant_screen(G, R, seed=20240506).to("cuda:0")
+CONFIG = sys.argv[1] if len(sys.argv) > 1 else "survival"
+if CONFIG == "survival":
+    G, R = 100000, 3
+    data = syn.make_survival_variant_screen(G, R, seed=20240506).to("cuda:0")
+else:  # the metric shape: no q0 blocks, 16 lanes per target
+    G, R = int(sys.argv[2]) if len(sys.argv) > 2 else 50000, 5
+    data = syn.make_sorting_variant_screen(G, R, seed=20240502).to("cuda:0")
 eng = engine.HipSVI("MixtureNormal", data, num_steps=100)
 eng.run(20, graph_chunk=0)
 torch.cuda.synchronize()
 T = int(data.n_targets)
 gpb = 256
-lpt = 4  # kLanesPerTargetSurv
+lpt = 4 if CONFIG == "survival" else 16  # kLanesPerTargetNarrow / kLanesPerTarget
 ntb, ngb = (T * lpt + 255) // 256, (G + 255) // 256
-ndb = (G + gpb - 1) // gpb
+ndb = (G + gpb - 1) // gpb if CONFIG == "survival" else 0
 nrec = ntb + ngb + ndb
 buf = np.zeros(nrec * 8, dtype=np.uint64)
 lib = _lib.load()
@@ -43,4 +49,5 @@ def show(name, rows, cols):
 
 show("target blocks", s[:ntb], [0, 7])
 show("alpha_pi blocks", s[ntb:ntb + ngb], [0, 7])
-show("q0 blocks", s[ntb + ngb:], [0, 1, 3, 4, 7])
+if ndb:
+    show("q0 blocks", s[ntb + ngb:], [0, 1, 3, 4, 7])
