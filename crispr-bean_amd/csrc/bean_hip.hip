@@ -44,6 +44,7 @@ struct bean_hip_ctx {
     std::vector<hipGraphExec_t> graphs_fused;  // [k]: 2^(k+1) launches of k_step_wave2
     long long* loss_acc;  // library-owned fixed-point loss accumulators, kLossWords per loss_hist slot
     int* tile_targets_dev;
+    int* live_slots;   // tiling: compact list of the allele slots that hold an allele (own allocation, (A - 1) G ints)
     bool tiling_wave;  // tiling families, default: k_guide_tiling_wave (BEAN_HIP_TILING=block: k_guide_tiling)
     bool tiling_wide;  // more alleles per guide than this build's kAMax: bean_tiling_wide.hpp
     int tiling_rep_w;  // ... with this many waves per workgroup
@@ -304,6 +305,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->tile_svi = false;
     c->tile_ready = false;
     c->tile_tab = nullptr;
+    c->live_slots = nullptr;
     c->n_tiles = c->tile_ntm = c->tile_gbm = c->tile_blocks = 0;
     c->step_sizes = nullptr;
     c->step_sizes_cap = 0;
@@ -545,6 +547,7 @@ extern "C" int bean_hip_destroy(bean_hip_ctx* c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->workspace) (void)hipFree(c->workspace);
     if (c->tile_tab) (void)hipFree(c->tile_tab);
+    if (c->live_slots) (void)hipFree(c->live_slots);
     if (c->step_sizes) (void)hipFree(c->step_sizes);
     if (c->dargs_dev) (void)hipFree(c->dargs_dev);
     if (c->loss_acc) (void)hipFree(c->loss_acc);
@@ -642,6 +645,40 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
         if (nt < 1 || nt > 64) return fail("bean_hip_prepare: guides are not sorted by target (BEAN_BUF_GUIDE_TO_TARGET)");
         if (nt != c->d.tile_targets) drop_graph(c);
         c->d.tile_targets = nt;
+    }
+    if (c->d.family == kMultiMixture) {
+        // k_allele's work list: the allele slots that hold an allele, in (a1, g) order.  Setup only: the mask
+        // and the CSR row pointers come to the host once (G A bytes + (G (A - 1) + 1) ints).
+        const DevArgs& d = c->d;
+        const long G = d.G, A = d.A, A1 = d.A - 1;
+        std::vector<uint8_t> mask((size_t)(G * A));
+        std::vector<int> ptr((size_t)(G * A1 + 1));
+        HIP_OK(hipMemcpyAsync(mask.data(), d.amask, mask.size(), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(ptr.data(), d.a2e_ptr, ptr.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        std::vector<int> live;
+        live.reserve((size_t)(G * A1));
+        for (long a1 = 0; a1 < A1; ++a1)
+            for (long g = 0; g < G; ++g) {
+                const long slot = g * A1 + a1;
+                if (mask[(size_t)(g * A + a1 + 1)] != 0 || ptr[(size_t)slot + 1] > ptr[(size_t)slot]) live.push_back((int)(a1 * G + g));
+            }
+        if (!c->live_slots) HIP_OK(hipMalloc(&c->live_slots, (size_t)(G * A1) * sizeof(int)));
+        if (!live.empty())
+            HIP_OK(hipMemcpyAsync(c->live_slots, live.data(), live.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));  // `live` goes out of scope
+        // the slots left out hold what k_allele would write there: zeros
+        {
+            const long n_tab = (long)d.B * A1 * G;
+            HIP_OK(hipMemsetAsync((void*)d.tabP, 0, (size_t)n_tab * sizeof(double), stream));
+            HIP_OK(hipMemsetAsync((void*)d.tabPmu, 0, (size_t)n_tab * sizeof(double), stream));
+            HIP_OK(hipMemsetAsync((void*)d.tabPy, 0, (size_t)n_tab * sizeof(double), stream));
+            HIP_OK(hipMemsetAsync((void*)d.mu_a, 0, (size_t)(A1 * G) * sizeof(double), stream));
+            if (d.sig_a) HIP_OK(hipMemsetAsync((void*)d.sig_a, 0, (size_t)(A1 * G) * sizeof(double), stream));
+            drop_graph(c);
+        }
+        c->d.live_slots = c->live_slots;
+        c->d.n_live_slots = (int)live.size();
     }
     {
         // more than 64 KB of dynamic LDS per workgroup (many conditions): the kernel has to be told
@@ -1074,8 +1111,8 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         return;
     }
     if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
-        const long n = (long)(d.A - 1) * d.G;
-        hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
+        const long n = d.n_live_slots;
+        if (n > 0) hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
     }
     if (c->tiling_rep) {
         launch_guide_tiling_rep(c, stream);

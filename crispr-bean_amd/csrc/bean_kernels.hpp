@@ -185,6 +185,8 @@ struct DevArgs {
     const int *a2e_ptr, *a2e_idx;  // (G*(A-1)+1), (nnz): slot = g*(A-1) + (a-1)
     const int *e2a_ptr, *e2a_idx;  // (E+1), (nnz): slots containing each edit
     const uint8_t* amask;          // (G, A)
+    const int* live_slots;         // tiling: the n_live_slots allele slots k_allele fills, as a1 * G + g (bean_hip_prepare)
+    int n_live_slots;
     double *mu_a, *sig_a;          // (A-1, G) allele mean / scale of the current draw
     // survival (exp(mu t) growth instead of Normal-CDF bins)
     int survival;
@@ -2710,11 +2712,16 @@ __device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int
     }
 }
 
+// One thread per slot that holds an allele (DevArgs::live_slots, built once by bean_hip_prepare: the
+// slots in (a1, g) order whose mask is set or whose edit list is not empty).  The other slots' tables are
+// zero from the start and stay zero.  At BASELINE config 3 that is 193k of 350k slots, and because the
+// empty ones are scattered (a wave of 64 consecutive guides at slot a1 nearly always held a few alleles)
+// the launch ran every wave for half the lanes.
 __global__ __launch_bounds__(256) void k_allele(DevArgs c) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int A1 = c.A - 1;
-    if (idx >= (long)A1 * c.G) return;
-    allele_slot_tables(c, (int)(idx / c.G), (int)(idx % c.G));
+    if (idx >= c.n_live_slots) return;
+    const int s = c.live_slots[idx];  // a1 * G + g
+    allele_slot_tables(c, s / c.G, s % c.G);
 }
 
 #if defined(BEAN_AB_KERNELS) && BEAN_AMAX <= 8  // the block form: an A/B reference of the default allele count only
