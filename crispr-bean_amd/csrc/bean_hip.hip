@@ -633,7 +633,7 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c->d);
     HIP_OK(hipGetLastError());
     if (c->wave_guide) {
-        // LDS sizing of k_guide_wave: the one host read-back of the library (4 bytes, setup only)
+        // LDS sizing of k_guide_wave: a host read-back (4 bytes, setup only; the other one is the tiling work list below)
         HIP_OK(hipMemsetAsync(c->tile_targets_dev, 0, sizeof(int), stream));
         const int tiles = (c->d.G + 63) / 64;
         hipLaunchKernelGGL(k_tile_targets, dim3((tiles + 255) / 256), dim3(256), 0, stream, c->d.g2t, c->d.G,

@@ -223,8 +223,10 @@ int bean_hip_destroy(bean_hip_ctx* ctx);
 int bean_hip_bind(bean_hip_ctx* ctx, int slot, void* device_ptr, uint64_t nbytes);
 
 /* Validate that every slot the family needs is bound, and run the one-off
- * data-only precomputation (masks, log-factorial constants of the likelihoods).
- * Must be called after the data slots are bound and before any step. */
+ * data-only precomputation (masks, log-factorial constants of the likelihoods;
+ * tiling: the list of allele slots that hold an allele, for which the allele
+ * mask and the CSR row pointers are read back to the host once).  Synchronises
+ * the stream.  Must be called after the data slots are bound and before any step. */
 int bean_hip_prepare(bean_hip_ctx* ctx, void* stream);
 
 /* One ELBO evaluation with gradients: draws the step's noise (or reads the
