@@ -700,15 +700,14 @@ __device__ __forceinline__ void write_phi_entry(const DevArgs& c, int t, int b, 
     c.tabPy[o] = -(ufh - ufl) * inv * dsig_dy;
 }
 
-// Thin mode (the usual one): a target block of kParamBlock threads holds kTargetsPerBlock targets and
-// works in three phases with two thread -> work maps:
-//   A  sums      kLanesPerTarget lanes per target (group map): the target's (guide, replicate) rows
+// Thin mode (the usual one): a target block of kParamBlock threads holds kParamBlock / DevArgs::lpt targets
+// and works in three phases with two thread -> work maps:
+//   A  sums      lpt lanes per target (group map): the target's (guide, replicate) rows
 //   B  scalar    ONE lane per target, packed into the block's first lanes (owner map): priors,
 //                entropies, ClippedAdam, the next draw.  Packing matters: this is a long serial chain,
 //                and a wave issues it whether one or all of its lanes are active
 //   C  tables    group map again: one lane per bin edge
 // with the hand-over through LDS.  Wide mode (few or very long targets): one target per block.
-constexpr int kTargetsPerBlock = kParamBlock / kLanesPerTarget;
 // The survival families and the tiling families have no table to fill and few rows per target (~15
 // (guide, replicate) rows; the handful of alleles that carry an edit): with kLanesPerTargetNarrow lanes
 // per target a block takes 64 targets instead of 16.  BASELINE config 5: 313 target blocks instead of
@@ -1182,7 +1181,8 @@ __device__ __forceinline__ void q0_draws_and_totals(const DevArgs& c, int gb, in
 }
 
 // -------------------------------------------------------------------- k_param
-// grid = n_target_blocks + n_guide_blocks, 256 threads.
+// grid = n_target_blocks + n_guide_blocks (+ the q0 blocks of the survival families with a
+// Dirichlet-over-all-guides site), 256 threads; the roles' dispatch order: see `bid` below.
 // KIND 1: the variant sorting families on the wave-form path in thin mode (what a `bean run ... variant`
 // fit of a sorting screen launches 2 000 times).  The launch conditions are stated to the compiler, which
 // drops the other families' code: 121 -> <= 96 VGPRs without scratch (five instead of four resident
