@@ -27,7 +27,8 @@ namespace bean {
 // used (coalesced rows, twice per step).  BASELINE config 5: 92.7 -> 85.8 us per step.  The kernel is
 // VALU-bound (SQ_INSTS_VALU x 4 cycles / 1 024 SIMDs = 39 us) and its 4 689 waves still do not fit the
 // 4 096 slots of four waves per SIMD; five waves per SIMD (96 VGPRs: 52 spilled) measured 88.2 us, six
-// (80 VGPRs: 78 spilled) 96.3 us.
+// (80 VGPRs: 78 spilled) 96.3 us.  Two timepoints per iteration through lgamma_digamma_diff2 (the metric kernel's
+// two side-by-side chains): 85.8 against 86.2-86.5 us, with 33 instead of 11 spilled registers - not adopted.
 __host__ __device__ inline size_t guide_survival_wave_lds(int B) {
     return ((size_t)4 * B + (size_t)2 * B * 64) * sizeof(double);
 }
