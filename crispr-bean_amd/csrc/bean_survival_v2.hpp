@@ -29,6 +29,12 @@ namespace bean {
 // 4 096 slots of four waves per SIMD; five waves per SIMD (96 VGPRs: 52 spilled) measured 88.2 us, six
 // (80 VGPRs: 78 spilled) 96.3 us.  Two timepoints per iteration through lgamma_digamma_diff2 (the metric kernel's
 // two side-by-side chains): 85.8 against 86.2-86.5 us, with 33 instead of 11 spilled registers - not adopted.
+// What the launch's 66 us are (scripts/stamps_surv_guide.py, every wave's start and end on the real-time clock):
+// 4 096 waves are resident for the first 25 us; the four waves of a SIMD finish one after another (25, 37, 45,
+// 53 us: the oldest wave issues first), and the 593 waves that are left start on the SIMDs that free up first and
+// run until 66 us - 593 of the 1 024 SIMDs do five waves' work (5 x 13.2 us) and the others four.  Raising the late
+// waves' priority (s_setprio) makes THEM finish early and the older waves of the same SIMDs late: 64.2 us.
+// The launch is at its issue bound for whole-wave work items; the balance is a property of 4 689 / 1 024.
 __host__ __device__ inline size_t guide_survival_wave_lds(int B) {
     return ((size_t)4 * B + (size_t)2 * B * 64) * sizeof(double);
 }
@@ -52,6 +58,7 @@ void k_guide_survival_wave(DevArgs c) {
     const bool valid = g < G;
     const StepCtr ctr = *c.ctrB;
     double loss = 0.0;
+    BEAN_STAMP_RT(wg, 0);
 
     // LDS: [4][B] sf, sf_bc, sample mask, time | [B][64] P0 | [B][64] P1
     double* cst = sls;
@@ -351,6 +358,7 @@ void k_guide_survival_wave(DevArgs c) {
         loss = nll;
     }
     const double tot = wave_sum(loss);
+    BEAN_STAMP_RT(wg, 7);
     if (lane == 0) {
         wave_loss_out(c, ctr.slot, wg, tot);
         if (wg == 0) publish_ctr(c, ctr);
