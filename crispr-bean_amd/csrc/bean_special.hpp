@@ -21,27 +21,41 @@ struct DD {
 // ---------------------------------------------------------------------------
 // Lean float64 primitives.  The ocml log/division are correctly rounded but cost
 // ~100 / ~12 instructions (double-double arithmetic); the ELBO needs ~1e-15
-// relative accuracy, which these reach in ~28 / 5 instructions.  Arguments are
+// relative accuracy, which these reach in ~28 / 4 instructions.  Arguments are
 // positive finite normal numbers everywhere they are used.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double frcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: ~2^-26 relative
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: ~2^-26 relative
+    // one third-order step, 1 / x = r (1 + e + e^2 + ...) with e = 1 - x r: the remainder e^3 is 2^-78
+    // (three FMAs; two Newton steps took four)
+    const double e = fma(-x, r, 1.0);
+    return fma(fma(e, e, e), r, r);
 }
 
 // natural log of a positive normal double: x = m 2^e, m in [sqrt(1/2), sqrt(2)),
 // log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, series to s^19.
-__device__ __forceinline__ double flog(double x) {
+// In two halves, so that a caller with several logs (and other reciprocals) to form can take all its
+// reciprocals from ONE v_rcp_f64 (batched inversion: stirling_diff): flog_arg splits x = (1 + f) 2^e, and
+// flog_from finishes the log given 1 / (2 + f).
+struct LogArg {
+    double f;   // m - 1, m in [sqrt(1/2), sqrt(2))
+    double ed;  // the exponent e
+};
+__device__ __forceinline__ LogArg flog_arg(double x) {
 #pragma clang fp contract(off)  // every rounding pinned: the same bits wherever this is inlined
     int e = __builtin_amdgcn_frexp_exp(x);
     double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
     const bool lo = m < 0.70710678118654752440;
     m = lo ? m + m : m;
     e = lo ? e - 1 : e;
-    const double f = m - 1.0;
-    const double s = f * frcp(2.0 + f);
+    LogArg a;
+    a.f = m - 1.0;
+    a.ed = (double)e;
+    return a;
+}
+__device__ __forceinline__ double flog_from(const LogArg& a, double rinv) {  // rinv = 1 / (2 + a.f)
+#pragma clang fp contract(off)
+    const double s = a.f * rinv;
     const double z = s * s;
     double p = 2.0 / 19.0;
     p = fma(p, z, 2.0 / 17.0);
@@ -52,11 +66,15 @@ __device__ __forceinline__ double flog(double x) {
     p = fma(p, z, 2.0 / 7.0);
     p = fma(p, z, 2.0 / 5.0);
     p = fma(p, z, 2.0 / 3.0);
-    const double ed = (double)e;
     // e*ln2 split so that the leading product is exact for |e| < 2^11
-    const double hi = ed * 6.93147180369123816490e-01;
-    const double lo2 = fma(ed, 1.90821492927058770002e-10, s * z * p);
+    const double hi = a.ed * 6.93147180369123816490e-01;
+    const double lo2 = fma(a.ed, 1.90821492927058770002e-10, s * z * p);
     return hi + fma(2.0, s, lo2);
+}
+__device__ __forceinline__ double flog(double x) {
+#pragma clang fp contract(off)
+    const LogArg a = flog_arg(x);
+    return flog_from(a, frcp(2.0 + a.f));
 }
 
 // Stirling tails, valid to ~1e-14 absolute for z >= 10 (r = 1/z, w = r*r).
@@ -142,19 +160,38 @@ __device__ __forceinline__ double digamma(double z) {
 }
 
 // The series part of D(a, x) for shifted arguments z1 >= kShiftLo (from a, shift product P1 and its
-// derivative Q1) and z2 >= kShift: roundings pinned.  With P1 == 1 (no shift) log P1 = 0 and Q1 = 0 exactly,
-// so the correction is added unconditionally.
+// derivative Q1) and z2 >= kShift: roundings pinned.  With P1 == 1 (no shift) log P1 = 0 and Q1 = 0 exactly.
+// It needs 1 / z and log z of three numbers (z1, z2, P1), and the log has a reciprocal of its own inside;
+// a v_rcp_f64 costs 3.3 float64 FMAs of issue time, 7 with its two Newton steps
+// (profiles/r01_valu_issue.txt).  log_and_rcp takes both reciprocals from one: 1 / z = d / (z d),
+// 1 / d = z / (z d) with d = 2 + f in [1.7, 2.42] (three multiplications + one frcp instead of two frcp).
+// (All six from ONE reciprocal - 17 multiplications - was measured too: the twelve values it keeps live
+// cost more in spilled registers than the reciprocals it saves.)
+struct LogRcp {
+    double l, r;  // log z, 1 / z
+};
+__device__ __forceinline__ LogRcp log_and_rcp(double z) {
+#pragma clang fp contract(off)
+    const LogArg a = flog_arg(z);
+    const double d = 2.0 + a.f;
+    const double inv = frcp(z * d);
+    LogRcp o;
+    o.r = inv * d;
+    o.l = flog_from(a, inv * z);
+    return o;
+}
 __device__ __forceinline__ void stirling_diff(double z1, double z2, double P1, double Q1, double& d, double& dp) {
 #pragma clang fp contract(off)
-    const double l1 = flog(z1), l2 = flog(z2);
-    const double r1 = frcp(z1), r2 = frcp(z2);
+    const LogRcp k1 = log_and_rcp(z1), k2 = log_and_rcp(z2);
+    const double l1 = k1.l, l2 = k2.l, r1 = k1.r, r2 = k2.r;
     const double w1 = r1 * r1, w2 = r2 * r2;
     const double head = (z2 - 0.5) * l2 - (z1 - 0.5) * l1 - (z2 - z1);
     d = head + (stirling_lgamma_tail(r2, w2) - stirling_lgamma_tail_long(r1, w1));
     dp = (l2 - l1) - 0.5 * (r2 - r1) - (stirling_digamma_tail(w2) - stirling_digamma_tail_long(w1));
     if (P1 != 1.0) {
-        d += flog(P1);
-        dp += Q1 * frcp(P1);
+        const LogRcp kP = log_and_rcp(P1);
+        d += kP.l;
+        dp += Q1 * kP.r;
     }
 }
 // two at once: the same operations, written side by side so that the scheduler interleaves the chains
@@ -162,8 +199,9 @@ __device__ __forceinline__ void stirling_diff2(double z1a, double z2a, double P1
                                                double P1b, double Q1b, double& da, double& dpa, double& db,
                                                double& dpb) {
 #pragma clang fp contract(off)
-    const double l1a = flog(z1a), l1b = flog(z1b), l2a = flog(z2a), l2b = flog(z2b);
-    const double r1a = frcp(z1a), r1b = frcp(z1b), r2a = frcp(z2a), r2b = frcp(z2b);
+    const LogRcp k1a = log_and_rcp(z1a), k1b = log_and_rcp(z1b), k2a = log_and_rcp(z2a), k2b = log_and_rcp(z2b);
+    const double l1a = k1a.l, l1b = k1b.l, l2a = k2a.l, l2b = k2b.l;
+    const double r1a = k1a.r, r1b = k1b.r, r2a = k2a.r, r2b = k2b.r;
     const double w1a = r1a * r1a, w1b = r1b * r1b, w2a = r2a * r2a, w2b = r2b * r2b;
     const double heada = (z2a - 0.5) * l2a - (z1a - 0.5) * l1a - (z2a - z1a);
     const double headb = (z2b - 0.5) * l2b - (z1b - 0.5) * l1b - (z2b - z1b);
@@ -173,12 +211,14 @@ __device__ __forceinline__ void stirling_diff2(double z1a, double z2a, double P1
     dpb = (l2b - l1b) - 0.5 * (r2b - r1b) - (stirling_digamma_tail(w2b) - stirling_digamma_tail_long(w1b));
     if (__any(P1a != 1.0 || P1b != 1.0)) {  // (adds exact zeros where nothing was shifted)
         if (P1a != 1.0) {
-            da += flog(P1a);
-            dpa += Q1a * frcp(P1a);
+            const LogRcp kP = log_and_rcp(P1a);
+            da += kP.l;
+            dpa += Q1a * kP.r;
         }
         if (P1b != 1.0) {
-            db += flog(P1b);
-            dpb += Q1b * frcp(P1b);
+            const LogRcp kP = log_and_rcp(P1b);
+            db += kP.l;
+            dpb += Q1b * kP.r;
         }
     }
 }
