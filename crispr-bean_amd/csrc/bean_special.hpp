@@ -32,7 +32,8 @@ __device__ __forceinline__ double frcp(double x) {
 }
 // (One third-order step, r (1 + e + e^2) with e = 1 - x r, is three FMAs instead of four and as accurate: it
 // measured -0.6 us per step at the metric shape, but the opt-in fused step kernel of the A/B library then
-// faulted with accessibility on - a memory access fault whose cause was not found - so it was not adopted.)
+// faulted with accessibility on - a memory access fault in the -O3 build only (none with -g, none under rocgdb's
+// precise-memory mode), whose cause was not found - so it was not adopted.)
 
 // natural log of a positive normal double: x = m 2^e, m in [sqrt(1/2), sqrt(2)),
 // log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, series to s^19.
