@@ -41,16 +41,21 @@ __host__ __device__ inline size_t guide_tiling_lds(int B, bool acc, size_t nt, b
 
 
 constexpr int kTilingRepMaxR = 64;  // more replicates than that: the wave form + k_sum_trow
-// waves per workgroup of k_guide_tiling_rep: of 1, 2, 4 the one that fills most lanes with (replicate,
-// guide) pairs, the smaller on a tie (R = 5: 60 / 64, 125 / 128, 255 / 256 -> 4; measured at config 3:
-// W = 2 188.6 us per step, W = 4 183.1)
-__host__ inline int tiling_rep_waves(int R) {
+// waves per workgroup of k_guide_tiling_rep: of 1, 2, 4 the one that keeps most lanes busy - the share of
+// lanes holding a (replicate, guide) pair (R = 5: 60 / 64, 125 / 128, 255 / 256) times the share of the CU's 16
+// wave slots its LDS lets the kernel use (160 KB per CU; with many conditions or the accessibility columns a
+// 256-thread workgroup no longer fits four times); the smaller on a tie.  Measured at config 3 (B = 5): W = 2
+// 188.6 us per step, W = 4 183.1.
+__host__ inline int tiling_rep_waves(int R, int B, bool acc) {
     int best = 1;
-    double best_eff = 0.0;
+    double best_score = 0.0;
     for (int w = 1; w <= 4; w *= 2) {
         const double eff = (double)((64 * w / R) * R) / (double)(64 * w);
-        if (eff > best_eff + 1e-12) {
-            best_eff = eff;
+        const size_t lds = guide_tiling_lds(B, acc, (size_t)64 * w, false);
+        const size_t wgs = lds ? (size_t)160 * 1024 / lds : 16;
+        const double waves = (double)(wgs * w < 16 ? wgs * w : 16) / 16.0;
+        if (eff * waves > best_score + 1e-12) {
+            best_score = eff * waves;
             best = w;
         }
     }
