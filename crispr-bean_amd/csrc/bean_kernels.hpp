@@ -1256,14 +1256,13 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     BEAN_STAMP_KP(0);
     if (PREP && FINISH) BEAN_STAMP_RT(bid, 0);
     const StepCtr ctr = *c.ctrA;
-    const unsigned long long s_fin = ctr.step;
     const unsigned long long s_prep = FINISH ? ctr.step + 1 : ctr.step;
     const unsigned long long slot_prep = FINISH ? ctr.slot + 1 : ctr.slot;
     AdamCoef ak;
     ak.step_size = 0.f;
     ak.clip = 0.f;
     if (FINISH && ADAM) {
-        ak.step_size = ctr.step_size;  // of update t = s_fin + 1, computed by the guide kernel (publish_ctr)
+        ak.step_size = ctr.step_size;  // of update t = ctr.step + 1, computed by the guide kernel (publish_ctr)
         ak.clip = (float)c.clip;
     }
     double loss_fin = 0.0, loss_prep = 0.0;
