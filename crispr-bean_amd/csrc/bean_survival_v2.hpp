@@ -58,7 +58,7 @@ void k_guide_survival_wave(DevArgs c) {
     const bool valid = g < G;
     const StepCtr ctr = *c.ctrB;
     double loss = 0.0;
-    BEAN_STAMP_RT(wg, 0);
+    BEAN_STAMP_RT(wg, 5);  // (slots 5, 6: k_param's block roles use 0 ... 4 and 7 of the same records)
 
     // LDS: [4][B] sf, sf_bc, sample mask, time | [B][64] P0 | [B][64] P1
     double* cst = sls;
@@ -358,7 +358,7 @@ void k_guide_survival_wave(DevArgs c) {
         loss = nll;
     }
     const double tot = wave_sum(loss);
-    BEAN_STAMP_RT(wg, 7);
+    BEAN_STAMP_RT(wg, 6);
     if (lane == 0) {
         wave_loss_out(c, ctr.slot, wg, tot);
         if (wg == 0) publish_ctr(c, ctr);

@@ -23,9 +23,9 @@ lib = _lib.load()
 lib.bean_hip_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
 assert lib.bean_hip_debug_stamps(eng._h, buf.ctypes.data, buf.size) == 0
 s = buf.reshape(nw, 8).astype(np.int64)
-s = s[(s[:, 0] > 0) & (s[:, 7] > 0)]
-t0 = s[:, 0].min()
-st, en = (s[:, 0] - t0) / 100.0, (s[:, 7] - t0) / 100.0
+s = s[(s[:, 5] > 0) & (s[:, 6] > 0)]  # slots 5 / 6: start / end of a wave
+t0 = s[:, 5].min()
+st, en = (s[:, 5] - t0) / 100.0, (s[:, 6] - t0) / 100.0
 print(f"{len(s)} waves; kernel span {en.max():.1f} us")
 for name, v in (("start", st), ("end", en), ("duration", en - st)):
     q = np.percentile(v, [0, 10, 50, 90, 99, 100])
