@@ -455,6 +455,19 @@ def test_tiling_elbo_and_gradients_match_oracle(engine, gen_kw, kw):
     _compare_tiling(engine, data, kw)
 
 
+def test_tiling_masked_alleles_that_keep_their_edits(engine):
+    """k_allele fills the slots whose mask is set OR whose edit list is not empty (the work list of
+    bean_hip_prepare): alleles masked out AFTER the table was built keep their edits - mu_a of such a slot is
+    still formed, its bin probabilities are 0 - and slots with neither stay at the zeros they start from."""
+    data = make_sorting_tiling_screen(400, 3, seed=31, n_max_alleles=7)
+    g = torch.Generator().manual_seed(5)
+    drop = (torch.rand(data.allele_mask.shape, generator=g) < 0.15) & data.allele_mask
+    drop[:, 0] = False  # the unedited allele stays
+    data.allele_mask = data.allele_mask & ~drop
+    assert int(drop.sum()) > 100
+    _compare_tiling(engine, data, {})
+
+
 def test_tiling_screen_built_from_h5ad_matches_oracle(engine):
     """The reference's tiling mini-screen file through the .h5ad reader and the allele-table
     builder, then ELBO + gradients against the oracle on the same tensors."""
