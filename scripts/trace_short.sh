@@ -1,0 +1,30 @@
+#!/bin/bash
+# kernel timeline of the driver's short bench call (20 steps): gpurun -- 'bash scripts/trace_short.sh'
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/trace_short
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strong > $OUT/bench.json 2> $OUT/err.txt
+cd $REPO && python3 - <<'PY'
+import csv, glob
+f = glob.glob("gpurun_out/trace_short/kt/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the timed call = the last k_set_step ... k_loss_finalize group with 20 guide launches
+idx = [i for i, r in enumerate(rows) if "k_set_step" in r["Kernel_Name"]]
+for s in idx[-3:]:
+    e = next(i for i in range(s, len(rows)) if "k_loss_finalize" in rows[i]["Kernel_Name"])
+    grp = rows[s:e + 1]
+    n_guide = sum("k_guide_wave2" in r["Kernel_Name"] for r in grp)
+    t0 = int(grp[0]["Start_Timestamp"])
+    span = (int(grp[-1]["End_Timestamp"]) - t0) / 1e3
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in grp) / 1e3
+    print(f"call with {n_guide} steps: span {span:.1f} us, kernels busy {busy:.1f} us, gaps {span - busy:.1f} us")
+    if n_guide == 20:
+        prev = t0
+        for r in grp:
+            st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            name = r["Kernel_Name"].split("(")[0][-40:]
+            print(f"   +{(st - prev) / 1e3:6.1f} gap  {(en - st) / 1e3:7.1f} us  {name}")
+            prev = en
+PY
