@@ -157,6 +157,15 @@ def build_library(force: bool = False, verbose: bool = False, amax=8) -> str:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+    # the toolchain's misplaced live-range copies (isa_check.py): a build that has one is not usable
+    from . import isa_check
+
+    bad = isa_check.findings_of(path)
+    if bad:
+        os.replace(path, path + ".rejected")
+        lines = [f"{name} @ {addr:#x}: " + "; ".join(tx for _, tx in pre) for name, addr, _, pre in bad]
+        raise RuntimeError(f"{path}: vector instructions in front of an exec restore at a control-flow join "
+                           "(compiler fault, see crispr-bean_amd/isa_check.py):\n  " + "\n  ".join(lines))
     return path
 
 

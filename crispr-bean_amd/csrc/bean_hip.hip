@@ -399,14 +399,11 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     {
         // one launch per step (bean_step_v2.hpp), opt-in (BEAN_HIP_STEP=fused; measured slower than the
         // two-launch path, see the header): the variant sorting families of k_guide_wave2 whose
-        // parameters are all per target or per guide, no target longer than a tile.  Not with accessibility
-        // scaling: in one -O3 build of this round (a one-instruction change in frcp) k_step_wave2<kMixture, true>
-        // ended in a memory access fault that no debug build reproduced; an experiment that cannot be trusted in
-        // every build is not offered for that family (the two launches run instead).
+        // parameters are all per target or per guide, no target longer than a tile
         const char* sm = getenv("BEAN_HIP_STEP");
         c->fused_step = c->wave2 && !d.wide_targets && s->max_target_len <= 64 && s->n_sample_covariates == 0 &&
                         (s->family == BEAN_FAMILY_MIXTURE_NORMAL || s->family == BEAN_FAMILY_NORMAL) &&
-                        !(s->flags & BEAN_FLAG_SCALE_BY_ACC) && (sm && !strcmp(sm, "fused"));
+                        (sm && !strcmp(sm, "fused"));
     }
     {
         // OPT-IN (BEAN_HIP_STEP=tile): ONE launch per call, a workgroup per tile of targets
@@ -1037,7 +1034,10 @@ static void launch_step_wave2(bean_hip_ctx* c, hipStream_t stream, int flip) {
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
         if (d.family == kMixture) {
-            hipExtLaunchKernelGGL((k_step_wave2<kMixture, false>), grid, block, lds, stream, e0, e1, 0, d, flip);
+            if (d.flags & kAcc)
+                hipExtLaunchKernelGGL((k_step_wave2<kMixture, true>), grid, block, lds, stream, e0, e1, 0, d, flip);
+            else
+                hipExtLaunchKernelGGL((k_step_wave2<kMixture, false>), grid, block, lds, stream, e0, e1, 0, d, flip);
         } else {
             hipExtLaunchKernelGGL((k_step_wave2<kNormal, false>), grid, block, lds, stream, e0, e1, 0, d, flip);
         }
@@ -1046,7 +1046,10 @@ static void launch_step_wave2(bean_hip_ctx* c, hipStream_t stream, int flip) {
         return;
     }
     if (d.family == kMixture) {
-        hipLaunchKernelGGL((k_step_wave2<kMixture, false>), grid, block, lds, stream, d, flip);
+        if (d.flags & kAcc)
+            hipLaunchKernelGGL((k_step_wave2<kMixture, true>), grid, block, lds, stream, d, flip);
+        else
+            hipLaunchKernelGGL((k_step_wave2<kMixture, false>), grid, block, lds, stream, d, flip);
     } else {
         hipLaunchKernelGGL((k_step_wave2<kNormal, false>), grid, block, lds, stream, d, flip);
     }

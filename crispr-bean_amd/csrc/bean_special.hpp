@@ -25,15 +25,14 @@ struct DD {
 // positive finite normal numbers everywhere they are used.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double frcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: ~2^-26 relative
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: ~2^-26 relative
+    // one third-order step, 1 / x = r (1 + e + e^2 + ...) with e = 1 - x r: the remainder e^3 is 2^-78
+    // (three FMAs; two Newton steps took four).  Round 3 backed this out because the A/B library's fused
+    // step kernel faulted with it: that was the toolchain's misplaced live-range copy (isa_check.py), which
+    // this change happened to provoke, not this arithmetic.
+    const double e = fma(-x, r, 1.0);
+    return fma(fma(e, e, e), r, r);
 }
-// (One third-order step, r (1 + e + e^2) with e = 1 - x r, is three FMAs instead of four and as accurate: it
-// measured -0.6 us per step at the metric shape, but the opt-in fused step kernel of the A/B library then
-// faulted with accessibility on - a memory access fault in the -O3 build only (none with -g, none under rocgdb's
-// precise-memory mode), whose cause was not found - so it was not adopted.)
 
 // natural log of a positive normal double: x = m 2^e, m in [sqrt(1/2), sqrt(2)),
 // log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, series to s^19.
@@ -278,7 +277,10 @@ __device__ __forceinline__ DD2 lgamma_digamma_diff2(double a0, double x0, double
         return out;
     }
     double z1a = a0, z1b = a1, P1a = 1.0, Q1a = 0.0, P1b = 1.0, Q1b = 0.0;
-    while (z1a < kShiftLo || z1b < kShiftLo) {
+    // a wave-uniform loop (the lanes that are done take neither `if`: same values as a per-lane loop): the
+    // wave runs for its slowest lane either way, and a scalar branch leaves no exec mask to restore - the
+    // join of the per-lane form is where the toolchain once misplaced a copy (isa_check.py)
+    while (__any(z1a < kShiftLo || z1b < kShiftLo)) {
         if (z1a < kShiftLo) {
             Q1a = fma(Q1a, z1a, P1a);
             P1a *= z1a;

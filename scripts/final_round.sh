@@ -2,9 +2,9 @@
 # End-of-round measurement pass (one gpurun call): profiles of the three bench configurations, the
 # BASELINE configuration timings, the exchange-path and wide-tiling timings, and the bench lines themselves.
 # Every step is bounded by its own timeout; a step that was killed ends the pass (no further GPU work).
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out
-step() { echo "== $*"; timeout -k 10 "$@"; rc=$?; if [ $rc -ge 124 ]; then echo "step killed (rc=$rc): stopping"; exit $rc; fi; }
+step() { echo "== $*" >&2; timeout -k 10 "$@"; rc=$?; if [ $rc -ge 124 ]; then echo "step killed (rc=$rc): stopping"; exit $rc; fi; }
 for cfg in metric tiling survival; do
   step 400 bash scripts/profile.sh $TAG $cfg > gpurun_out/prof_$cfg.log 2>&1
 done

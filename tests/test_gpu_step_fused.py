@@ -58,7 +58,8 @@ def test_fused_step_counts_and_graph_replay(monkeypatch, steps, chunks):
 
 def test_fused_step_families(monkeypatch):
     data = make_sorting_variant_screen(1800, 3, seed=78, with_accessibility=True, mask_fraction=0.05)
-    _same(monkeypatch, "MixtureNormal", data, 40)
+    _same(monkeypatch, "MixtureNormal", data, 40, dict(scale_by_accessibility=True))
+    _same(monkeypatch, "MixtureNormal", data, 40, dict(scale_by_accessibility=True, fit_noise=False))
     _same(monkeypatch, "Normal", data, 40)
     _same(monkeypatch, "Normal", data, 40, dict(use_bcmatch=False))
     T = data.n_targets
@@ -75,19 +76,6 @@ def test_fused_step_families(monkeypatch):
 def test_fused_step_metric_shape(monkeypatch):
     data = make_sorting_variant_screen(50000, 5, seed=79)
     _same(monkeypatch, "MixtureNormal", data, 130)
-
-
-def test_accessibility_scaling_takes_the_pair_path(monkeypatch):
-    """The fused step kernel is not offered with accessibility scaling (csrc/bean_hip.hip, fused_step)."""
-    from bean_amd import engine
-
-    monkeypatch.setenv("BEAN_HIP_STEP", "fused")
-    data = make_sorting_variant_screen(1800, 3, seed=78, with_accessibility=True, mask_fraction=0.05)
-    eng = engine.HipSVI("MixtureNormal", data.to(DEV), num_steps=10, lib_variant="ab", scale_by_accessibility=True)
-    assert eng.dominant_kernel == "k_guide_wave2"
-    eng.run(5)
-    assert np.all(np.isfinite(eng.losses()))
-    eng.close()
 
 
 def test_targets_longer_than_a_tile_take_the_pair_path(monkeypatch):
