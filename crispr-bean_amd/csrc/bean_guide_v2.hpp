@@ -6,6 +6,12 @@
 //     d/dnoise and, per Dirichlet component a, GA_a = [unclamped] (log pi_a + path_a) - [rg] log pi_a -
 //     because the (c_p - 1) log pi / (c_q - 1) log pi terms of the two Dirichlet log-densities are
 //     added to the loss here, where c_p / c_q are known.  v1 wrote eight to nine rows.
+//   * (round 4) d/dmu_t and d/dy_t do not leave the wave per guide any more: the guides of a target are
+//     consecutive lanes, so the wave adds them up per target (segmented scan, fixed shape) and stores one
+//     pair per (replicate, TARGET PART) - DevArgs::tsum, target_part_sums below.  k_param adds R (or 2 R,
+//     where a target straddles two tiles) numbers per target instead of R x its guides.  Tiles are aligned
+//     to the GLOBAL guide index (a shard's first tile starts at g_off rounded down to 64), so a target is
+//     cut at the same guides whatever the shard: parameters stay bitwise shard-independent.
 //   * count totals n = sum_b x_b are re-summed from the staged counts (exact: integer-valued
 //     float32), so the (2, R, G) `nobs` array is gone.
 //   * the bin loop that contains the lgamma / digamma differences carries two accumulators (A0 and the
@@ -58,7 +64,8 @@ __device__ __forceinline__ void w2_row_store(double* p, double v) {
 
 // The arithmetic of one (replicate, guide): draw, accessibility transform, both Dirichlet-Multinomial terms
 // with their gradients, Multinomial on the control allele counts, the pi site's densities and implicit
-// gradient; stores the five rows of the pair and returns its part of the loss.  ONE body for every kernel
+// gradient; stores the per-guide rows of the pair (d/dnoise, GA_0, GA_1), hands d/dmu_t and d/dy_t back
+// in o_mu / o_y and returns the pair's part of the loss.  ONE body for every kernel
 // that runs it (k_guide_wave2, k_step_wave2: a wave = 64 guides of one replicate, LS = 64; k_svi_tile:
 // a workgroup = all replicates of a tile, LS = its thread count), so that they produce the same bits.
 //   tp            this guide's column of the staged Phi tables: tp[(which * B + b) * ntm]
@@ -73,7 +80,7 @@ __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCt
                                                   const double* tp, int ntm, const double* c_sf, const double* c_sm,
                                                   const double* c_p0, float* xl, double* dps, const double* m_a0,
                                                   const double* m_a0bc, const double* m_cnt0, const double* m_cnt1,
-                                                  double* m_cp0, double* m_cp1) {
+                                                  double* m_cp0, double* m_cp1, double& o_mu, double& o_y) {
     constexpr bool MIX = FAM == kMixture;
     const int G = c.G, B = c.B, R = c.R;
     const bool use_bc = (c.flags & kUseBc) != 0;
@@ -251,8 +258,8 @@ __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCt
         g1 += S_1 - W * t_1;
     }
     double* row = c.wrow + rgi;  // row q of this replicate at row[q * RG]
-    W2_ROW_STORE(row + kW2Gmu * RG, a_mu);
-    W2_ROW_STORE(row + kW2Gy * RG, a_y);
+    o_mu = a_mu;  // d nll / d mu_t, d nll / d y_t of this pair: summed per target by the caller
+    o_y = a_y;
     if (MIX) {
         const double cp0 = *m_cp0, cp1 = *m_cp1;
         const bool cl0 = cp0 < 1e-5, cl1 = cp1 < 1e-5;
@@ -324,8 +331,46 @@ __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCt
     return nll;
 }
 
-// The work of one wave = 64 consecutive guides of one replicate.  Returns false for the padded tiles of
-// the XCD-aware grid; otherwise the wave's part of the loss in `tot` (valid in lane 0).
+// Per-target sums of a wave's d/dmu_t, d/dy_t (a8's backward inside the wave).  The guides of a target are
+// consecutive lanes (guides are target-sorted): a segmented inclusive scan in Hillis-Steele form - after the
+// step with offset d a lane holds the sum of the (up to) 2 d values that end at it - whose addition tree
+// depends on the position INSIDE the segment only, not on the lane, so that a target part gives the same
+// bits wherever it sits in a wave.  `pos` = lanes between this lane and the head of its segment;
+// c.seg_steps = ceil(log2(longest target, capped at a tile)).  The lane at the end of each segment stores
+// the pair: tsum[(q R + r) S + tile ntm + tcol], S = n_tiles ntm (STEP: agent-scope stores, as the rows).
+// Lanes without a guide (the ends of a shard's first and last tile) carry tcol = -1 and zeros.
+template <bool STEP>
+__device__ __forceinline__ void target_part_sums(const DevArgs& c, int lane, int tile, int r, int tcol, bool valid,
+                                                 double a_mu, double a_y) {
+    // head of a segment: lane 0, or another target than the lane below
+    const int below = __shfl_up(tcol, 1, 64);
+    const bool head = lane == 0 || below != tcol;
+    const unsigned long long heads = __ballot(head);
+    // position inside the segment: lane - (highest head at or below this lane)
+    const unsigned long long le = heads & (~0ull >> (63 - lane));
+    const int pos = lane - (63 - __clzll((long long)le));
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull) != 0;
+    const int steps = c.seg_steps;
+    for (int s = 0; s < steps; ++s) {
+        const int d = 1 << s;
+        const double ym = __shfl_up(a_mu, d, 64), yy = __shfl_up(a_y, d, 64);
+        if (pos >= d) {
+            a_mu += ym;
+            a_y += yy;
+        }
+    }
+    if (valid && tail) {
+        const long S = (long)c.n_tiles * c.tile_targets;
+        double* o = c.tsum + (long)r * S + (long)tile * c.tile_targets + tcol;
+        w2_row_store<STEP>(o, a_mu);
+        w2_row_store<STEP>(o + (long)c.R * S, a_y);
+    }
+}
+
+// The work of one wave = 64 consecutive guides of one replicate (tile k holds the guides whose GLOBAL index
+// g_off + g lies in [64 (k + g_off / 64), + 64): DevArgs::g_sh = g_off % 64 lanes of a shard's first tile
+// are empty).  Returns false for the padded tiles of the XCD-aware grid; otherwise the wave's part of the
+// loss in `tot` (valid in lane 0).
 template <int FAM, bool ACC, bool STEP>
 __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr& ctr, int& tile_o, int& r_o,
                                                  int& t0_o, int& nt_o, double& tot_o) {
@@ -339,11 +384,11 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     const int kk = wg >> 3;
     const int r = kk % R;
     const int tile = (kk / R) * 8 + (wg & 7);
-    if (tile * 64 >= G) return false;
+    if (tile >= c.n_tiles) return false;
     tile_o = tile;
     r_o = r;
-    const int g = tile * 64 + lane;
-    const bool valid = g < G;
+    const int g = tile * 64 + lane - c.g_sh;
+    const bool valid = g >= 0 && g < G;
     double loss = 0.0;
 #ifdef BEAN_STAMP
     const long wave_gid = wg;
@@ -351,8 +396,8 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     BEAN_STAMP_AT(0);
     BEAN_STAMP_CLK(0);
 
-    const int g_first = tile * 64;
-    const int g_last = (g_first + 63 < G ? g_first + 63 : G - 1);
+    const int g_first = tile * 64 - c.g_sh > 0 ? tile * 64 - c.g_sh : 0;
+    const int g_last = (tile * 64 + 63 - c.g_sh < G ? tile * 64 + 63 - c.g_sh : G - 1);
     const int t0 = __builtin_amdgcn_readfirstlane(c.g2t[g_first]);
     const int nt = __builtin_amdgcn_readfirstlane(c.g2t[g_last]) - t0 + 1;
     const int ntm = c.tile_targets;
@@ -372,7 +417,7 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     double pa0 = 0.0;
     {
         // everything the wave reads from global memory, issued as one batch before the first wait
-        const int gc = valid ? g : G - 1;
+        const int gc = valid ? g : (g < 0 ? 0 : G - 1);
         const long rgc = (long)r * G + gc;
         float xv[2][kBMax];
 #pragma unroll
@@ -470,10 +515,12 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     }
     __syncthreads();
 
+    double a_mu = 0.0, a_y = 0.0;
     if (valid)
         loss = guide_pair_math<FAM, ACC, STEP, 64>(c, ctr, r, g, rgm, api0, api1, pa0, &philox_first, tabs + tcol, ntm, cst,
                                                    cst + 2 * B, cst + 3 * B, xs + lane, dps, ms, ms + 64, ms + 2 * 64,
-                                                   ms + 3 * 64, ms + 4 * 64, ms + 5 * 64);
+                                                   ms + 3 * 64, ms + 4 * 64, ms + 5 * 64, a_mu, a_y);
+    target_part_sums<STEP>(c, lane, tile, r, valid ? tcol : -1, valid, a_mu, a_y);
     tot_o = wave_sum(loss);
     BEAN_STAMP_AT(7);
     BEAN_STAMP_CLK(2);

@@ -44,6 +44,8 @@ struct bean_hip_ctx {
     std::vector<hipGraphExec_t> graphs_fused;  // [k]: 2^(k+1) launches of k_step_wave2
     long long* loss_acc;  // library-owned fixed-point loss accumulators, kLossWords per loss_hist slot
     int* tile_targets_dev;
+    double* tsum_buf;   // DevArgs::tsum / tdesc (sized by bean_hip_prepare: they depend on tile_targets)
+    int2* tdesc_buf;
     int* live_slots;   // tiling: compact list of the allele slots that hold an allele (own allocation, (A - 1) G ints)
     bool tiling_wave;  // tiling families, default: k_guide_tiling_wave (BEAN_HIP_TILING=block: k_guide_tiling)
     bool tiling_wide;  // more alleles per guide than this build's kAMax: bean_tiling_wide.hpp
@@ -371,6 +373,17 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         return fail("bean_hip_create: sample covariates need the default guide kernel (k_guide_wave2)");
     }
     d.n_cov = s->n_sample_covariates;
+    // k_guide_wave2's tiles follow the GLOBAL guide index (bean_guide_v2.hpp): a shard that does not start at a
+    // multiple of 64 has g_sh empty lanes at the head of its first tile
+    d.g_sh = c->wave2 ? s->guide_offset % 64 : 0;
+    d.n_tiles = (int)((d.g_sh + G + 63) / 64);
+    {
+        const int seg = s->max_target_len < 1 ? 64 : (s->max_target_len > 64 ? 64 : s->max_target_len);
+        d.seg_steps = 0;
+        while ((1 << d.seg_steps) < seg) ++d.seg_steps;
+    }
+    c->tsum_buf = nullptr;
+    c->tdesc_buf = nullptr;
     c->surv_wave = c->surv_wave && is_survival(*s) && !is_tiling(*s);
     d.rows_v2 = (c->wave2 || c->surv_wave) ? 1 : 0;
 
@@ -424,16 +437,16 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
                                        : (c->wave_guide ? (uint64_t)(c->wave2 ? kW2Rows : kNumPart + 2) * Rr * G
                                                         : (c->surv_wave ? (uint64_t)kW2Rows * Rr * G : 0));
 #ifdef BEAN_STAMP
-    const uint64_t n_dbg = 8 * 2 * Rr * (((G + 63) / 64 + 7) / 8 * 8);
+    const uint64_t n_dbg = 8 * 2 * Rr * (((uint64_t)((G + 63) / 64 + 1) + 7) / 8 * 8);
 #else
     const uint64_t n_dbg = 0;
 #endif
     // per-wave loss parts of the wave-form guide kernels (1-D grid of padded tiles x replicates)
-    const uint64_t n_lpart = (c->wave2 || c->surv_wave) ? ((G + 63) / 64 + 7) / 8 * 8 * Rr : 0;
+    const uint64_t n_lpart = (c->wave2 || c->surv_wave) ? ((uint64_t)d.n_tiles + 7) / 8 * 8 * Rr : 0;
     const uint64_t n_dgq = ((c->wave2 || c->surv_wave) && s->family == BEAN_FAMILY_MIXTURE_NORMAL) ? 6 * G : 0;
     const uint64_t n_dgq_t = (c->tiling_wave || c->tiling_rep) ? (uint64_t)(kAMax + 1) * G : 0;
     // arrival counters of the fused step kernel: per tile and per tile boundary (ints, zero between launches)
-    const uint64_t n_ctr = c->wave2 ? ((G + 63) / 64 + 7) / 8 * 8 + 2 + 3 * B + 2 : 0;
+    const uint64_t n_ctr = c->wave2 ? ((uint64_t)d.n_tiles + 7) / 8 * 8 + 2 + 3 * B + 2 : 0;
     const uint64_t n_dbl = n_ctr + 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
                            n_split + n_dbg + n_trow + 3 * n_lpart + n_dgq + n_dgq_t + 2 * n_cov + 2 * Rr + 1;
     c->workspace_bytes = n_dbl * 8;
@@ -550,6 +563,8 @@ extern "C" int bean_hip_destroy(bean_hip_ctx* c) {
     if (c->workspace) (void)hipFree(c->workspace);
     if (c->tile_tab) (void)hipFree(c->tile_tab);
     if (c->live_slots) (void)hipFree(c->live_slots);
+    if (c->tsum_buf) (void)hipFree(c->tsum_buf);
+    if (c->tdesc_buf) (void)hipFree(c->tdesc_buf);
     if (c->step_sizes) (void)hipFree(c->step_sizes);
     if (c->dargs_dev) (void)hipFree(c->dargs_dev);
     if (c->loss_acc) (void)hipFree(c->loss_acc);
@@ -637,9 +652,9 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
     if (c->wave_guide) {
         // LDS sizing of k_guide_wave: a host read-back (4 bytes, setup only; the other one is the tiling work list below)
         HIP_OK(hipMemsetAsync(c->tile_targets_dev, 0, sizeof(int), stream));
-        const int tiles = (c->d.G + 63) / 64;
+        const int tiles = c->wave2 ? c->d.n_tiles : (c->d.G + 63) / 64;
         hipLaunchKernelGGL(k_tile_targets, dim3((tiles + 255) / 256), dim3(256), 0, stream, c->d.g2t, c->d.G,
-                           c->tile_targets_dev);
+                           c->d.g_sh, c->tile_targets_dev);
         HIP_OK(hipGetLastError());
         int nt = 0;
         HIP_OK(hipMemcpyAsync(&nt, c->tile_targets_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -647,6 +662,20 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
         if (nt < 1 || nt > 64) return fail("bean_hip_prepare: guides are not sorted by target (BEAN_BUF_GUIDE_TO_TARGET)");
         if (nt != c->d.tile_targets) drop_graph(c);
         c->d.tile_targets = nt;
+        if (c->wave2) {
+            // per-target-part sums of d/dmu_t, d/dy_t (k_guide_wave2 -> k_param) and where each target's lie
+            const size_t n_sum = (size_t)2 * c->d.R * c->d.n_tiles * nt;
+            if (c->tsum_buf) (void)hipFree(c->tsum_buf);
+            c->tsum_buf = nullptr;
+            HIP_OK(hipMalloc((void**)&c->tsum_buf, n_sum * sizeof(double)));
+            HIP_OK(hipMemsetAsync(c->tsum_buf, 0, n_sum * sizeof(double), stream));
+            if (!c->tdesc_buf) HIP_OK(hipMalloc((void**)&c->tdesc_buf, (size_t)c->d.T * sizeof(int2)));
+            c->d.tsum = c->tsum_buf;
+            c->d.tdesc = c->tdesc_buf;
+            hipLaunchKernelGGL(k_tdesc, dim3((c->d.T + 255) / 256), dim3(256), 0, stream, c->d, c->tdesc_buf);
+            HIP_OK(hipGetLastError());
+            drop_graph(c);
+        }
     }
     if (c->d.family == kMultiMixture) {
         // k_allele's work list: the allele slots that hold an allele, in (a1, g) order.  Setup only: the mask
@@ -778,7 +807,7 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
     // the specialised build of the kernel (k_param<..., 1>) where its launch conditions hold
     const bool kind1 = !d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
                        d.rows_v2 && !d.rrow && !d.surv_q0lik && !d.not_loss_owner && d.lpart &&
-                       (d.dgq || d.family != kMixture);
+                       (d.dgq || d.family != kMixture) && d.tsum;
     const bool kind2 = d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
                        d.rows_v2 && !d.rrow && d.lpart && d.lpt == kLanesPerTargetNarrow;
     const bool kind3 = d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov &&
@@ -888,7 +917,7 @@ static void launch_guide_split(bean_hip_ctx* c, hipStream_t stream) {
 // sorting variant families, one wave per (guide tile, replicate), second form (bean_guide_v2.hpp)
 static void launch_guide_wave2(bean_hip_ctx* c, hipStream_t stream) {
     const DevArgs& d = c->d;
-    const int tiles = (d.G + 63) / 64;
+    const int tiles = d.n_tiles;
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8) * (unsigned)d.R), block(64);
     // BEAN_HIP_LDS_PAD (bytes; experiments only): a larger LDS request lowers the number of resident waves
     static const size_t lds_pad = getenv("BEAN_HIP_LDS_PAD") ? (size_t)atol(getenv("BEAN_HIP_LDS_PAD")) : 0;
@@ -1025,7 +1054,7 @@ static void launch_guide_tiling_rep(bean_hip_ctx* c, hipStream_t stream) {
 // One SVI step in one launch (bean_step_v2.hpp); `flip` alternates the step-counter buffers.
 static void launch_step_wave2(bean_hip_ctx* c, hipStream_t stream, int flip) {
     const DevArgs& d = c->d;
-    const int tiles = (d.G + 63) / 64;
+    const int tiles = d.n_tiles;
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8) * (unsigned)d.R), block(64);
     const size_t lds = guide_wave2_lds(d.B, d.tile_targets);
     const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;

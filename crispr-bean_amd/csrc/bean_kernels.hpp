@@ -212,6 +212,14 @@ struct DevArgs {
     int q0_blocks;                   // survival: k_param has q0 blocks (n_gamma_blocks of them, kParamBlock guides each)
     int q0_blk0;                     // survival: k_param's guide-part blocks ahead of its q0 blocks (MixtureNormal: the alpha_pi blocks)
     int lpt;                         // k_param, thin mode: lanes per target (kLanesPerTarget; kLanesPerTargetNarrow: survival and tiling families)
+    // k_guide_wave2 (bean_guide_v2.hpp): tiles are aligned to the GLOBAL guide index, and the wave leaves d/dmu_t,
+    // d/dy_t summed per target part instead of per guide
+    int g_sh;                        // g_off % 64: empty lanes at the head of this shard's first tile
+    int n_tiles;                     // (g_sh + G + 63) / 64
+    int seg_steps;                   // ceil(log2(min(longest target, 64))): steps of the in-wave segmented scan
+    double* tsum;                    // (2, R, n_tiles * tile_targets): sums per (replicate, tile, target of the tile); null: per-guide rows
+    const int2* tdesc;               // (T): {slot of the target's first part = tile * tile_targets + index in the tile, number of parts};
+                                     //      part i >= 1 is the first target of the i-th next tile: slot (tile + i) * tile_targets
 };
 
 // rows of the per-guide partials written by k_guide_tiling, (kTNumPart, G)
@@ -772,6 +780,23 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
                                                  double& gmu, double& gy) {
     gmu = 0.0;
     gy = 0.0;
+    if (c.wide_targets && c.tsum) {
+        // few or very long targets, one per block: entry i = part * R + r of the target's partial sums
+        const int2 dsc = c.tdesc[t];
+        const int R = c.R, n = dsc.y * R, ntm = c.tile_targets;
+        const long S = (long)c.n_tiles * ntm;
+        const int tile0 = dsc.x / ntm;
+        double a = 0.0, b = 0.0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int part = i / R, r = i - part * R;
+            const long o = (long)r * S + (part == 0 ? dsc.x : (tile0 + part) * ntm);
+            a += c.tsum[o];
+            b += c.tsum[(long)R * S + o];
+        }
+        gmu = block_sum(a, scratch);
+        gy = block_sum(b, scratch);
+        return;
+    }
     if (c.wide_targets) {
         const int g0 = c.toff[t], g1 = c.toff[t + 1];
         double a = 0.0, b = 0.0;
@@ -820,7 +845,30 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
             }
         }
     }
-    if (c.wrow) {
+    if (c.wrow && c.tsum) {
+        // k_guide_wave2 has summed the target's guides inside its waves: entry i = part * R + r of the
+        // target's (part, replicate) sums - R of them, 2 R where the target straddles two tiles - goes to lane
+        // i mod lpt of its group; fixed shuffle tree.  A target is cut at multiples of 64 of the GLOBAL guide
+        // index: the same parts, the same bits, whatever the shard.
+        const int lpt = c.lpt;
+        const int lg = threadIdx.x & (lpt - 1);
+        double a = 0.0, b = 0.0;
+        if (t < c.T) {
+            const int2 dsc = c.tdesc[t];
+            const int R = c.R, n = dsc.y * R, ntm = c.tile_targets;
+            const long S = (long)c.n_tiles * ntm;
+            const float rR = 1.0f / (float)R;  // i / R below: exact for i < 2^20
+            for (int i = lg; i < n; i += lpt) {
+                const int part = (int)(((float)i + 0.5f) * rR), r = i - part * R;
+                const long o = (long)r * S + (part == 0 ? dsc.x : (dsc.x / ntm + part) * ntm);
+                a += c.tsum[o];
+                b += c.tsum[(long)R * S + o];
+            }
+        }
+        group_allsum(lpt, a, b);
+        gmu = a;
+        gy = b;
+    } else if (c.wrow) {
         // wave form: the (guide, replicate) rows of the target are spread over its lane
         // group and summed by a fixed shuffle tree (deterministic, shard independent)
         const int lpt = c.lpt;
@@ -1204,6 +1252,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(!c.not_loss_owner);
         __builtin_assume(c.lpart != nullptr);
         __builtin_assume(c.dgq != nullptr || c.family != kMixture);
+        __builtin_assume(c.tsum != nullptr);
     }
     if (KIND == 2) {  // the survival variant families on the wave-form path (thin mode, unsharded parameters)
         __builtin_assume(c.lpt == kLanesPerTargetNarrow);
@@ -3465,12 +3514,31 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
     }
 }
 
-// most targets spanned by one 64-guide tile (guides are target-sorted); *out must start at 0
-__global__ __launch_bounds__(256) void k_tile_targets(const int* g2t, int G, int* out) {
+// most targets spanned by one 64-guide tile (guides are target-sorted; tile k = local guides
+// [64 k - sh, 64 k - sh + 64), sh = g_off % 64); *out must start at 0
+__global__ __launch_bounds__(256) void k_tile_targets(const int* g2t, int G, int sh, int* out) {
     const int tile = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile * 64 >= G) return;
-    const int first = tile * 64, last = first + 63 < G ? first + 63 : G - 1;
+    if (tile * 64 - sh >= G) return;
+    const int first = tile * 64 - sh > 0 ? tile * 64 - sh : 0;
+    const int last = tile * 64 - sh + 63 < G ? tile * 64 - sh + 63 : G - 1;
     atomicMax(out, g2t[last] - g2t[first] + 1);
+}
+
+// DevArgs::tdesc: where k_guide_wave2 leaves the partial sums of each target (bean_guide_v2.hpp)
+__global__ __launch_bounds__(256) void k_tdesc(DevArgs c, int2* out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= c.T) return;
+    const int g0 = c.toff[t], g1 = c.toff[t + 1];
+    int2 d;
+    d.x = 0;
+    d.y = 0;
+    if (g1 > g0) {
+        const int tile_a = (c.g_sh + g0) >> 6, tile_b = (c.g_sh + g1 - 1) >> 6;
+        const int first = tile_a * 64 - c.g_sh > 0 ? tile_a * 64 - c.g_sh : 0;
+        d.x = tile_a * c.tile_targets + (t - c.g2t[first]);
+        d.y = tile_b - tile_a + 1;
+    }
+    out[t] = d;
 }
 
 // loss_hist[i] = accumulated parts of step i + the data-only constant, for n slots from `first`
@@ -3504,7 +3572,13 @@ __global__ __launch_bounds__(1024) void k_cov_sum(DevArgs c) {
     __shared__ double scratch[16];
     const int r = blockIdx.x;
     double v = 0.0;
-    for (int g = threadIdx.x; g < c.G; g += blockDim.x) v += c.wrow[((long)kPGmu * c.R + r) * c.G + g];
+    if (c.tsum) {
+        // the guide kernel's per-target-part sums of this replicate (slots no target uses hold zero)
+        const long S = (long)c.n_tiles * c.tile_targets;
+        for (long i = threadIdx.x; i < S; i += blockDim.x) v += c.tsum[(long)r * S + i];
+    } else {
+        for (int g = threadIdx.x; g < c.G; g += blockDim.x) v += c.wrow[((long)kPGmu * c.R + r) * c.G + g];
+    }
     const double tot = block_sum(v, scratch);
     if (threadIdx.x == 0) c.cov_sum[r] = tot;
 }

@@ -15,7 +15,7 @@
 // to the two-launch path (tests/test_gpu_step_fused.py), which pins the shared per-target / per-guide
 // code and the arrival mechanism below - the building block a persistent, tile-asynchronous step would need.
 //
-// How a tile is finished without a fence: the R waves of a tile store their five rows and their loss
+// How a tile is finished without a fence: the R waves of a tile store their rows, per-target sums and their loss
 // part with agent-scope stores (write-through, `sc1`), wait for those stores to complete
 // (s_waitcnt vmcnt(0)) and then count themselves in with one relaxed agent-scope atomic; the wave that
 // counts R - 1 predecessors reads the rows with agent-scope loads.  (An agent-scope FENCE per wave -
@@ -94,8 +94,8 @@ void k_step_wave2(DevArgs c, int flip) {
     AdamCoef ak;
     ak.step_size = ctr.step_size;  // of update t = step + 1 (k_set_step / the previous launch)
     ak.clip = (float)c.clip;
-    const int g_first = tile * 64;
-    const int g_last = g_first + 63 < G ? g_first + 63 : G - 1;
+    const int g_first = tile * 64 - c.g_sh > 0 ? tile * 64 - c.g_sh : 0;  // (tiles follow the global guide index)
+    const int g_last = tile * 64 + 63 - c.g_sh < G ? tile * 64 + 63 - c.g_sh : G - 1;
     const bool left_str = tof0 < g_first;
     const bool right_str = tof1 > g_last + 1;
     int own_left = left_str ? 0 : 1, own_right = right_str ? 0 : 1;
@@ -134,15 +134,17 @@ void k_step_wave2(DevArgs c, int flip) {
             const int t = base + (lane >> 2);
             const bool act = t <= tb;
             const int tc = act ? t : tb;
-            // everything that does not depend on the rows first: one round trip
-            const int g0 = c.toff[tc], ng = c.toff[tc + 1] - g0, n = ng * R;
+            // everything that does not depend on the sums first: one round trip
+            const int2 dsc = c.tdesc[tc];
+            const int n = dsc.y * R, ntm = c.tile_targets;
+            const long S = (long)c.n_tiles * ntm;
             float pj = P[tc], mj = M[tc], vj = V[tc];
             const float p1 = c.p[1][tc], p3 = c.p[3][tc];
             const double eps1 = c.eps_mu[tc], eps2 = c.eps_sd[tc], mu = c.mu_t[tc], y = c.y_t[tc];
-            // the (guide, replicate) rows of the target in k_param's order: its 16 lanes take entries
+            // the (part, replicate) sums of the target in k_param's order: its 16 lanes take entries
             // lg, lg + 16, ... and combine by an xor tree (8, 4, 2, 1); lane j here plays lanes j + 4 k
             double am[4] = {0.0, 0.0, 0.0, 0.0}, ay[4] = {0.0, 0.0, 0.0, 0.0};
-            const float rng = 1.0f / (float)ng;  // i / ng below: exact for i < 2^20 (ng <= 64)
+            const float rR = 1.0f / (float)R;  // i / R below: exact for i < 2^20
             for (int i0 = 0; i0 < n; i0 += 32) {
                 // 16 loads in flight per lane (an atomic load is waited for where it is used, and the
                 // compiler keeps atomic loads in program order: load first, add afterwards)
@@ -155,9 +157,10 @@ void k_step_wave2(DevArgs c, int flip) {
                         xm[mm][k] = 0.0;
                         xy[mm][k] = 0.0;
                         if (act && i < n) {
-                            const int rr = (int)(((float)i + 0.5f) * rng), gg = g0 + (i - rr * ng);
-                            xm[mm][k] = row_ld<true>(c.wrow + ((long)kPGmu * R + rr) * G + gg);
-                            xy[mm][k] = row_ld<true>(c.wrow + ((long)kPGy * R + rr) * G + gg);
+                            const int part = (int)(((float)i + 0.5f) * rR), rr = i - part * R;
+                            const long o = (long)rr * S + (part == 0 ? dsc.x : (dsc.x / ntm + part) * ntm);
+                            xm[mm][k] = row_ld<true>(c.tsum + o);
+                            xy[mm][k] = row_ld<true>(c.tsum + (long)R * S + o);
                         }
                     }
 #pragma unroll
@@ -257,9 +260,9 @@ void k_step_wave2(DevArgs c, int flip) {
     BEAN_STAMP_TL(3);
     // ---- the tile's guides: alpha_pi (and the accessibility noise site), tables for the next launch
     if (MIX) {
-        const int g = g_first + lane;
+        const int g = tile * 64 + lane - c.g_sh;
         double lg = 0.0;  // (param_guide_mix assigns its loss terms)
-        if (g < G) param_guide_mix<true, true, true, true>(c, g, ak, s_prep, lg);
+        if (g >= 0 && g < G) param_guide_mix<true, true, true, true>(c, g, ak, s_prep, lg);
         loss_fin += lg;
     }
     BEAN_STAMP_TL(4);

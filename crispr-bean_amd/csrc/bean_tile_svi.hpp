@@ -329,11 +329,18 @@ __device__ __noinline__ void tile_guide_step(const DevArgs* cp, int g0, int t0, 
     }
     const double* c_sf = cst + r * 4 * B;
     double loss = 0.0;
-    if (pair_on)
+    if (pair_on) {
+        // (this kernel keeps d/dmu_t, d/dy_t as per-guide rows: its finish phase adds them in the order k_param
+        // used until round 4; k_guide_wave2 now sums per target inside its waves)
+        double a_mu = 0.0, a_y = 0.0;
         loss = guide_pair_math<FAM, ACC, true, NT>(c, ctr, r, g, rgm, api0, api1, pa0, nullptr, tabs + tcol, ntm,
                                                    c_sf, c_sf + 2 * B, c_sf + 3 * B, xs + tid, dcol + tid, mper + j,
                                                    mper + gbm + j, mcnt + tid, mcnt + NT + tid, mper + 2 * gbm + j,
-                                                   mper + 3 * gbm + j);
+                                                   mper + 3 * gbm + j, a_mu, a_y);
+        double* row = c.wrow + (long)r * c.G + g;
+        w2_row_store<true>(row + (long)kW2Gmu * c.R * c.G, a_mu);
+        w2_row_store<true>(row + (long)kW2Gy * c.R * c.G, a_y);
+    }
     const double wl = wave_sum(loss);
     if ((tid & 63) == 0) mstep[tid >> 6] = wl;
 }

@@ -12,7 +12,7 @@ SUF=""; [ "$CONFIG" != "metric" ] && SUF="_$CONFIG"
 OUT=$REPO/gpurun_out/prof_$TAG$SUF
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $REPO/bench.py --config $CONFIG --no-cpu-baseline --no-strong"
+B="python3 $REPO/bench.py --config $CONFIG --no-cpu-baseline --no-strong --no-other-configs"
 # pass 1: per-kernel time (graph replay, as the bench runs it)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $B --steps 400 --warmup 50 > $OUT/bench_kt.json 2> $OUT/kt.err
 # pass 2..4: PMC counters, eager launches

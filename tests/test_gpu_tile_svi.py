@@ -1,7 +1,10 @@
 """k_svi_tile (opt-in, BEAN_HIP_STEP=tile: one launch per call, a workgroup per tile of targets,
 csrc/bean_tile_svi.hpp) against the default two launches per step ({k_param, k_guide_wave2}), which the oracle tests pin.
-Same draws, same arithmetic, same summation orders: the parameters must be BIT-IDENTICAL; the loss history
-is a sum of fixed-point partial sums grouped differently (per tile instead of per wave): 1e-12.  -m gpu."""
+Same draws and the same per-pair arithmetic (guide_pair_math is one function).  Until round 4 the summation
+orders were the same too and the parameters BIT-IDENTICAL; since then k_guide_wave2 adds a target's guides up
+inside its waves (bean_guide_v2.hpp: target_part_sums) while this kernel keeps the per-guide rows and the old
+order, so the two paths differ by roundings of float64 sums: float32 parameters and moments agree to a few ulp,
+the loss history to 1e-9.  -m gpu."""
 import os
 
 import numpy as np
@@ -42,11 +45,12 @@ def _compare(family, data, chunks=(1, 7, 30), **kw):
         b.run(n, seed=13)
     torch.cuda.synchronize()
     for k in a.unconstrained:
-        assert torch.equal(a.unconstrained[k], b.unconstrained[k]), k
-        assert torch.equal(a._m[k], b._m[k]) and torch.equal(a._v[k], b._v[k]), k
+        torch.testing.assert_close(a.unconstrained[k], b.unconstrained[k], rtol=2e-5, atol=2e-6, msg=k)
+        torch.testing.assert_close(a._m[k], b._m[k], rtol=2e-4, atol=1e-5, msg=k)
+        torch.testing.assert_close(a._v[k], b._v[k], rtol=2e-4, atol=1e-7, msg=k)
     la, lb = np.array(a.losses()), np.array(b.losses())
     assert np.isfinite(la).all() and la.shape == lb.shape
-    np.testing.assert_allclose(la, lb, rtol=1e-12)
+    np.testing.assert_allclose(la, lb, rtol=1e-9)
     a.close()
     b.close()
 
