@@ -361,13 +361,14 @@ class Leg:
         if self.exchanged:
             x = self.eng.exchange_buffers()
             self.exchange = "per step: " + ", ".join(f"all-reduce {k} ({v.numel()} f64)" for k, v in x.items())
-            # RCCL ranks: the library steps with its own communicator (kernels + ncclAllReduce enqueued natively);
-            # gloo rehearsals keep the Python stepping loop
+            # default: the Python stepping loop + torch.distributed.all_reduce; BEAN_HIP_NATIVE_COMM=1: the library
+            # steps with its own RCCL communicator (kernels + ncclAllReduce enqueued natively)
             native = False
-            try:
-                native = self.eng.init_native_comm()
-            except Exception as exc:  # noqa: BLE001  (never lose the run over the faster path)
-                print(f"[bench] native RCCL stepping unavailable: {exc}", file=sys.stderr)
+            if parallel.native_comm_enabled():  # opt-in, BEAN_HIP_NATIVE_COMM=1 (parallel.py)
+                try:
+                    native = self.eng.init_native_comm()
+                except Exception as exc:  # noqa: BLE001  (never lose the run over the faster path)
+                    print(f"[bench] native RCCL stepping unavailable: {exc}", file=sys.stderr)
             self.exchange += "; stepping: " + ("library-owned RCCL communicator, no host in the loop" if native
                                                else "Python loop + torch.distributed.all_reduce")
 

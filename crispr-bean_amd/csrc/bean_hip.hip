@@ -1651,11 +1651,33 @@ static int enqueue_exchanged_step(bean_hip_ctx* c, hipStream_t stream, bool last
     double* cov = c->d.n_cov ? (double*)c->slot_ptr[BEAN_BUF_XCHG_COV] : nullptr;
     if (cov) hipLaunchKernelGGL(k_cov_sum, dim3(c->d.R), dim3(1024), 0, stream, c->d);
     const int n_coll = (tg ? 1 : 0) + (sq ? 1 : 0) + (cov ? 1 : 0);
-    if (n_coll > 1) RCCL_OK(g_rccl.GroupStart());
-    if (tg) RCCL_OK(g_rccl.AllReduce(tg, tg, (size_t)2 * s.n_targets, ncclFloat64, ncclSum, c->comm, stream));
-    if (sq) RCCL_OK(g_rccl.AllReduce(sq, sq, (size_t)s.n_reps, ncclFloat64, ncclSum, c->comm, stream));
-    if (cov) RCCL_OK(g_rccl.AllReduce(cov, cov, (size_t)s.n_reps, ncclFloat64, ncclSum, c->comm, stream));
-    if (n_coll > 1) RCCL_OK(g_rccl.GroupEnd());
+    {
+        // a group that has been opened is ALWAYS closed, whatever fails inside it: a rank that returned between
+        // GroupStart and GroupEnd would leave its peers inside the collective (and a capturing stream half-captured)
+        const bool grouped = n_coll > 1;
+        ncclResult_t r = ncclSuccess, rg = ncclSuccess;
+        const char* what = "";
+        if (grouped) {
+            r = g_rccl.GroupStart();
+            what = "ncclGroupStart";
+        }
+        const bool opened = grouped && r == ncclSuccess;
+        if (r == ncclSuccess && tg) {
+            r = g_rccl.AllReduce(tg, tg, (size_t)2 * s.n_targets, ncclFloat64, ncclSum, c->comm, stream);
+            what = "ncclAllReduce(tgrad)";
+        }
+        if (r == ncclSuccess && sq) {
+            r = g_rccl.AllReduce(sq, sq, (size_t)s.n_reps, ncclFloat64, ncclSum, c->comm, stream);
+            what = "ncclAllReduce(sq)";
+        }
+        if (r == ncclSuccess && cov) {
+            r = g_rccl.AllReduce(cov, cov, (size_t)s.n_reps, ncclFloat64, ncclSum, c->comm, stream);
+            what = "ncclAllReduce(cov)";
+        }
+        if (opened) rg = g_rccl.GroupEnd();
+        if (r != ncclSuccess) return fail(std::string(what) + ": " + g_rccl.GetErrorString(r));
+        if (rg != ncclSuccess) return fail(std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(rg));
+    }
     if (last) launch_param<true, true, false>(c, stream, tg, cov != nullptr);
     else launch_param<true, true, true>(c, stream, tg, cov != nullptr);
     launch_finalize(c, stream, 0, 1, true);  // the slot of the step that has just finished
@@ -1683,6 +1705,8 @@ extern "C" int bean_hip_svi_run_exchanged(bean_hip_ctx* c, uint64_t seed, uint64
                 bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (ok) {
                     for (uint64_t i = 0; ok && i < (2ull << k); ++i) ok = enqueue_exchanged_step(c, stream, false) == 0;
+                    // the capture is ended whether or not a step failed inside it (enqueue_exchanged_step closes
+                    // its RCCL group on every path); a partial graph is destroyed below
                     hipError_t e = hipStreamEndCapture(stream, &graph);
                     ok = ok && e == hipSuccess && graph != nullptr;
                 }

@@ -438,15 +438,16 @@ class HipSVI:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         path = _lib.rccl_path().encode()
         idt = torch.zeros(128, dtype=torch.uint8, device=self.device)
-        ok = torch.ones(1, dtype=torch.int32, device=self.device)
-        if rank == 0:
-            buf = (ctypes.c_uint8 * 128)()
-            if self.lib.bean_hip_comm_unique_id(path, buf) == 0:
-                idt.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
-            else:
-                ok.zero_()
-        dist.broadcast(ok, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        if int(ok.item()) == 0:  # every rank learns that rank 0 could not load RCCL
+        # EVERY rank loads RCCL now (asking for an id does that; only rank 0's id is used) and the ranks agree
+        # on the outcome BEFORE anyone enters ncclCommInitRank: a rank that could not load the library would
+        # otherwise return while its peers block inside that collective
+        buf = (ctypes.c_uint8 * 128)()
+        loaded = self.lib.bean_hip_comm_unique_id(path, buf) == 0
+        if rank == 0 and loaded:
+            idt.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        ok = torch.tensor([1 if loaded else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
             return False
         dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         raw = bytes(idt.cpu().numpy().tobytes())
@@ -634,10 +635,18 @@ class HipSVI:
         """Dynamic LDS per workgroup the library requests for the dominant kernel at this shape."""
         return int(self.lib.bean_hip_dominant_lds_bytes(self._h))
 
-    def constrained(self) -> Dict[str, torch.Tensor]:
-        """Constrained parameter values, as ``pyro.get_param_store()[name]``."""
+    def snapshot(self) -> Dict[str, torch.Tensor]:
+        """Device-side copy of the unconstrained parameters as they are when everything enqueued so far has
+        run (``run_inference`` keeps the one taken at the start of a report window: if the window's loss
+        turns non-finite, that is what ``tmp_result.pkl`` holds, not the NaN updates applied since)."""
+        with self._on_stream():
+            return {k: v.clone() for k, v in self.unconstrained.items()}
+
+    def constrained(self, snapshot: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """Constrained parameter values, as ``pyro.get_param_store()[name]`` (of ``snapshot`` if given)."""
         torch.cuda.synchronize(self.device)
-        out = {k: (v.exp() if k in POSITIVE else v.clone()) for k, v in self.unconstrained.items()}
+        src = self.unconstrained if snapshot is None else snapshot
+        out = {k: (v.exp() if k in POSITIVE else v.clone()) for k, v in src.items()}
         if self.survival and self.family == "MultiMixtureNormal":
             # the reference's tiling survival guide registers this parameter and never uses it
             # (survival_model.py:770-774): it keeps its initial value

@@ -99,7 +99,8 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
     constrained values, exactly the structure the reference returns.
     A non-finite loss halts the fit at the end of its report window (100 steps) and raises
     ``ValueError`` after dumping the parameters to ``tmp_result.pkl``, as the reference does on a
-    ``ValueError`` inside the loop (there at the failing step itself).
+    ``ValueError`` inside the loop (there at the failing step itself; here the dump holds the parameters
+    as they were at the start of the failing window, i.e. at most 99 steps earlier and finite).
 
     When ``torch.distributed`` is initialised with more than one rank the guides
     are sharded on target boundaries (``parallel.run_sharded``): every rank fits
@@ -142,6 +143,7 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
             done = 0
             while done < num_steps:
                 k = min(report_every, num_steps - done)
+                eng.window_start = eng.snapshot()  # what a halt inside this window dumps
                 eng.run(k, seed=seed)
                 # the reference halts at the failing step (run.py:375-390); here at the end of its report window
                 window = eng.loss_hist[done:done + k]
@@ -159,7 +161,13 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
         name = "tmp_result.pkl" if world == 1 else f"tmp_result.rank{rank}.pkl"
         error(f"Error occurred during fitting. Saving temporary output at {name}.")
         with open(name, "wb") as handle:
-            dump = {k: v.cpu() for k, v in engines[-1].constrained().items()} if engines else {}
+            # the parameters as they were at the START of the failing report window: the device loop has
+            # applied up to report_every - 1 further (NaN) updates since the failing step, the reference
+            # stops at the failing step itself (run.py:375-390)
+            dump = {}
+            if engines:
+                eng = engines[-1]
+                dump = {k: v.cpu() for k, v in eng.constrained(getattr(eng, "window_start", None)).items()}
             pkl.dump({"param": dump}, handle)
         for e in engines:
             e.close()

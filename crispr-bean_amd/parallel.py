@@ -132,6 +132,14 @@ PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale", "q0", "initial_abundance")
 REPLICATED = ("mu_cov_loc", "mu_cov_scale")  # shared by every guide: identical on every rank
 
 
+def native_comm_enabled() -> bool:
+    """``BEAN_HIP_NATIVE_COMM=1``: exchange families of a guide-sharded fit step through the library-owned
+    RCCL communicator (``HipSVI.init_native_comm``).  Off by default until a multi-GPU run has exercised it."""
+    import os
+
+    return os.environ.get("BEAN_HIP_NATIVE_COMM", "0") == "1"
+
+
 def run_sharded(
     engine_factory: Callable,
     data,
@@ -175,13 +183,17 @@ def run_sharded(
         extra["t0_totals"] = (data.X[:, 0, :].to(torch.float32) + 1).sum(-1)
     eng = engine_factory(shard_screen(data, mine), mine, data.n_guides, **extra)
     exchanged = bool(eng.exchange_buffers()) if hasattr(eng, "exchange_buffers") else False
-    if exchanged and grp.on and hasattr(eng, "init_native_comm"):
-        # RCCL ranks: the library steps with its own communicator (no host in the per-step loop);
-        # any other backend (gloo rehearsals) keeps the Python stepping loop
+    if exchanged and grp.on and hasattr(eng, "init_native_comm") and native_comm_enabled():
+        # opt-in (BEAN_HIP_NATIVE_COMM=1): the library steps with its own RCCL communicator, no host in
+        # the per-step loop.  Default: the Python stepping loop + torch.distributed.all_reduce, which two
+        # and more ranks have exercised (gloo here, nccl on the driver's nodes); the native path has run
+        # with ONE rank on hardware so far (tests/test_gpu_nccl.py)
         eng.init_native_comm(group)
     done = 0
     while done < num_steps:
         k = min(report_every, num_steps - done)
+        if hasattr(eng, "snapshot"):
+            eng.window_start = eng.snapshot()  # what a halt inside this window dumps (model/run.py)
         if exchanged:
             eng.run_exchanged(k, grp.all_reduce_sum, seed=seed)
         else:

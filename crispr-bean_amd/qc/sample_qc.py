@@ -85,7 +85,9 @@ def fill_in_missing_samples(screen, condition_label: str, replicate_label: Union
     if isinstance(replicate_label, str):
         rep_list = list(pd.unique(screen.samples[replicate_label]))
     else:
-        rep_list = [tuple(r) for r in screen.samples[list(replicate_label)].drop_duplicates().values.tolist()]
+        # lists, as the reference makes them before it formats the dummy's id (bean/qc/utils.py:139, 96):
+        # "['rep1', 'x']_bulk"
+        rep_list = [list(r) for r in screen.samples[list(replicate_label)].drop_duplicates().values.tolist()]
     for rep in rep_list:
         for cond in pd.unique(screen.samples[condition_label]):
             if isinstance(replicate_label, str):

@@ -47,18 +47,23 @@ def main():
     for k in want:
         assert torch.equal(whole[k], want[k]), k
     assert losses == want_losses, "loss history differs"
-    # (b) per-step exchange: tiling per-edit gradients
-    data = syn.make_sorting_tiling_screen(3000, 3, seed=6)
-    whole, losses, want, want_losses = fit("MultiMixtureNormal", data)
-    for k in want:
-        assert torch.allclose(whole[k], want[k], rtol=1e-5, atol=1e-7), k
-    assert max(abs(a - b) / abs(b) for a, b in zip(losses, want_losses)) < 1e-9
-    # (c) per-step exchange: survival normalisers
-    data = syn.make_survival_variant_screen(4000, 3, seed=7)
-    whole, losses, want, want_losses = fit("MixtureNormal", data)
-    for k in want:
-        assert torch.allclose(whole[k], want[k], rtol=1e-5, atol=1e-7), k
-    assert max(abs(a - b) / abs(b) for a, b in zip(losses, want_losses)) < 1e-9
+    # the exchange families step through the Python loop + dist.all_reduce by default and through the
+    # library-owned RCCL communicator with BEAN_HIP_NATIVE_COMM=1 (parallel.native_comm_enabled): both
+    for native in ("0", "1"):
+        os.environ["BEAN_HIP_NATIVE_COMM"] = native
+        # (b) per-step exchange: tiling per-edit gradients
+        data = syn.make_sorting_tiling_screen(3000, 3, seed=6)
+        whole, losses, want, want_losses = fit("MultiMixtureNormal", data)
+        for k in want:
+            assert torch.allclose(whole[k], want[k], rtol=1e-5, atol=1e-7), (native, k)
+        assert max(abs(a - b) / abs(b) for a, b in zip(losses, want_losses)) < 1e-9, native
+        # (c) per-step exchange: survival normalisers
+        data = syn.make_survival_variant_screen(4000, 3, seed=7)
+        whole, losses, want, want_losses = fit("MixtureNormal", data)
+        for k in want:
+            assert torch.allclose(whole[k], want[k], rtol=1e-5, atol=1e-7), (native, k)
+        assert max(abs(a - b) / abs(b) for a, b in zip(losses, want_losses)) < 1e-9, native
+    os.environ.pop("BEAN_HIP_NATIVE_COMM", None)
     # the collective itself, on the engine-style side stream
     s = torch.cuda.Stream(device=dev)
     t = torch.arange(1000, dtype=torch.float64, device=dev)

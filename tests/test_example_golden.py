@@ -1,0 +1,66 @@
+"""a15 pinned by the reference's OWN run: the parameters its shipped 2000-step `bean run sorting variant
+--fit-negctrl --scale-by-acc` fit ended with (docs/example_run_output/variant/MixtureNormal+Acc.result.pkl) go
+through this build's `write_result_table`; every fitted column of the element and sgRNA tables the reference
+wrote from them must come out (fixture: tests/golden/make_example_golden.py)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pandas as pd
+import torch
+
+import bean_amd  # noqa: F401
+from bean_amd.model import readwrite
+
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "example_variant.npz"))
+POSITIVE = ("mu_scale", "sd_scale", "alpha_pi", "noise_scale")
+ELEMENT_INPUT = ["target", "target_variant", "target_group", "target_group2", "n_guides", "edit_rate_mean", "edit_rate_std"]
+
+
+def _params(prefix):
+    # the pickle holds the parameter store's state, i.e. unconstrained values: pyro.param applies exp
+    out = {}
+    for k in Z.files:
+        if k.startswith(prefix):
+            name = k[len(prefix):]
+            t = torch.from_numpy(Z[k])
+            out[name] = t.exp() if name in POSITIVE else t
+    return out
+
+
+def test_reference_run_parameters_give_the_reference_tables(tmp_path):
+    P, N = _params("P__"), _params("N__")
+    assert P["mu_loc"].shape == (694, 1) and P["alpha_pi"].shape == (3446, 2)
+    # the table's index column is the row's position in target order, the order the parameters are in
+    # (readwrite.py:130-132)
+    pos = Z["element__index"].astype(int)
+    order = np.argsort(pos)
+    assert (pos[order] == np.arange(694)).all()
+    target = pd.DataFrame({c: Z[f"element__{c}"][order] for c in ELEMENT_INPUT}).set_index("target")
+    # sgRNA table: `edit_rate` and the log fold changes are inputs (bdata.guides), accessibility is passed in
+    guide = pd.DataFrame({c: Z[f"sgRNA__{c}"] for c in Z["sgRNA__columns"] if c not in ("accessibility", "scaled_edit_eff")},
+                         index=pd.Index(Z["sgRNA__index"]))
+    negatives = np.where(pd.Series(Z["element__target_group"][order]).str.lower() == "negctrl")[0]
+    assert len(negatives) > 10
+    prefix = str(tmp_path) + "/"
+    with contextlib.redirect_stdout(io.StringIO()):
+        readwrite.write_result_table(target.copy(), guide.copy(), P, "M", prefix=prefix, negctrl_params=N,
+                                     adjust_confidence_by_negative_control=True,
+                                     adjust_confidence_negatives=negatives, guide_acc=Z["sgRNA__accessibility"],
+                                     sd_is_fitted=True)
+    got = pd.read_csv(prefix + "bean_element_result.M.csv", index_col=0)
+    assert list(got.columns) == list(Z["element__columns"])
+    fitted = [c for c in Z["element__columns"] if c not in ELEMENT_INPUT]
+    assert len(fitted) == 15
+    got = got.loc[pos]  # rows by original position (the sort itself is checked below)
+    for c in fitted:
+        np.testing.assert_allclose(got[c].values, Z[f"element__{c}"], rtol=2e-6, atol=2e-7, err_msg=c)
+    # the reference's quirk C-4: "negctrl" is never a key of the parameter dict, so _adj derives from mu, not mu_scaled
+    np.testing.assert_array_equal(got["mu_adj"].values, got["mu"].values)
+    # (the shipped table is in target order - it predates the sort by |mu_z_adj| of readwrite.py:170, which the
+    # reference-generated fixtures of test_readwrite_golden.py pin; rows were matched by position above)
+    sg = pd.read_csv(prefix + "bean_sgRNA_result.M.csv", index_col=0)
+    assert list(sg.columns) == list(Z["sgRNA__columns"])
+    assert list(sg.index) == list(Z["sgRNA__index"])
+    np.testing.assert_allclose(sg["scaled_edit_eff"].values, Z["sgRNA__scaled_edit_eff"], rtol=2e-6, atol=2e-7)

@@ -37,3 +37,7 @@ def test_non_finite_loss_halts_at_its_report_window(tmp_path, monkeypatch):
     with open(tmp_path / "tmp_result.pkl", "rb") as fh:
         dump = pickle.load(fh)
     assert "mu_loc" in dump["param"]
+    # the dump is the parameter store at the start of the failing window (here: the initial values), not what
+    # a hundred NaN updates have left of it
+    for k, v in dump["param"].items():
+        assert torch.isfinite(v).all(), k

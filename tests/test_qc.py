@@ -181,3 +181,20 @@ def test_cli_qc_on_screens_with_missing_samples(_needs_h5ad, tmp_path):
     assert bean_main(["qc", TILING_MISSING, "-o", out_d, "-r", str(tmp_path / "rep"), "--count-correlation-thres", "0.6",
                       "--posctrl-col=", "-i", "--dont-recalculate-edits", "--edit-start-pos", "0", "--edit-end-pos", "20"]) == 0
     assert np.array_equal(read_h5ad(out_d).layers["edits"], read_h5ad(TILING_MISSING).layers["edits"])
+
+
+def test_dummy_sample_id_with_several_replicate_columns():
+    """The reference turns a multi-column replicate label into a LIST before it formats the dummy sample's
+    id (bean/qc/utils.py:139, 96): "['r2', 'x']_bot", not a tuple's repr."""
+    from bean_amd.qc.sample_qc import fill_in_missing_samples
+
+    scr = _screen(n_guides=200)
+    scr.samples["batch"] = ["x"] * 6 + ["y"] * 3
+    keep = [i for i, n in enumerate(scr.samples.index) if n != "r2_bot"]
+    scr = scr[:, scr.samples.index[keep]]
+    out = fill_in_missing_samples(scr, "condition", ["replicate", "batch"])
+    new = [n for n in out.samples.index if n not in scr.samples.index]
+    assert new == ["['r2', 'x']_bot"]
+    row = out.samples.loc[new[0]]
+    assert row["replicate"] == "r2" and row["batch"] == "x" and row["condition"] == "bot"
+    assert float(np.asarray(out.X)[:, list(out.samples.index).index(new[0])].sum()) == 0.0
