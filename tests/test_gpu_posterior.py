@@ -130,6 +130,48 @@ def test_free_running_fit_within_oracle_seed_spread(engine, screen):
     assert abs(lh - la) <= 2e-3 * abs(la), rep
 
 
+def test_seed_averaged_posterior_has_no_bias(engine, screen):
+    """A single HIP fit cannot be told from another oracle seed (above), which leaves room for a bias smaller
+    than the seed-to-seed spread (~3 % of mu_loc).  K = 16 HIP seeds against K = 16 oracle seeds: the
+    seed-AVERAGED mu_loc of the strong targets (|z| > 2) must agree within the standard error of the two
+    means - a bias four times below the spread of one fit would show."""
+    K, steps = 16, 400
+    mus_h, mus_o = [], []
+    for i in range(K):
+        eng = engine.HipSVI("MixtureNormal", screen.to(DEV), num_steps=steps, initial_lr=LR)
+        eng.run(steps, seed=2000 + i)
+        torch.cuda.synchronize()
+        mus_h.append(eng.constrained()["mu_loc"].cpu().flatten().double())
+        eng.close()
+    for i in range(K):
+        mu, sc, _ = _oracle_fit(screen, 1000 + i, steps)
+        mus_o.append(mu)
+        if i == 0:
+            strong = (mu / sc).abs() > 2.0
+    H, O = torch.stack(mus_h)[:, strong], torch.stack(mus_o)[:, strong]
+    n = int(strong.sum())
+    assert n >= 20
+    mh, mo = H.mean(0), O.mean(0)
+    se = (H.var(0, unbiased=True) / K + O.var(0, unbiased=True) / K).sqrt()
+    z = (mh - mo) / se
+    spread = float((O.std(0, unbiased=True) / mo.abs()).median())          # one fit's seed-to-seed spread
+    rel_bias = float(((mh - mo).abs() / mo.abs()).median())                 # of the seed-averaged fits
+    rep = {"config": "5000 guides x (4 bins + bulk) x 3 reps, MixtureNormal, %d steps, lr %g, K = %d seeds each" % (steps, LR, K),
+           "n_strong": n, "one_fit_rel_spread_median": spread, "seed_averaged_rel_difference_median": rel_bias,
+           "z_mean": float(z.mean()), "z_std": float(z.std()), "z_abs_max": float(z.abs().max()),
+           "frac_abs_z_gt_3": float((z.abs() > 3).double().mean())}
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(rep, open(os.path.join(out, "posterior_bias.json"), "w"), indent=1)
+    print(json.dumps(rep))
+    # no systematic shift: the z scores of the strong targets scatter around 0 like standard normals (their
+    # mean over n targets within 4 / sqrt(n); targets share the data, so the bound is generous) ...
+    assert abs(rep["z_mean"]) <= 4.0 / np.sqrt(n) + 0.25, rep
+    assert rep["z_std"] <= 1.6 and rep["frac_abs_z_gt_3"] <= 0.05, rep
+    # ... and the seed-averaged fits differ by what averaging K seeds leaves of the spread, not by more
+    assert rel_bias <= 2.5 * spread * np.sqrt(2.0 / K) + 1e-3, rep
+
+
 # ------------------------------------------------ the other BASELINE configurations, small sizes
 def _fit_pair(engine, family, data, loss_fn, init_fn, steps, kw=None):
     kw = kw or {}
