@@ -383,7 +383,7 @@ class Leg:
             if self.exchanged:
                 eng.run_exchanged(k, dist.all_reduce, seed=101)
             else:
-                eng.run(k, seed=101, graph_chunk=self.graph_chunk)
+                eng.run(k, seed=101, graph_chunk=self.graph_chunk, resume=True)  # windows, as run_inference steps them
             if self.world > 1:
                 with torch.cuda.stream(eng.stream):
                     dist.all_reduce(eng.loss_hist[first:first + k])

@@ -89,6 +89,7 @@ SYMBOLS = [
     ("bean_hip_elbo_grad", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_void_p]),
     ("bean_hip_adam", c_int32, [c_void_p, c_uint64, c_void_p]),
     ("bean_hip_svi_run", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_int32, c_void_p]),
+    ("bean_hip_svi_resume", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_int32, c_void_p]),
     ("bean_hip_sharded_begin", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_void_p]),
     ("bean_hip_sharded_sums", c_int32, [c_void_p, c_void_p]),
     ("bean_hip_sharded_guide", c_int32, [c_void_p, c_void_p]),

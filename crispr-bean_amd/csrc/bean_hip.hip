@@ -74,6 +74,12 @@ struct bean_hip_ctx {
     ncclComm_t comm;
     int comm_world;
     std::vector<hipGraphExec_t> graphs_xchg;
+    // bean_hip_svi_resume: graphs of 2^k {guide, k_param<FINISH, ADAM, PREP>} pairs, and what the last call left
+    // prepared on the device: the draw and tables of step resume_next (same seed, same stream)
+    std::vector<hipGraphExec_t> graphs_resume;
+    bool resume_ok;
+    uint64_t resume_next, resume_seed;
+    void* resume_stream;
 };
 
 extern "C" const char* bean_hip_version(void) {
@@ -232,6 +238,10 @@ static void drop_graph(bean_hip_ctx* c) {
     for (hipGraphExec_t g : c->graphs_xchg)
         if (g) (void)hipGraphExecDestroy(g);
     c->graphs_xchg.clear();
+    for (hipGraphExec_t g : c->graphs_resume)
+        if (g) (void)hipGraphExecDestroy(g);
+    c->graphs_resume.clear();
+    c->resume_ok = false;  // (called whenever a buffer, the shape-dependent state or the seed changes)
 }
 
 extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
@@ -302,6 +312,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
 #endif
     }
     c->graph_seed = 0;
+    c->resume_ok = false;
+    c->resume_next = c->resume_seed = 0;
+    c->resume_stream = nullptr;
     c->comm = nullptr;
     c->comm_world = 0;
     c->tile_svi = false;
@@ -1221,8 +1234,8 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
 }
 
 static void launch_finalize(bean_hip_ctx* c, hipStream_t stream, uint64_t first, uint64_t n, bool cur) {
-    const unsigned blocks = cur ? 1u : (unsigned)((n + 3) / 4);  // one wave per slot
-    hipLaunchKernelGGL(k_loss_finalize, dim3(blocks), dim3(cur ? 64 : 256), 0, stream, c->d, (unsigned long long)first,
+    const unsigned blocks = (unsigned)((n + 3) / 4);  // one wave per slot
+    hipLaunchKernelGGL(k_loss_finalize, dim3(blocks), dim3(n == 1 ? 64 : 256), 0, stream, c->d, (unsigned long long)first,
                        (unsigned long long)n, cur ? 1 : 0);
 }
 
@@ -1244,6 +1257,7 @@ extern "C" int bean_hip_elbo_grad(bean_hip_ctx* c, uint64_t seed, uint64_t step,
     if (loss_index >= c->loss_capacity) return fail("bean_hip_elbo_grad: loss_index beyond loss_hist");
     hipStream_t stream = (hipStream_t)stream_;
     c->d.seed = seed;
+    c->resume_ok = false;
     launch_set_step(c, stream, step, loss_index, 1);
     launch_param<false, false, true>(c, stream);
     launch_guide(c, stream);
@@ -1257,6 +1271,7 @@ extern "C" int bean_hip_adam(bean_hip_ctx* c, uint64_t t, void* stream_) {
     if (!c) return fail("bean_hip_adam: null handle");
     if (check_bound(c, true, true)) return -1;
     if (t < 1) return fail("bean_hip_adam: t is 1-based");
+    c->resume_ok = false;
     hipStream_t stream = (hipStream_t)stream_;
     for (int i = 0; i < 8; ++i) {
         const uint64_t bytes = expected_bytes(c->shape, BEAN_BUF_P_MU_LOC + i);
@@ -1391,6 +1406,7 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
     hipStream_t stream = (hipStream_t)stream_;
     if ((!c->graphs.empty() || !c->graphs_fused.empty()) && (c->graph_seed != seed)) drop_graph(c);
     c->d.seed = seed;
+    c->resume_ok = false;
     const bool tile_candidate = c->tile_svi && c->tile_ready && !c->profile_param && !c->d.eps_mu_in && !c->d.eps_sd_in &&
                                 !c->d.pi_in && !c->d.eps_noise_in && !c->d.eps_mu_out && !c->d.eps_sd_out &&
                                 !c->d.eps_noise_out && !(c->d.flags & kDumpPi);
@@ -1492,6 +1508,108 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
     return 0;
 }
 
+// ---- bean_hip_svi_resume: the loop of a fit that is stepped in windows (run_inference: 100 steps at a time)
+// n steps and the loss of those n slots (finalized from the device step counter: the group is self-contained,
+// so a captured one closes itself and no launch has to follow the last graph of a call)
+static void enqueue_resume_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n) {
+    if (n == 0) return;
+    for (uint64_t i = 0; i < n; ++i) {
+        launch_guide(c, stream);
+        launch_param<true, true, true>(c, stream);
+    }
+    launch_finalize(c, stream, 0, n, true);
+}
+
+static int capture_resume_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n, hipGraphExec_t* out) {
+    hipGraph_t graph = nullptr;
+    HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    enqueue_resume_pairs(c, stream, n);
+    hipError_t e = hipStreamEndCapture(stream, &graph);
+    if (e != hipSuccess) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            hipGraph_t junk = nullptr;
+            (void)hipStreamEndCapture(stream, &junk);
+            if (junk) (void)hipGraphDestroy(junk);
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
+
+extern "C" int bean_hip_svi_resume(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
+                                   int32_t graph_chunk, void* stream_) {
+    if (!c) return fail("bean_hip_svi_resume: null handle");
+    if (!c->prepared) return fail("bean_hip_svi_resume: call bean_hip_prepare first");
+    const DevArgs& dd = c->d;
+    // noise injected or dumped per step, a timed k_param, the opt-in steppers: the plain loop
+    if (dd.eps_mu_in || dd.eps_sd_in || dd.pi_in || dd.eps_noise_in || dd.eps_mu_out || dd.eps_sd_out || dd.eps_noise_out ||
+        dd.x0_in || dd.eps_u_in || dd.x0_out || dd.eps_u_out || (dd.flags & kDumpPi) || c->profile || c->profile_param ||
+        c->fused_step || c->tile_svi || stream_ == nullptr)
+        return bean_hip_svi_run(c, seed, first_step, n_steps, graph_chunk, stream_);
+    if (check_bound(c, false, true)) return -1;
+    if (n_steps == 0) return 0;
+    if (first_step + n_steps > c->loss_capacity)
+        return fail("bean_hip_svi_resume: loss_hist too small for first_step + n_steps");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c->graphs_resume.empty() && c->graph_seed != seed) drop_graph(c);
+    const bool resumed = c->resume_ok && c->resume_next == first_step && c->resume_seed == seed &&
+                         c->resume_stream == stream_;
+    c->resume_ok = false;
+    c->d.seed = seed;
+    int kmax = 0;
+    if (graph_chunk > 1) {
+        // graphs of 4, 8, ... <= graph_chunk pairs, all instantiated at the first call
+        while ((8ull << kmax) <= (uint64_t)graph_chunk && kmax < 8) ++kmax;
+        if ((int)c->graphs_resume.size() != kmax + 1) {
+            drop_graph(c);
+            for (int k = 0; k <= kmax; ++k) {
+                hipGraphExec_t ge = nullptr;
+                if (capture_resume_pairs(c, stream, 4ull << k, &ge)) {
+                    drop_graph(c);
+                    return -1;
+                }
+                c->graphs_resume.push_back(ge);
+            }
+            c->graph_seed = seed;
+        }
+    }
+    if (!resumed) {
+        launch_set_step(c, stream, first_step, first_step, n_steps);
+        launch_param<false, false, true>(c, stream);  // draw and tables of the first step
+    }
+    uint64_t left = n_steps;
+    if (graph_chunk > 1 && !c->graphs_resume.empty()) {
+        // one to four pairs directly - the device starts on an eager launch some 15 us sooner than on a graph
+        // launch, and works on them while the host submits the graphs - then graphs, smallest first
+        const uint64_t head = left % 4 ? left % 4 : (left >= 4 ? 4 : 0);
+        enqueue_resume_pairs(c, stream, head);
+        left -= head;
+        const uint64_t big = left >> (kmax + 2);
+        const uint64_t rest = left - (big << (kmax + 2));
+        for (int k = 0; k < kmax; ++k)
+            if (rest & (4ull << k)) HIP_OK(hipGraphLaunch(c->graphs_resume[k], stream));
+        for (uint64_t i = 0; i < big; ++i) HIP_OK(hipGraphLaunch(c->graphs_resume[kmax], stream));
+        left = 0;
+    }
+    enqueue_resume_pairs(c, stream, left);
+    HIP_OK(hipGetLastError());
+    // the last k_param has drawn step first_step + n_steps and filled its tables
+    c->resume_ok = true;
+    c->resume_next = first_step + n_steps;
+    c->resume_seed = seed;
+    c->resume_stream = stream_;
+    return 0;
+}
+
 // ---- guide-sharded stepping with exchange points (see bean_hip.h)
 extern "C" int bean_hip_sharded_begin(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
                                       void* stream_) {
@@ -1509,6 +1627,7 @@ extern "C" int bean_hip_sharded_begin(bean_hip_ctx* c, uint64_t seed, uint64_t f
         return fail("bean_hip_sharded_begin: bind BEAN_BUF_XCHG_TGRAD for a sharded ControlNormal / tiling fit");
     hipStream_t stream = (hipStream_t)stream_;
     c->d.seed = seed;
+    c->resume_ok = false;
     launch_set_step(c, stream, first_step, first_step, n_steps);
     launch_param<false, false, true>(c, stream);
     HIP_OK(hipGetLastError());

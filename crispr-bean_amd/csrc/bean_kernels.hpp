@@ -3549,15 +3549,23 @@ __global__ __launch_bounds__(256) void k_loss_finalize(DevArgs c, unsigned long 
     const int lane = threadIdx.x & 63;
     unsigned long long i = first + (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (cur) {
-        if (blockIdx.x != 0 || threadIdx.x >= 64) return;
-        i = c.ctrA->slot;
+        // the n slots that end with the step which has just finished (device step counter): what a captured
+        // graph of n steps closes with, whatever step it is replayed at
+        const unsigned long long k = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (k >= n) return;
+        i = c.ctrA->slot - k;
     } else if (i >= first + n) {
         return;
     }
     static_assert(kLossSub == 64, "one accumulator line per lane");
-    const long long* acc = c.loss_acc + ((long)i * kLossSub + lane) * kLossWords;
-    const long long hi = wave_sum_i64(acc[0]), lo = wave_sum_i64(acc[1]);
-    long long bad = acc[2] != 0 ? 1 : 0;
+    long long* acc = c.loss_acc + ((long)i * kLossSub + lane) * kLossWords;
+    const long long a0 = acc[0], a1 = acc[1], a2 = acc[2];
+    // a finalized slot is left at zero: bean_hip_svi_resume starts a window without k_set_step
+    acc[0] = 0;
+    acc[1] = 0;
+    acc[2] = 0;
+    const long long hi = wave_sum_i64(a0), lo = wave_sum_i64(a1);
+    long long bad = a2 != 0 ? 1 : 0;
     bad = wave_sum_i64(bad);
     if (lane == 0) {
         const double v = bad != 0 ? __builtin_nan("")

@@ -592,16 +592,21 @@ class HipSVI:
         with self._on_stream():
             self._check(self.lib.bean_hip_adam(self._h, int(t), self._sptr()), "adam")
 
-    def run(self, n_steps: int, seed: int = 101, graph_chunk: int = 50, first_step: Optional[int] = None):
-        """Enqueue ``n_steps`` fused SVI steps (no host synchronisation)."""
+    def run(self, n_steps: int, seed: int = 101, graph_chunk: int = 50, first_step: Optional[int] = None,
+            resume: bool = False):
+        """Enqueue ``n_steps`` fused SVI steps (no host synchronisation).
+
+        ``resume=True`` (``bean_hip_svi_resume``): for a fit stepped in windows.  Same results; a call that
+        continues exactly where the previous one ended starts stepping at once (the previous call has left
+        the next step's draw and tables on the device).  The caller promises not to write the parameter /
+        moment tensors between such calls - ``run_inference`` and ``bench.py`` do not."""
         first = self.steps_done if first_step is None else int(first_step)
         if first + n_steps > self.loss_hist.numel():
             raise ValueError("loss history too small: raise num_steps / loss_capacity")
+        fn = self.lib.bean_hip_svi_resume if resume else self.lib.bean_hip_svi_run
         with self._on_stream():
-            self._check(
-                self.lib.bean_hip_svi_run(self._h, int(seed), first, int(n_steps), int(graph_chunk), self._sptr()),
-                "svi_run",
-            )
+            self._check(fn(self._h, int(seed), first, int(n_steps), int(graph_chunk), self._sptr()),
+                        "svi_resume" if resume else "svi_run")
         self.steps_done = first + n_steps
 
     def losses(self):

@@ -144,7 +144,7 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
             while done < num_steps:
                 k = min(report_every, num_steps - done)
                 eng.window_start = eng.snapshot()  # what a halt inside this window dumps
-                eng.run(k, seed=seed)
+                eng.run(k, seed=seed, resume=True)
                 # the reference halts at the failing step (run.py:375-390); here at the end of its report window
                 window = eng.loss_hist[done:done + k]
                 parallel.check_window_finite(window, done)

@@ -197,7 +197,7 @@ def run_sharded(
         if exchanged:
             eng.run_exchanged(k, grp.all_reduce_sum, seed=seed)
         else:
-            eng.run(k, seed=seed)
+            eng.run(k, seed=seed, resume=True)
         window = eng.loss_hist[done : done + k]
         stream = getattr(eng, "stream", None)
         if stream is not None:

@@ -246,6 +246,17 @@ int bean_hip_adam(bean_hip_ctx* ctx, uint64_t t, void* stream);
 int bean_hip_svi_run(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step,
                      uint64_t n_steps, int32_t graph_chunk, void* stream);
 
+/* The same loop for a fit that is stepped in windows (run_inference reports every 100 steps,
+ * bean/model/run.py:378): results are those of bean_hip_svi_run, bit for bit, but the call ends with the
+ * draw and the tables of step first_step + n_steps already on the device, and a call that continues exactly
+ * there - same seed, same stream, first_step = the previous call's first_step + n_steps, nothing bound,
+ * prepared or stepped through another entry point in between - starts stepping at once instead of with the
+ * two preparing launches.  The caller asserts that it has not written the bound parameter / moment buffers
+ * since the previous call returned (the library cannot see such writes; use bean_hip_svi_run after one).
+ * Falls back to bean_hip_svi_run when per-step noise is injected or dumped. */
+int bean_hip_svi_resume(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step,
+                        uint64_t n_steps, int32_t graph_chunk, void* stream);
+
 /* The same loop for guide-sharded fits of families in which something is shared across the
  * shards (the reference is single-process, so there is no interface to
  * mirror).  The step is cut at its exchange points; after each call that names a buffer the

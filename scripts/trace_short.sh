@@ -4,16 +4,16 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/trace_short
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strong > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strong --no-other-configs > $OUT/bench.json 2> $OUT/err.txt
 cd $REPO && python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/trace_short/kt/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# the timed call = the last k_set_step ... k_loss_finalize group with 20 guide launches
-idx = [i for i, r in enumerate(rows) if "k_set_step" in r["Kernel_Name"]]
-for s in idx[-3:]:
-    e = next(i for i in range(s, len(rows)) if "k_loss_finalize" in rows[i]["Kernel_Name"])
+# a call = the launches up to and including a k_loss_finalize (a resumed call has no k_set_step at its head)
+ends = [i for i, r in enumerate(rows) if "k_loss_finalize" in r["Kernel_Name"]]
+starts = [0] + [e + 1 for e in ends[:-1]]
+for s, e in list(zip(starts, ends))[-3:]:
     grp = rows[s:e + 1]
     n_guide = sum("k_guide_wave2" in r["Kernel_Name"] for r in grp)
     t0 = int(grp[0]["Start_Timestamp"])

@@ -54,7 +54,7 @@ class OracleEngine:
         return {"eps_mu": torch.tensor(eps_mu[t0:t1]), "eps_sd": torch.tensor(eps_sd[t0:t1]),
                 "pi": torch.tensor(pi)}
 
-    def run(self, k, seed=101):
+    def run(self, k, seed=101, resume=False):
         for _ in range(k):
             s = self.steps_done
             self.loss_hist[s] = svi.svi_step(elbo.LOSSES[FAMILY], self.data, self.params, self.optim,
