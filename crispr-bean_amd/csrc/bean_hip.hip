@@ -702,11 +702,19 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
         HIP_OK(hipStreamSynchronize(stream));
         std::vector<int> live;
         live.reserve((size_t)(G * A1));
-        for (long a1 = 0; a1 < A1; ++a1)
-            for (long g = 0; g < G; ++g) {
-                const long slot = g * A1 + a1;
-                if (mask[(size_t)(g * A + a1 + 1)] != 0 || ptr[(size_t)slot + 1] > ptr[(size_t)slot]) live.push_back((int)(a1 * G + g));
-            }
+        // in the order the tables are laid out (tab_off): guide-contiguous for the register-resident kernels,
+        // allele-contiguous for the allele-parallel ones - consecutive k_allele threads store next to each other
+        auto consider = [&](long a1, long g) {
+            const long slot = g * A1 + a1;
+            if (mask[(size_t)(g * A + a1 + 1)] != 0 || ptr[(size_t)slot + 1] > ptr[(size_t)slot]) live.push_back((int)(a1 * G + g));
+        };
+        if (d.wide_alleles) {
+            for (long g = 0; g < G; ++g)
+                for (long a1 = 0; a1 < A1; ++a1) consider(a1, g);
+        } else {
+            for (long a1 = 0; a1 < A1; ++a1)
+                for (long g = 0; g < G; ++g) consider(a1, g);
+        }
         if (!c->live_slots) HIP_OK(hipMalloc(&c->live_slots, (size_t)(G * A1) * sizeof(int)));
         if (!live.empty())
             HIP_OK(hipMemcpyAsync(c->live_slots, live.data(), live.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -1168,7 +1176,7 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
     }
     if (c->tiling_wide) {
         const bool acc = (d.flags & kAcc) != 0;
-        const dim3 gridw((unsigned)((long)d.R * d.G)), blockw(64);
+        const dim3 gridw((unsigned)(((long)d.G + 7) / 8 * 8 * d.R)), blockw(64);
         const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof) {

@@ -254,6 +254,19 @@ __device__ __forceinline__ double uniform_ld(const double* p, int i) {
     return ((cptr)(unsigned long long)p)[i];
 }
 
+// Layout of the per-allele-slot tables (tabP, tabPmu, tabPy: `b`-th plane of slot (a1, g)) and of mu_a / sig_a.
+// The register-resident tiling kernels run one lane per GUIDE, so the guide index is the contiguous one:
+// (B, A - 1, G) and (A - 1, G).  The allele-parallel kernels (bean_tiling_wide.hpp, DevArgs::wide_alleles) run
+// one lane per ALLELE of one guide: there the allele index is contiguous - (B, G, A - 1) and (G, A - 1) - so
+// that a wave's 64 lanes read consecutive doubles instead of 64 cache lines.
+__device__ __forceinline__ long tab_off(const DevArgs& c, int b, int a1, long g) {
+    const long A1 = c.A - 1;
+    return c.wide_alleles ? ((long)b * c.G + g) * A1 + a1 : ((long)b * A1 + a1) * c.G + g;
+}
+__device__ __forceinline__ long slot_off(const DevArgs& c, int a1, long g) {
+    return c.wide_alleles ? g * (long)(c.A - 1) + a1 : (long)a1 * c.G + g;
+}
+
 // ---------------------------------------------------------------- loss accumulation
 // Every wave / block adds its part of the step's loss with INTEGER atomics: the part is split exactly
 // into a multiple of 2^-10 and a remainder rounded to 2^-40, so the sum does not depend on the order
@@ -393,6 +406,12 @@ __device__ __forceinline__ double part_row(const DevArgs& c, int q, int g) {
 __device__ __forceinline__ double trow_sum(const DevArgs& c, int q, long g) {
     if (!c.trow || c.trow_summed) return c.part[(long)q * c.G + g];
     double s = 0.0;
+    if (c.wide_alleles) {
+        // allele-parallel path: the rows of a (replicate, guide) are contiguous, (R, G, Q)
+        const long Q = 2 + 2 * (long)c.A + 2 * ((long)c.A - 1);
+        for (int r = 0; r < c.R; ++r) s += c.trow[((long)r * c.G + g) * Q + q];
+        return s;
+    }
     for (int r = 0; r < c.R; ++r) s += c.trow[((long)q * c.R + r) * c.G + g];
     return s;
 }
@@ -825,7 +844,7 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
             for (int k = c.e2a_ptr[t] + lg; k < c.e2a_ptr[t + 1]; k += lpt) {
                 const int slot = c.e2a_idx[k];
                 const int a1 = slot % A1, gs = slot / A1;
-                const long o = (long)a1 * c.G + gs;
+                const long o = slot_off(c, a1, gs);
                 a += trow_sum(c, q_gmu + a1, gs);
                 // d sigma_a / d y_e = sd_e^2 / sigma_a
                 if (!c.survival) b += trow_sum(c, q_gsig + a1, gs) * sd * sd / c.sig_a[o];
@@ -2685,7 +2704,7 @@ void k_guide_survival(DevArgs c) {
 // k_guide_tiling_rep (the slots of the workgroup's own guides).
 __device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int g) {
     const int A1 = c.A - 1;
-    const long idx = (long)a1 * c.G + g;
+    const long idx = slot_off(c, a1, g);
     const long slot = (long)g * A1 + a1;
     const bool valid = c.amask[(long)g * c.A + a1 + 1] != 0;
     if (c.survival) {
@@ -2698,7 +2717,7 @@ __device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int
         for (int b = 0; b < c.B; ++b) {
             const double tb = c.time[b];
             const double P = valid ? exp(full * tb) : 0.0;
-            const long o = ((long)b * A1 + a1) * c.G + g;
+            const long o = tab_off(c, b, a1, g);
             c.tabP[o] = P;
             c.tabPmu[o] = tb * P;
             c.tabPy[o] = 0.0;
@@ -2753,7 +2772,7 @@ __device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int
             dmu = -(fh - fl) * inv;
             dsig = -(ufh - ufl) * inv;
         }
-        const long o = ((long)b * A1 + a1) * c.G + g;
+        const long o = tab_off(c, b, a1, g);
         c.tabP[o] = P;
         c.tabPmu[o] = dmu;
         c.tabPy[o] = dsig;  // d/d sigma_a here (chain to y_e in k_param)

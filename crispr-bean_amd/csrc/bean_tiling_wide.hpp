@@ -10,7 +10,10 @@
 //   param_guide_tiling_wide   the per-guide finish of k_param, one wave per guide
 //
 // Row layout (runtime A): 0 d/dnoise | 1 n unmasked replicates | 2 + a path_a | 2 + A + a log pi_a |
-// 2 + 2A + s d/dmu of allele slot s | 2 + 2A + (A-1) + s d/dsigma of slot s.
+// 2 + 2A + s d/dmu of allele slot s | 2 + 2A + (A-1) + s d/dsigma of slot s; the rows of one (replicate,
+// guide) are contiguous, trow is (R, G, Q) (trow_sum), and the allele tables are allele-contiguous (tab_off):
+// round 4 - with the guide-contiguous layouts of the narrow kernels every load and store of this kernel
+// touched 64 cache lines (5.8 % VALU-busy, 1.86 ms per launch at 5 000 guides x 232 slots).
 // Same arithmetic as k_guide_tiling_wave; the random stream is keyed per allele (site, (replicate,
 // guide) * 256 + allele), so it differs from the narrow kernels' - they never meet: the engine picks the
 // wide path only when n_max_alleles exceeds what the narrow build holds.
@@ -26,22 +29,24 @@ __host__ __device__ inline int tq_gmu(int A) { return 2 + 2 * A; }
 __host__ __device__ inline int tq_gsig(int A) { return 2 + 2 * A + (A - 1); }
 __host__ __device__ inline int tq_num(int A) { return 2 + 2 * A + 2 * (A - 1); }
 
-// sum over the wave, result in every lane (fixed butterfly)
-__device__ __forceinline__ double wave_allsum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+// sum over the wave, result in every lane: the DPP scan of wave_sum (fixed order; six row operations and a
+// readlane instead of six trips through the LDS crossbar - this kernel takes ~30 such sums per wave)
+__device__ __forceinline__ double wave_allsum(double v) { return wave_sum(v); }
 
 template <bool ACC, bool SURV>
 __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
     const int lane = threadIdx.x;
-    const long rg = blockIdx.x;
     const int G = c.G, A = c.A, A1 = c.A - 1, B = c.B, R = c.R;
-    const int r = (int)(rg / G), g = (int)(rg % G);
+    // the R waves of a guide read the same table columns: they get block ids that are equal modulo 8 (one
+    // XCD, one L2) and adjacent in dispatch order, so the columns come from HBM once, not R times
+    const int wg = blockIdx.x, kk = wg >> 3;
+    const int r = kk % R, g = (kk / R) * 8 + (wg & 7);
+    if (g >= G) return;
     const StepCtr ctr = *c.ctrB;
-    const long RG = (long)R * G;
-    double* row = c.trow + (long)r * G + g;  // row q of this (replicate, guide) at row[q * RG]
+    // the rows of this (replicate, guide) are contiguous - row q at row[q] - so that lanes (= alleles) store
+    // consecutive doubles: (R, G, Q)
+    double* row = c.trow + ((long)r * G + g) * tq_num(A);
+    constexpr long RG = 1;
     const bool rgm = c.rg[(long)r * G + g] != 0;
     const bool use_bc = (c.flags & kUseBc) != 0;
     double loss = 0.0;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
 #pragma unroll
             for (int j = 0; j < kWideSlots; ++j) {
                 const int a = j * 64 + lane;
-                if (a >= 1 && a < A) part += pe[j] * c.tabP[((long)b * A1 + (a - 1)) * G + g];
+                if (a >= 1 && a < A) part += pe[j] * c.tabP[tab_off(c, b, a - 1, g)];
             }
             const double p0b = SURV ? exp(u * c.time[b]) : c.P0[b];
             const double eb = wave_allsum(part) + pe0 * p0b;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
             for (int j = 0; j < kWideSlots; ++j) {
                 const int a = j * 64 + lane;
                 if (a >= 1 && a < A) {
-                    const long o = ((long)b * A1 + (a - 1)) * G + g;
+                    const long o = tab_off(c, b, a - 1, g);
                     sa[j] += ge * c.tabP[o];
                     dm[j] += ge * c.tabPmu[o];
                     if (!SURV) dsg[j] += ge * c.tabPy[o];
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
                     gr[j] = 0.0;
                     cnt[j] = 0.0;
                     if (a < A) {
-                        gr[j] = exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+                        gr[j] = exp((a == 0 ? u : u + c.mu_a[slot_off(c, a - 1, g)]) * tc);
                         cnt[j] = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
                         wpart += pi[j] * gr[j];
                     }
@@ -326,6 +331,7 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
         loss_add(c, ctr.slot, tot);
         if (blockIdx.x == 0) publish_ctr(c, ctr);
     }
+    (void)A1;
 }
 
 // Guide part of k_param for the wide tiling path: one wave per guide, lane l owns alleles l, l + 64, ...
