@@ -829,8 +829,8 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
     const bool kind1 = !d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
                        d.rows_v2 && !d.rrow && !d.surv_q0lik && !d.not_loss_owner && d.lpart &&
                        (d.dgq || d.family != kMixture) && d.tsum;
-    const bool kind2 = d.survival && d.family != kMultiMixture && !d.wide_targets && !d.tgrad && !d.n_cov && d.wrow &&
-                       d.rows_v2 && !d.rrow && d.lpart && d.lpt == kLanesPerTargetNarrow;
+    const bool kind2 = d.survival && d.family == kMixture && !d.surv_q0lik && d.dgq && !d.tsum && !d.wide_targets && !d.tgrad &&
+                       !d.n_cov && d.wrow && d.rows_v2 && !d.rrow && d.lpart && d.lpt == kLanesPerTargetNarrow;
     const bool kind3 = d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov &&
                        !d.lpart && d.trow_summed && !d.surv_q0lik && d.lpt == kLanesPerTargetNarrow;
     // BEAN_HIP_PARAM_KIND=0 forces the generic build (the test that the specialised builds change nothing)

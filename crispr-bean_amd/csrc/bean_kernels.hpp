@@ -1273,10 +1273,13 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(c.dgq != nullptr || c.family != kMixture);
         __builtin_assume(c.tsum != nullptr);
     }
-    if (KIND == 2) {  // the survival variant families on the wave-form path (thin mode, unsharded parameters)
+    if (KIND == 2) {  // survival variant MixtureNormal on the wave-form path (thin mode, unsharded parameters)
         __builtin_assume(c.lpt == kLanesPerTargetNarrow);
         __builtin_assume(c.survival != 0);
-        __builtin_assume(c.family != kMultiMixture);
+        __builtin_assume(c.family == kMixture);
+        __builtin_assume(!c.surv_q0lik);
+        __builtin_assume(c.dgq != nullptr);
+        __builtin_assume(c.tsum == nullptr);
         __builtin_assume(!c.wide_targets);
         __builtin_assume(c.tgrad == nullptr);
         __builtin_assume(c.n_cov == 0);

@@ -35,8 +35,14 @@ namespace bean {
 // run until 66 us - 593 of the 1 024 SIMDs do five waves' work (5 x 13.2 us) and the others four.  Raising the late
 // waves' priority (s_setprio) makes THEM finish early and the older waves of the same SIMDs late: 64.2 us.
 // The launch is at its issue bound for whole-wave work items; the balance is a property of 4 689 / 1 024.
+// (round 4) + kSurvPark thread-private columns in which values that are loaded with the first batch but needed
+// only after the likelihoods wait (log of the observed t0 abundance, the gamma draw of the Dirichlet-over-guides
+// site, pi_a0, alpha_pi, q0; with accessibility scaling the two derivatives of the transform): the kernel needed
+// 128 VGPRs + 11 spilled (27 with accessibility) to carry them through the timepoint loops; 8.9 KB per wave
+// still lets sixteen single-wave workgroups share a CU.
+constexpr int kSurvPark = 7;
 __host__ __device__ inline size_t guide_survival_wave_lds(int B) {
-    return ((size_t)4 * B + (size_t)2 * B * 64) * sizeof(double);
+    return ((size_t)4 * B + (size_t)2 * B * 64 + (size_t)kSurvPark * 64) * sizeof(double);
 }
 
 #ifndef BEAN_SURV_EU
@@ -64,12 +70,14 @@ void k_guide_survival_wave(DevArgs c) {
     double* cst = sls;
     double* p0s = cst + 4 * B + lane;              // exp(u t_b)          at p0s[b * 64]
     double* p1s = cst + 4 * B + B * 64 + lane;     // exp((u + mu_t) t_b) at p1s[b * 64]
+    double* park = cst + 4 * B + 2 * B * 64 + lane;  // parked values at park[k * 64] (thread-private)
+    enum { kPkLobs = 0, kPkGam = 1, kPkPa0 = 2, kPkApi = 3, kPkP7 = 4, kPkDpi = 5, kPkU = 6 };
     const bool use_bc = (c.flags & kUseBc) != 0;
     const bool q0lik = !MIX && c.surv_q0lik;
     bool rgm = false, negc = false;
     uint4 philox_first = make_uint4(0u, 0u, 0u, 0u);
-    float api0 = 0.f, api1 = 0.f, p7 = 0.f;
-    double pa0 = 0.0, mu_t = 0.0, u = 0.0, gam = 0.0, lobs = 0.0, a00 = 0.0, a01 = 0.0;
+    float api0 = 0.f, api1 = 0.f;
+    double pa0 = 0.0, mu_t = 0.0, u = 0.0, gam = 0.0, a00 = 0.0, a01 = 0.0;
     double n_x = 0.0, n_bc = 0.0;
     {
         const int gc = valid ? g : G - 1;
@@ -100,6 +108,8 @@ void k_guide_survival_wave(DevArgs c) {
         if (MIX && !c.pi_in) philox_first = philox_block(c.seed, ((unsigned long long)kSitePi << 48) +
                                                                    ((unsigned long long)r * c.G_tot + (c.g_off + gc)),
                                                          ctr.step * 256ull);
+        double lobs = 0.0;
+        float p7 = 0.f;
         if (MIX) {
             api0 = c.p[4][2 * gc];
             api1 = c.p[4][2 * gc + 1];
@@ -134,6 +144,18 @@ void k_guide_survival_wave(DevArgs c) {
                 }
             }
         }
+        // needed after the likelihoods only: parked (MixtureNormal: the gamma draw too - NormalModel uses it
+        // as a weight of the likelihood right away)
+        // (+Acc: the draw pi_0, pi_1 is not a weight of the likelihood and takes the first two columns; the log
+        // abundance and the gamma draw are loaded where they are used)
+        if (!(MIX && ACC)) park[kPkLobs * 64] = lobs;
+        park[kPkP7 * 64] = (double)p7;
+        if (MIX) {
+            if (!ACC) park[kPkGam * 64] = gam;
+            park[kPkPa0 * 64] = pa0;
+            park[kPkApi * 64] = __builtin_bit_cast(double, ((unsigned long long)__builtin_bit_cast(unsigned int, api1) << 32) |
+                                                               (unsigned long long)__builtin_bit_cast(unsigned int, api0));
+        }
     }
     __syncthreads();
 
@@ -152,6 +174,10 @@ void k_guide_survival_wave(DevArgs c) {
             p1s[b * 64] = exp(mu1 * tb);
             if (MIX) p0s[b * 64] = exp(u * tb);
         }
+        if (MIX) park[kPkU * 64] = u;
+        // (a compiler-level fence after a park: without it the stored value is forwarded to its later load, i.e.
+        // stays in its register, and nothing is gained)
+        asm volatile("" ::: "memory");
         double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0, dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
         if (MIX) {
             const double al0 = (double)expf(api0), al1 = (double)expf(api1);
@@ -186,12 +212,16 @@ void k_guide_survival_wave(DevArgs c) {
                 pe1 = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
                 dpe1_dl = in2 ? pn * (1.0 - pn) : 0.0;
                 dpe1_dpi1 = in1 ? dpe1_dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+                park[kPkDpi * 64] = dpe1_dpi1;  // (d pe1 / d l is pe1 (1 - pe1) inside the clamp, 0 on it: re-formed below)
+                park[kPkLobs * 64] = pi0;
+                park[kPkGam * 64] = pi1;
+                asm volatile("" ::: "memory");
             }
         }
         // the draw of the Dirichlet-over-all-guides site, float32 semantics of torch's sampler:
-        // normalise, clamp to [FLT_MIN, 1 - 2^-24]
+        // normalise, clamp to [FLT_MIN, 1 - 2^-24] (MixtureNormal: formed after the likelihoods, where it is used)
         double x0 = 1.0;
-        if (MIX || q0lik) {
+        if (q0lik) {
             x0 = c.x0_in ? gam
                          : (double)fminf(fmaxf((float)(gam * frcp(c.gsum[r])), 1.17549435e-38f), 0.99999994f);
             if (c.x0_out) c.x0_out[rgi] = x0;
@@ -201,13 +231,6 @@ void k_guide_survival_wave(DevArgs c) {
         const double w1 = MIX ? (ACC ? pe1 : pi1) : (q0lik ? x0 : 1.0);
         const double epsB = kEps / (double)B;
         double g0 = 0.0, g1 = 0.0, dmu = 0.0, nll = 0.0;
-        double S_x = 0.0, S_bc = 0.0;
-#pragma unroll 1
-        for (int b = 0; b < B; ++b) {
-            const double e = fma(w0, MIX ? p0s[b * 64] : 0.0, w1 * p1s[b * 64]);
-            S_x += e * c_sf[b];
-            S_bc += e * c_sf[B + b];
-        }
 #pragma unroll 1
         for (int lik = 0; lik < 2; ++lik) {
             if (lik == 1 && !use_bc) break;
@@ -215,7 +238,11 @@ void k_guide_survival_wave(DevArgs c) {
             if (!(rgm && nn > (double)c.mask_thres)) continue;
             const float* xp = (lik ? c.Xbc : c.X) + (long)r * B * G + g;  // timepoint b at xp[b * G]
             const double* sf = c_sf + lik * B;
-            const double S = lik ? S_bc : S_x;
+            // S = sum_b e_b sf_b of THIS likelihood (formed here, not for both ahead of the loop: two
+            // registers fewer to carry through the first likelihood)
+            double S = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) S += fma(w0, MIX ? p0s[b * 64] : 0.0, w1 * p1s[b * 64]) * sf[b];
             const double a0 = lik ? a01 : a00;
             const double inv = frcp(S + kEps);
             const double ai = a0 * inv;
@@ -276,7 +303,7 @@ void k_guide_survival_wave(DevArgs c) {
         if (q0lik) {
             // survival NormalModel: - log p(q_0) + log q(q_0) = (ia - 1/G) log x per guide (normalisers
             // in k_param); d loss / d q_0 for the pathwise gradient of the G-dimensional Dirichlet
-            const double ia = (double)expf(p7);
+            const double ia = (double)expf((float)park[kPkP7 * 64]);
             const double dconc = ia - (c.prior_ia ? c.prior_ia[g] : (double)(1.0f / (float)c.G_tot));
             const double lx = flog(x0);
             nll += dconc * lx;
@@ -284,17 +311,22 @@ void k_guide_survival_wave(DevArgs c) {
             row[kPQ0 * RG] = lx;
         }
         if (MIX) {
-            // the concentrations again (as before the draw: same expression, same bits)
-            const double al0 = (double)expf(api0), al1 = (double)expf(api1);
-            const double rs = frcp(al0 + al1) * pa0;
+            // the concentrations again (as before the draw: same expression, same bits), from the parked inputs
+            const unsigned long long apb = __builtin_bit_cast(unsigned long long, park[kPkApi * 64]);
+            const float api0r = __builtin_bit_cast(float, (unsigned int)apb);
+            const float api1r = __builtin_bit_cast(float, (unsigned int)(apb >> 32));
+            const double al0 = (double)expf(api0r), al1 = (double)expf(api1r);
+            const double rs = frcp(al0 + al1) * park[kPkPa0 * 64];
             const double cp0 = al0 * rs, cp1 = al1 * rs;
             const bool cl0 = cp0 < 1e-5, cl1 = cp1 < 1e-5;
             const double cq0 = cl0 ? 1e-5 : cp0, cq1 = cl1 ? 1e-5 : cp1;
             double gpi0 = g0, gpi1 = g1;
             if (ACC) {
+                pi0 = park[kPkLobs * 64];
+                pi1 = park[kPkGam * 64];
                 gpi0 = 0.0;
-                gpi1 = (g1 - g0) * dpe1_dpi1;
-                row[kW2Gnoise * RG] = (g1 - g0) * dpe1_dl;
+                gpi1 = (g1 - g0) * park[kPkDpi * 64];
+                row[kW2Gnoise * RG] = (g1 - g0) * ((pe1 > 1e-3 && pe1 < 1.0 - 1e-3) ? pe1 * (1.0 - pe1) : 0.0);
             }
             // digamma of the concentrations, tabulated by k_param (DevArgs::dgq): issued here, used
             // by the implicit-gradient calls below
@@ -303,9 +335,10 @@ void k_guide_survival_wave(DevArgs c) {
             const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
             if (rgm) {
                 // control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)) (survival_model.py:326-346)
+                const double ur = park[kPkU * 64], mu1r = ur + mu_t;
                 for (int cc = 0; cc < c.C; ++cc) {
                     const double tc = c.ctrl_time[cc];
-                    const double gr0 = exp(u * tc), gr1 = exp(mu1 * tc);
+                    const double gr0 = exp(ur * tc), gr1 = exp(mu1r * tc);
                     const double wv0 = pi0 * gr0, wv1 = pi1 * gr1;
                     const double rW = frcp(wv0 + wv1);
                     const float* al = c.allele + (((long)r * c.C + cc) * G + g) * 2;
@@ -345,9 +378,14 @@ void k_guide_survival_wave(DevArgs c) {
             // ---- Dirichlet(q0) site: + log q(x) of the guide's draw, - log p(obs) of the model
             // (observed in the model, sampled in the guide: survival_model.py:306-311, 665-669)
             {
-                const double q0 = (double)expf(p7);
+                const double gamr = ACC ? c.gam[rgi] : park[kPkGam * 64];
+                x0 = c.x0_in ? gamr
+                             : (double)fminf(fmaxf((float)(gamr * frcp(c.gsum[r])), 1.17549435e-38f), 0.99999994f);
+                if (c.x0_out) c.x0_out[rgi] = x0;
+                const double q0 = (double)expf((float)park[kPkP7 * 64]);
                 const double lx = flog(x0);
                 const double tot0 = c.gsum[R];
+                const double lobs = ACC ? c.log_obs0[rgi] : park[kPkLobs * 64];
                 nll += (q0 - 1.0) * (lx - lobs);
                 const double gout = (q0 - 1.0) * frcp(x0);
                 const double Sx = tot0 - (double)c.G_tot;  // sum_g x_g * gout_g
