@@ -339,9 +339,11 @@ __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCt
 // c.seg_steps = ceil(log2(longest target, capped at a tile)).  The lane at the end of each segment stores
 // the pair: tsum[(q R + r) S + tile ntm + tcol], S = n_tiles ntm (STEP: agent-scope stores, as the rows).
 // Lanes without a guide (the ends of a shard's first and last tile) carry tcol = -1 and zeros.
+// tsum_direct (no target longer than a tile): the slot is 2 t, or 2 t + 1 for the wave's FIRST segment when its
+// target began in the previous tile (`cont0`) - a target then has at most these two parts.
 template <bool STEP>
 __device__ __forceinline__ void target_part_sums(const DevArgs& c, int lane, int tile, int r, int tcol, bool valid,
-                                                 double a_mu, double a_y) {
+                                                 double a_mu, double a_y, int t0, bool cont0) {
     // head of a segment: lane 0, or another target than the lane below
     const int below = __shfl_up(tcol, 1, 64);
     const bool head = lane == 0 || below != tcol;
@@ -360,8 +362,10 @@ __device__ __forceinline__ void target_part_sums(const DevArgs& c, int lane, int
         }
     }
     if (valid && tail) {
-        const long S = (long)c.n_tiles * c.tile_targets;
-        double* o = c.tsum + (long)r * S + (long)tile * c.tile_targets + tcol;
+        const long S = c.tsum_direct ? 2 * (long)c.T : (long)c.n_tiles * c.tile_targets;
+        const long slot = c.tsum_direct ? 2 * (long)(t0 + tcol) + ((tcol == 0 && cont0) ? 1 : 0)
+                                        : (long)tile * c.tile_targets + tcol;
+        double* o = c.tsum + (long)r * S + slot;
         w2_row_store<STEP>(o, a_mu);
         w2_row_store<STEP>(o + (long)c.R * S, a_y);
     }
@@ -400,6 +404,8 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     const int g_last = (tile * 64 + 63 - c.g_sh < G ? tile * 64 + 63 - c.g_sh : G - 1);
     const int t0 = __builtin_amdgcn_readfirstlane(c.g2t[g_first]);
     const int nt = __builtin_amdgcn_readfirstlane(c.g2t[g_last]) - t0 + 1;
+    // did the tile's first target begin in the previous tile?  (wave-uniform; used when the sums are stored)
+    const int tof_first = c.tsum_direct ? uniform_ld_i(c.toff, t0) : 0;
     const int ntm = c.tile_targets;
     t0_o = t0;
     nt_o = nt;
@@ -520,7 +526,7 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
         loss = guide_pair_math<FAM, ACC, STEP, 64>(c, ctr, r, g, rgm, api0, api1, pa0, &philox_first, tabs + tcol, ntm, cst,
                                                    cst + 2 * B, cst + 3 * B, xs + lane, dps, ms, ms + 64, ms + 2 * 64,
                                                    ms + 3 * 64, ms + 4 * 64, ms + 5 * 64, a_mu, a_y);
-    target_part_sums<STEP>(c, lane, tile, r, valid ? tcol : -1, valid, a_mu, a_y);
+    target_part_sums<STEP>(c, lane, tile, r, valid ? tcol : -1, valid, a_mu, a_y, t0, tof_first < g_first);
     tot_o = wave_sum(loss);
     BEAN_STAMP_AT(7);
     BEAN_STAMP_CLK(2);

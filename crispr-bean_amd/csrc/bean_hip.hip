@@ -664,20 +664,30 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
     HIP_OK(hipGetLastError());
     if (c->wave_guide) {
         // LDS sizing of k_guide_wave: a host read-back (4 bytes, setup only; the other one is the tiling work list below)
-        HIP_OK(hipMemsetAsync(c->tile_targets_dev, 0, sizeof(int), stream));
+        HIP_OK(hipMemsetAsync(c->tile_targets_dev, 0, 2 * sizeof(int), stream));
         const int tiles = c->wave2 ? c->d.n_tiles : (c->d.G + 63) / 64;
         hipLaunchKernelGGL(k_tile_targets, dim3((tiles + 255) / 256), dim3(256), 0, stream, c->d.g2t, c->d.G,
                            c->d.g_sh, c->tile_targets_dev);
         HIP_OK(hipGetLastError());
-        int nt = 0;
-        HIP_OK(hipMemcpyAsync(&nt, c->tile_targets_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+        // the shape's max_target_len decides the kernels' layouts (scan steps, two slots per target): checked
+        hipLaunchKernelGGL(k_max_target_len, dim3((c->d.T + 255) / 256), dim3(256), 0, stream, c->d.toff, c->d.T,
+                           c->tile_targets_dev + 1);
+        HIP_OK(hipGetLastError());
+        int ntl[2] = {0, 0};
+        HIP_OK(hipMemcpyAsync(ntl, c->tile_targets_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
+        const int nt = ntl[0];
         if (nt < 1 || nt > 64) return fail("bean_hip_prepare: guides are not sorted by target (BEAN_BUF_GUIDE_TO_TARGET)");
+        if (ntl[1] > c->shape.max_target_len)
+            return fail("bean_hip_prepare: bean_hip_shape.max_target_len = " + std::to_string(c->shape.max_target_len) +
+                        " but BEAN_BUF_TARGET_OFFSETS holds a target of " + std::to_string(ntl[1]) + " guides");
         if (nt != c->d.tile_targets) drop_graph(c);
         c->d.tile_targets = nt;
         if (c->wave2) {
             // per-target-part sums of d/dmu_t, d/dy_t (k_guide_wave2 -> k_param) and where each target's lie
-            const size_t n_sum = (size_t)2 * c->d.R * c->d.n_tiles * nt;
+            // no target longer than a tile (thin mode): two fixed slots per target, no descriptor to read
+            c->d.tsum_direct = (!c->d.wide_targets && c->shape.max_target_len >= 1 && c->shape.max_target_len <= 64) ? 1 : 0;
+            const size_t n_sum = c->d.tsum_direct ? (size_t)2 * c->d.R * 2 * c->d.T : (size_t)2 * c->d.R * c->d.n_tiles * nt;
             if (c->tsum_buf) (void)hipFree(c->tsum_buf);
             c->tsum_buf = nullptr;
             HIP_OK(hipMalloc((void**)&c->tsum_buf, n_sum * sizeof(double)));

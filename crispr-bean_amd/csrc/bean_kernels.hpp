@@ -218,6 +218,9 @@ struct DevArgs {
     int n_tiles;                     // (g_sh + G + 63) / 64
     int seg_steps;                   // ceil(log2(min(longest target, 64))): steps of the in-wave segmented scan
     double* tsum;                    // (2, R, n_tiles * tile_targets): sums per (replicate, tile, target of the tile); null: per-guide rows
+    int tsum_direct;                 // 1 (no target longer than a tile, thin mode): (2, R, 2 T) instead - target t's part in the tile it
+                                     // starts in at slot 2 t, its continuation in the next tile at 2 t + 1 (zero if there is none): the
+                                     // reader needs no descriptor, i.e. one dependent memory round trip less at the head of k_param
     const int2* tdesc;               // (T): {slot of the target's first part = tile * tile_targets + index in the tile, number of parts};
                                      //      part i >= 1 is the first target of the i-th next tile: slot (tile + i) * tile_targets
 };
@@ -265,6 +268,11 @@ __device__ __forceinline__ long tab_off(const DevArgs& c, int b, int a1, long g)
 }
 __device__ __forceinline__ long slot_off(const DevArgs& c, int a1, long g) {
     return c.wide_alleles ? g * (long)(c.A - 1) + a1 : (long)a1 * c.G + g;
+}
+
+__device__ __forceinline__ int uniform_ld_i(const int* p, int i) {
+    typedef const int __attribute__((address_space(4))) * cptr;
+    return ((cptr)(unsigned long long)p)[i];
 }
 
 // ---------------------------------------------------------------- loss accumulation
@@ -872,7 +880,17 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
         const int lpt = c.lpt;
         const int lg = threadIdx.x & (lpt - 1);
         double a = 0.0, b = 0.0;
-        if (t < c.T) {
+        if (t < c.T && c.tsum_direct) {
+            // both slots of the target, 2 R entries: part-major, as below (an absent continuation holds zeros)
+            const int R = c.R, n = 2 * R;
+            const long S = 2 * (long)c.T;
+            for (int i = lg; i < n; i += lpt) {
+                const int part = i >= R ? 1 : 0, r = i - part * R;
+                const long o = (long)r * S + 2 * (long)t + part;
+                a += c.tsum[o];
+                b += c.tsum[(long)R * S + o];
+            }
+        } else if (t < c.T) {
             const int2 dsc = c.tdesc[t];
             const int R = c.R, n = dsc.y * R, ntm = c.tile_targets;
             const long S = (long)c.n_tiles * ntm;
@@ -3546,6 +3564,12 @@ __global__ __launch_bounds__(256) void k_tile_targets(const int* g2t, int G, int
     atomicMax(out, g2t[last] - g2t[first] + 1);
 }
 
+// longest target (guides), from the offsets themselves; *out must start at 0
+__global__ __launch_bounds__(256) void k_max_target_len(const int* toff, int T, int* out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) atomicMax(out, toff[t + 1] - toff[t]);
+}
+
 // DevArgs::tdesc: where k_guide_wave2 leaves the partial sums of each target (bean_guide_v2.hpp)
 __global__ __launch_bounds__(256) void k_tdesc(DevArgs c, int2* out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3604,7 +3628,7 @@ __global__ __launch_bounds__(1024) void k_cov_sum(DevArgs c) {
     double v = 0.0;
     if (c.tsum) {
         // the guide kernel's per-target-part sums of this replicate (slots no target uses hold zero)
-        const long S = (long)c.n_tiles * c.tile_targets;
+        const long S = c.tsum_direct ? 2 * (long)c.T : (long)c.n_tiles * c.tile_targets;
         for (long i = threadIdx.x; i < S; i += blockDim.x) v += c.tsum[(long)r * S + i];
     } else {
         for (int g = threadIdx.x; g < c.G; g += blockDim.x) v += c.wrow[((long)kPGmu * c.R + r) * c.G + g];

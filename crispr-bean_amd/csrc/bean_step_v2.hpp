@@ -135,9 +135,12 @@ void k_step_wave2(DevArgs c, int flip) {
             const bool act = t <= tb;
             const int tc = act ? t : tb;
             // everything that does not depend on the sums first: one round trip
-            const int2 dsc = c.tdesc[tc];
+            int2 dsc;
+            dsc.x = 0;
+            dsc.y = 2;
+            if (!c.tsum_direct) dsc = c.tdesc[tc];
             const int n = dsc.y * R, ntm = c.tile_targets;
-            const long S = (long)c.n_tiles * ntm;
+            const long S = c.tsum_direct ? 2 * (long)c.T : (long)c.n_tiles * ntm;
             float pj = P[tc], mj = M[tc], vj = V[tc];
             const float p1 = c.p[1][tc], p3 = c.p[3][tc];
             const double eps1 = c.eps_mu[tc], eps2 = c.eps_sd[tc], mu = c.mu_t[tc], y = c.y_t[tc];
@@ -158,7 +161,8 @@ void k_step_wave2(DevArgs c, int flip) {
                         xy[mm][k] = 0.0;
                         if (act && i < n) {
                             const int part = (int)(((float)i + 0.5f) * rR), rr = i - part * R;
-                            const long o = (long)rr * S + (part == 0 ? dsc.x : (dsc.x / ntm + part) * ntm);
+                            const long o = (long)rr * S + (c.tsum_direct ? 2 * (long)tc + part
+                                                                         : (part == 0 ? dsc.x : (dsc.x / ntm + part) * ntm));
                             xm[mm][k] = row_ld<true>(c.tsum + o);
                             xy[mm][k] = row_ld<true>(c.tsum + (long)R * S + o);
                         }
