@@ -63,15 +63,17 @@ def workload(name, guides, rank, acc=False):
                 elbo.init_params, f"variant sorting MixtureNormal{'+Acc' if acc else ''}: {guides} guides x 5 reps x "
                 f"(4 sort bins + bulk), {data.n_targets} targets")
     if name == "tiling":
-        data = syn.make_sorting_tiling_screen(guides, 5, seed=20240503 + rank)
+        data = syn.make_sorting_tiling_screen(guides, 5, seed=20240503 + rank, with_accessibility=acc)
         n_alleles = int(data.allele_mask.sum()) - data.n_guides
-        return ("MultiMixtureNormal", data, elbo.multi_mixture_normal_loss, dict(sparse=True), elbo.init_params,
-                f"tiling sorting MultiMixtureNormal: {guides} guides, {n_alleles} edited alleles, {data.n_edits} edits "
-                f"x 5 reps x (4 sort bins + bulk)")
+        kw = dict(sparse=True, scale_by_accessibility=True) if acc else dict(sparse=True)
+        return ("MultiMixtureNormal", data, elbo.multi_mixture_normal_loss, kw, elbo.init_params,
+                f"tiling sorting MultiMixtureNormal{'+Acc' if acc else ''}: {guides} guides, {n_alleles} edited alleles, "
+                f"{data.n_edits} edits x 5 reps x (4 sort bins + bulk)")
     if name == "survival":
-        data = syn.make_survival_variant_screen(guides, 3, seed=20240506 + rank)
-        return ("MixtureNormal", data, osurv.mixture_normal_loss, {}, osurv.init_params,
-                f"survival MixtureNormal: {guides} guides x {data.n_condits} timepoints x 3 reps")
+        data = syn.make_survival_variant_screen(guides, 3, seed=20240506 + rank, with_accessibility=acc)
+        return ("MixtureNormal", data, osurv.mixture_normal_loss, dict(scale_by_accessibility=True) if acc else {},
+                osurv.init_params,
+                f"survival MixtureNormal{'+Acc' if acc else ''}: {guides} guides x {data.n_condits} timepoints x 3 reps")
     raise SystemExit(f"unknown --config {name}")
 
 
@@ -325,7 +327,7 @@ class Leg:
 
         self.strong, self.world, self.dev, self.guides = strong, world, dev, guides
         self.graph_chunk = args.graph_chunk
-        acc = args.scale_by_acc and config == "metric"
+        acc = bool(args.scale_by_acc)
         # strong: every rank builds the SAME whole screen and keeps its shard
         fam, data_cpu, loss_fn, loss_kw, init_fn, desc = workload(config, guides, 0 if strong else rank, acc=acc)
         self.family, self.loss_fn, self.loss_kw, self.init_fn, self.desc = fam, loss_fn, loss_kw, init_fn, desc

@@ -280,13 +280,73 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
 #pragma unroll 1
     for (int b = 0; b < B; ++b)
         s0 += gs[b * NT] * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
+    // survival: control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)), mu = [u, u + mu_a]
+    // (survival_model.py:535-548) adds to d / d pi_a AND to d / d mu_a.  Its per-control-timepoint normaliser
+    // 1 / W and in-range count n_in are formed FIRST (they need every allele), so that the loop over alleles
+    // below finishes d / d mu_a of an allele and hands the row over at once: no array of kAMax - 1 partial
+    // results is carried across the control term (round 3: 14 - 22 spilled VGPRs in the survival builds).
+    // Up to kCtrlRegs control timepoints are kept in registers (the reference's screens have one); further ones
+    // are re-formed per allele.
+    constexpr int kCtrlRegs = 2;
+    double ctl_rW[kCtrlRegs], ctl_nin[kCtrlRegs];
+    auto ctrl_norm = [&](int cc, double& rW, double& n_in) {
+        const double tc = c.ctrl_time[cc];
+        double W = 0.0;
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a)
+            if (a < A) W += pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+        rW = frcp(W);
+        n_in = 0.0;
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a)
+            if (a < A) {
+                const double wv = pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+                const double pr = wv * rW;
+                const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+                nll -= cnt * flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                if (pr > kProbEps && pr < 1.0 - kProbEps) n_in += cnt;
+            }
+    };
+    if (SURV) {
+#pragma unroll
+        for (int k = 0; k < kCtrlRegs; ++k) {
+            ctl_rW[k] = 0.0;
+            ctl_nin[k] = 0.0;
+            if (k < c.C) ctrl_norm(k, ctl_rW[k], ctl_nin[k]);
+        }
+    }
+    // one allele's share of the control term: added to its d / d pi_a (gp) and d / d mu_a (gm), control
+    // timepoint by control timepoint (the order of the additions of the round-3 form)
+    auto ctrl_allele = [&](int a, double& gp, double& gm) {
+        for (int cc = 0; cc < c.C; ++cc) {
+            double rW, n_in;
+            if (cc < kCtrlRegs) {
+                rW = cc == 0 ? ctl_rW[0] : ctl_rW[1];
+                n_in = cc == 0 ? ctl_nin[0] : ctl_nin[1];
+            } else {
+                // re-formed; the loss terms ctrl_norm adds are counted once, by allele 0 (the first call)
+                const double nll_keep = nll;
+                ctrl_norm(cc, rW, n_in);
+                if (a != 0) nll = nll_keep;
+            }
+            const double tc = c.ctrl_time[cc];
+            const double gr = exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+            const double wv = pi[a] * gr, pr = wv * rW;
+            const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+            const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
+            gp += ((inside ? -cnt * frcp(wv) : 0.0) + n_in * rW) * gr;
+            if (a >= 1) gm += ((inside ? -cnt : 0.0) + n_in * wv * rW) * tc;
+        }
+    };
     double gpi[kAMax], gnoise = 0.0;
-    double gm[SURV ? kAMax - 1 : 1];  // survival: the control-count term below adds to d / d mu_a
     gpi[0] = ACC ? 0.0 : s0;
+    if (SURV) {
+        double unused = 0.0;
+        ctrl_allele(0, gpi[0], unused);
+    }
 #pragma unroll
     for (int a = 1; a < kAMax; ++a) {
         gpi[a] = 0.0;
-        if (SURV) gm[a - 1] = 0.0;
         if (a < A) {
             double sa = 0.0, dm = 0.0, dsg = 0.0;
 #pragma unroll 1
@@ -298,18 +358,19 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
                 if (!SURV) dsg += ge * c.tabPy[o];
             }
             const double pea = ACC ? ps[(0 * kAMax + a) * NT] : pi[a];
-            if (SURV) gm[a - 1] = pea * dm;
-            else row_out(kTGmu + a - 1, pea * dm);
-            row_out(kTGsig + a - 1, pea * dsg);
             if (ACC) {
                 gpi[a] = (sa - s0) * ps[(1 * kAMax + a) * NT];
                 gnoise += (sa - s0) * ps[(2 * kAMax + a) * NT];
             } else {
                 gpi[a] = sa;
             }
+            double gma = pea * dm;
+            if (SURV) ctrl_allele(a, gpi[a], gma);
+            row_out(kTGmu + a - 1, gma);
+            row_out(kTGsig + a - 1, pea * dsg);
         }
     }
-    // ---- Multinomial on control allele counts
+    // ---- Multinomial on control allele counts (sorting; the survival form is the control term above)
     if (!SURV) {
         double s = 0.0;
 #pragma unroll
@@ -330,40 +391,6 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
                 if (inside) gpi[a] -= cnt * frcp(pi[a]);
             }
         }
-    } else {
-        // control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)), mu = [u, u + mu_a]
-        // (survival_model.py:535-548): gradients to pi and, through the growth, to mu_a
-        for (int cc = 0; cc < c.C; ++cc) {
-            const double tc = c.ctrl_time[cc];
-            double W = 0.0;
-#pragma unroll
-            for (int a = 0; a < kAMax; ++a)
-                if (a < A) W += pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
-            const double rW = frcp(W);
-            double n_in = 0.0;
-#pragma unroll
-            for (int a = 0; a < kAMax; ++a)
-                if (a < A) {
-                    const double wv = pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
-                    const double pr = wv * rW;
-                    const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
-                    nll -= cnt * flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
-                    if (pr > kProbEps && pr < 1.0 - kProbEps) n_in += cnt;
-                }
-#pragma unroll
-            for (int a = 0; a < kAMax; ++a)
-                if (a < A) {
-                    const double gr = exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
-                    const double wv = pi[a] * gr, pr = wv * rW;
-                    const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
-                    const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
-                    gpi[a] += ((inside ? -cnt * frcp(wv) : 0.0) + n_in * rW) * gr;
-                    if (a >= 1) gm[a - 1] += ((inside ? -cnt : 0.0) + n_in * wv * rW) * tc;
-                }
-        }
-#pragma unroll
-        for (int a = 1; a < kAMax; ++a)
-            if (a < A) row_out(kTGmu + a - 1, gm[a - 1]);
     }
     // ---- the two Dirichlet log-densities of the pi site; the concentrations are formed again from
     // alpha_pi (same expressions as before the draw, same values).  The barrier keeps the compiler
