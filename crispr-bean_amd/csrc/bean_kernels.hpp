@@ -1444,6 +1444,16 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 }
             }
         }
+        // the standard normals of the NEXT step's draw depend on (seed, target, step) only: formed here, under
+        // the latency of the loads above and of the gradient sums below, not behind the update they will be
+        // scaled by (Philox + Box-Muller are ~250 instructions of this kernel's one-lane-per-target chain)
+        float2 nrm_next = make_float2(0.f, 0.f);
+        if (PREP && active && !c.eps_mu_in) {
+            rocrand_state_philox4x32_10 st;
+            rocrand_init(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + t),
+                         s_prep * 4ull, &st);
+            nrm_next = rocrand_normal2(&st);
+        }
         if (FINISH) {
             if (c.tgrad) {
                 // sharded run of a family whose per-target parameters are shared across shards: the
@@ -1512,10 +1522,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 if (c.eps_mu_in) {
                     eps1 = c.eps_mu_in[t];
                 } else {
-                    rocrand_state_philox4x32_10 st;
-                    rocrand_init(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + t),
-                                 s_prep * 4ull, &st);
-                    eps1 = (double)rocrand_normal2(&st).x;
+                    eps1 = (double)nrm_next.x;
                 }
                 c.eps_mu[t] = eps1;
                 c.mu_t[t] = (double)pl + eps1 * exp((double)psu);
@@ -1542,12 +1549,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                     eps1 = c.eps_mu_in[t];
                     eps2 = c.eps_sd_in[t];
                 } else {
-                    rocrand_state_philox4x32_10 st;
-                    rocrand_init(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + t),
-                                 s_prep * 4ull, &st);
-                    const float2 n = rocrand_normal2(&st);
-                    eps1 = (double)n.x;
-                    eps2 = (double)n.y;
+                    eps1 = (double)nrm_next.x;
+                    eps2 = (double)nrm_next.y;
                 }
                 const double mu = tgt_draw(pf[0], eps1, pf[1]);
                 const double y = tgt_draw(pf[2], eps2, pf[3]);
