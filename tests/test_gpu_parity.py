@@ -176,6 +176,10 @@ def _compare(engine, family, data, kw, seed=7, step=3, tol_loss=(1e-9, 1e-6), to
      dict(scale_by_accessibility=True, fit_noise=False)),
     ("Normal", dict(n_guides=2000, n_reps=3, mask_fraction=0.05), {}),
     ("Normal", dict(n_guides=700, n_reps=2), dict(use_bcmatch=False)),
+    # targets longer than a 64-guide tile (100 guides each, 70 targets: thin mode): a target's partial sums come
+    # from up to three tiles and k_param finds them through the per-target descriptor (DevArgs::tdesc)
+    ("MixtureNormal", dict(n_guides=7000, n_reps=3, guides_per_target=100, mask_fraction=0.05), {}),
+    ("Normal", dict(n_guides=9100, n_reps=2, guides_per_target=130), {}),
 ])
 def test_elbo_and_gradients_match_oracle(engine, family, gen_kw, kw):
     data = make_sorting_variant_screen(seed=31, **gen_kw)
@@ -370,19 +374,28 @@ def test_full_size_fit_is_deterministic_and_improves(engine, full_screen):
     np.testing.assert_allclose(runs[0][1], runs[1][1], rtol=1e-12)  # atomically summed, not bitwise
 
 
-def test_sharded_engines_reproduce_the_whole_screen_fit(engine):
-    """Two target-aligned shards fitted separately with their global offsets
+@pytest.mark.parametrize("gen_kw,acc,n_shards", [
+    (dict(n_guides=1000, n_reps=3, with_accessibility=True), True, 3),
+    # targets of 100 guides: every target spans two or three 64-guide tiles, and the tiles of a shard start
+    # wherever its first target does - the per-target sums are cut on the GLOBAL guide index (bean_guide_v2.hpp)
+    (dict(n_guides=7000, n_reps=3, guides_per_target=100), False, 3),
+    (dict(n_guides=3200, n_reps=2, guides_per_target=7), False, 5),   # 457 targets, shards of ~91 targets
+    (dict(n_guides=900, n_reps=2, guides_per_target=300), False, 3),  # three targets: one block per target
+])
+def test_sharded_engines_reproduce_the_whole_screen_fit(engine, gen_kw, acc, n_shards):
+    """Target-aligned shards fitted separately with their global offsets
     reproduce the single-engine fit bit for bit (what makes the N-GPU run
     independent of N)."""
     from bean_amd import parallel
 
-    data = make_sorting_variant_screen(1000, 3, seed=81, with_accessibility=True)
-    kw = dict(scale_by_accessibility=True, num_steps=300)
+    data = make_sorting_variant_screen(seed=81, **gen_kw)
+    kw = dict(scale_by_accessibility=True, num_steps=300) if acc else dict(num_steps=300)
     whole = engine.HipSVI("MixtureNormal", data.to(DEV), **kw)
     whole.run(60, seed=5)
     ref = whole.constrained()
     ref_losses = np.array(whole.losses())
-    shards = parallel.plan_shards(data.target_lengths.numpy(), 3)
+    shards = parallel.plan_shards(data.target_lengths.numpy(), n_shards)
+    assert any(sh[0] % 64 for sh in shards)  # a shard that does not start on a tile boundary
     parts, losses = [], np.zeros(60)
     for sh in shards:
         e = engine.HipSVI("MixtureNormal", parallel.shard_screen(data, sh).to(DEV), guide_offset=sh[0],
