@@ -66,7 +66,7 @@ def code_object(path):
     return out, True
 
 
-def scan(path, strict=False):
+def scan(path):
     co, tmp = code_object(path)
     dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
     if tmp:
@@ -108,7 +108,8 @@ def scan(path, strict=False):
             if not t.startswith("s_cbranch_execz") or a not in tg or i == 0:
                 continue
             # the idiom: s_and_saveexec_b64 sX, cond (or the else form) ; s_cbranch_execz L  ...  L: s_or_b64 exec, exec, sX
-            # - whatever vector instruction sits between L and that s_or_b64 runs for the lanes of the skipped side only
+            # - whatever vector instruction sits between L and that s_or_b64 runs for the lanes that took the branch
+            #   body only (for none at all when the s_cbranch_execz itself was taken)
             tgt = st + tg[a]
             if tgt not in idx or tgt in seen:
                 continue
@@ -139,7 +140,7 @@ def main(argv):
     paths = [a for a in argv if not a.startswith("--")]
     bad = 0
     for p in paths:
-        fs = scan(p, strict)
+        fs = scan(p)
         n_copy = sum(1 for f in fs if f[2] == "copy")
         print(f"{p}: {len(fs)} join blocks with vector instructions in front of the exec restore ({n_copy} with copies)")
         for name, tgt, kind, pre in fs:
