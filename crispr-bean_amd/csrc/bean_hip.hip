@@ -1966,7 +1966,7 @@ extern "C" int bean_hip_debug_stamps(bean_hip_ctx* c, unsigned long long* host, 
 
 extern "C" int bean_hip_test_special(int32_t op, uint64_t n, const double* a, const double* x,
                                      const double* b, double* out0, double* out1, void* stream_) {
-    if (op < 0 || op > 7) return fail("bean_hip_test_special: unknown op");
+    if (op < 0 || op > 9) return fail("bean_hip_test_special: unknown op");
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_test_special, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
                        (int)op, (long)n, a, x, b, out0, out1);

@@ -3776,6 +3776,15 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
         const GammaPair gp = op == 6 ? sample_gamma_pair(a[i], b[i], rng) : sample_gamma_pair_floor32(a[i], b[i], rng);
         o0[i] = (double)fmaxf((float)gp.g0, 1.17549435e-38f);
         o1[i] = (double)fmaxf((float)gp.g1, 1.17549435e-38f);
+    } else if (op == 8 || op == 9) {
+        // the wide tiling kernel's allele gammas (double floor, DBL_MIN): plain sampler (8) and the one that
+        // skips the rejection loop below the floor (9) - the same values
+        unsigned long long seed;
+        memcpy(&seed, &x[0], 8);
+        Rng rng(seed, kSitePi, (unsigned long long)i, 0ull);
+        const GammaPair gp = op == 8 ? sample_gamma_pair(a[i], b[i], rng) : sample_gamma_pair_floord(a[i], b[i], rng);
+        o0[i] = fmax(gp.g0, kDblMin);
+        o1[i] = fmax(gp.g1, kDblMin);
     }
 }
 

@@ -572,8 +572,13 @@ struct GammaPair {
 // Marsaglia-Tsang factor turns out to be (the factor is at most d v <= 5/3 (1 + 6.66 / sqrt(6))^3 = 86
 // with the 32-bit Box-Muller radius), so it skips the rejection loop: same result, and with
 // concentrations of 1 / n_guides most waves skip it altogether.
-template <bool FLOOR32 = false>
+// FLOOR = 2, the same shortcut for callers that keep max(g, DBL_MIN) (the tiling pi sites: masked alleles are
+// components with concentrations of ~1e-6, whose boost underflows for 99.9 % of the draws): a boosted component
+// with U^(1/alpha) < e^-716 gives a product below DBL_MIN whatever its Marsaglia-Tsang factor (<= 86) is.
+template <int FLOOR = 0>
 __device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1, Rng rng, const uint4* first = nullptr) {
+    constexpr bool FLOOR32 = FLOOR != 0;  // (the code below calls either floor FLOOR32; the thresholds differ)
+    constexpr double kLogFloor = FLOOR == 2 ? -716.5 : -92.5, kScaleFloor = FLOOR == 2 ? 1e-311 : 9.18e-41;
     double scale0 = 1.0, scale1 = 1.0;
     if (a0 < 1.0 || a1 < 1.0) {
         Pair u;
@@ -589,8 +594,8 @@ __device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1,
         // scale does not matter: 0 stands for it)
         bool fl0 = false, fl1 = false;
         if (FLOOR32) {
-            fl0 = (double)__logf((float)u.a) < -92.5 * a0 - 1e-5;
-            fl1 = (double)__logf((float)u.b) < -92.5 * a1 - 1e-5;
+            fl0 = (double)__logf((float)u.a) < kLogFloor * a0 - 1e-5;
+            fl1 = (double)__logf((float)u.b) < kLogFloor * a1 - 1e-5;
         }
         if (a0 < 1.0) {
             if (fl0) scale0 = 0.0;
@@ -605,8 +610,8 @@ __device__ __forceinline__ GammaPair sample_gamma_pair_inl(double a0, double a1,
     }
     bool done0 = false, done1 = false;
     if (FLOOR32) {
-        done0 = scale0 < 9.18e-41;  // FLT_MIN / 128
-        done1 = scale1 < 9.18e-41;
+        done0 = scale0 < kScaleFloor;  // FLT_MIN / 128, or DBL_MIN / 2e3
+        done1 = scale1 < kScaleFloor;
         if (done0 && done1) {
             GammaPair out;
             out.g0 = out.g1 = 0.0;  // floored by the caller
@@ -656,7 +661,10 @@ __device__ BEAN_NOINLINE GammaPair sample_gamma_pair(double a0, double a1, Rng r
     return sample_gamma_pair_inl(a0, a1, rng);
 }
 __device__ BEAN_NOINLINE GammaPair sample_gamma_pair_floor32(double a0, double a1, Rng rng) {
-    return sample_gamma_pair_inl<true>(a0, a1, rng);
+    return sample_gamma_pair_inl<1>(a0, a1, rng);
+}
+__device__ BEAN_NOINLINE GammaPair sample_gamma_pair_floord(double a0, double a1, Rng rng) {
+    return sample_gamma_pair_inl<2>(a0, a1, rng);
 }
 
 // single draw (second component unused)

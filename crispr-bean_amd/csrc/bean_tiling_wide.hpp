@@ -14,9 +14,10 @@
 // guide) are contiguous, trow is (R, G, Q) (trow_sum), and the allele tables are allele-contiguous (tab_off):
 // round 4 - with the guide-contiguous layouts of the narrow kernels every load and store of this kernel
 // touched 64 cache lines (5.8 % VALU-busy, 1.86 ms per launch at 5 000 guides x 232 slots).
-// Same arithmetic as k_guide_tiling_wave; the random stream is keyed per allele (site, (replicate,
-// guide) * 256 + allele), so it differs from the narrow kernels' - they never meet: the engine picks the
-// wide path only when n_max_alleles exceeds what the narrow build holds.
+// Same arithmetic as k_guide_tiling_wave; the random stream is keyed per PAIR of alleles (site, (replicate,
+// guide) * 256 + allele of the lane's even slot: alleles l + 128 k and l + 128 k + 64 are drawn together), so it
+// differs from the narrow kernels' - they never meet: the engine picks the wide path only when n_max_alleles
+// exceeds what the narrow build holds.
 #pragma once
 
 namespace bean {
@@ -79,22 +80,29 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
             csum += cq[j];
         }
         const double total = wave_allsum(csum);
-        // ---- draw
+        // ---- draw: two of the lane's alleles per rejection loop (slots j and j + 1 share one generator, keyed
+        // by the first of the two alleles: one loop and one Philox counter per round instead of two of each)
         double gsum = 0.0;
+        static_assert(kWideSlots % 2 == 0, "alleles are drawn in pairs of slots");
 #pragma unroll
-        for (int j = 0; j < kWideSlots; ++j) {
-            const int a = j * 64 + lane;
+        for (int j = 0; j < kWideSlots; j += 2) {
+            const int a = j * 64 + lane, a2 = a + 64;
             pi[j] = 0.0;
-            if (a < A) {
-                if (c.pi_in) {
-                    pi[j] = c.pi_in[((long)r * G + g) * A + a];
-                } else {
-                    Rng rng(c.seed, kSitePi, ((unsigned long long)r * c.G_tot + (c.g_off + g)) * kWideMaxA + a,
-                            ctr.step * 256ull);
-                    pi[j] = fmax(sample_gamma(cq[j], rng), kDblMin);
-                }
-                gsum += pi[j];
+            pi[j + 1] = 0.0;
+            if (c.pi_in) {
+                if (a < A) pi[j] = c.pi_in[((long)r * G + g) * A + a];
+                if (a2 < A) pi[j + 1] = c.pi_in[((long)r * G + g) * A + a2];
+            } else if (a < A) {
+                Rng rng(c.seed, kSitePi, ((unsigned long long)r * c.G_tot + (c.g_off + g)) * kWideMaxA + a,
+                        ctr.step * 256ull);
+                // (a draw whose boost factor has already put it below DBL_MIN skips the rejection loop: with both
+                // slots of the pair masked - concentrations of ~1e-6 - that is most waves; same values after the floor)
+                const GammaPair gp = sample_gamma_pair_floord(cq[j], a2 < A ? cq[j + 1] : 1.0, rng);
+                pi[j] = fmax(gp.g0, kDblMin);
+                if (a2 < A) pi[j + 1] = fmax(gp.g1, kDblMin);
             }
+            if (a < A) gsum += pi[j];
+            if (a2 < A) gsum += pi[j + 1];
         }
         if (!c.pi_in) {
             const double rs = frcp(wave_allsum(gsum));
@@ -314,10 +322,23 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
             }
         }
         const double proj = wave_allsum(pj);
+        // implicit-reparameterisation gradient: digamma(total) is the same for every allele of the guide - formed
+        // once, not inside each of the four calls (same function, same bits as dirichlet_grad_one evaluates)
+        const double dg_total = digamma(total);
+        // ... and the masked alleles of a guide all have ONE concentration (alpha = eps): where a whole pass of 64
+        // alleles is masked - every pass but the first, for a guide with fewer than 64 alleles - its digamma is the
+        // one evaluation below instead of one per pass
+        const double cq_masked = SURV ? fmax(kEps * rsq, 1e-5) : kEps * rsq;
+        const double dg_masked = digamma(cq_masked);
 #pragma unroll
         for (int j = 0; j < kWideSlots; ++j) {
             const int a = j * 64 + lane;
-            if (a < A) row[(long)(tq_path(A) + a) * RG] = dirichlet_grad_one(pi[j], cq[j], total) * (gpi[j] - proj);
+            const bool real = a < A && c.amask[(long)g * A + a] != 0;
+            double dgj = dg_masked;
+            if (__any(real)) dgj = digamma(cq[j]);  // (a masked lane of a mixed pass evaluates the same value)
+            if (a < A)
+                row[(long)(tq_path(A) + a) * RG] =
+                    dirichlet_grad_one_pre(pi[j], cq[j], total, dgj, dg_total) * (gpi[j] - proj);
         }
         const double gn = wave_allsum(gnoise);
         if (lane == 0) {

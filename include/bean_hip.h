@@ -329,7 +329,9 @@ int bean_hip_get_profile(bean_hip_ctx* ctx, double* avg_ms, uint64_t* launches);
  *   op 4: out0, out1 = Dirichlet(a, b) draw (seed = x[0] bits, element index)
  *   op 5: as op 0 through the two-chain evaluation (element i paired with element i ^ 1)
  *   op 6: out0, out1 = max((float)Gamma(a), FLT_MIN), max((float)Gamma(b), FLT_MIN) from the plain pair sampler
- *   op 7: the same from the float32-floor sampler of the survival q0 site (must equal op 6 draw for draw) */
+ *   op 7: the same from the float32-floor sampler of the survival q0 site (must equal op 6 draw for draw)
+ *   op 8: out0, out1 = max(Gamma(a), DBL_MIN), max(Gamma(b), DBL_MIN) from the plain pair sampler
+ *   op 9: the same from the double-floor sampler of the wide tiling kernel (must equal op 8 draw for draw) */
 int bean_hip_test_special(int32_t op, uint64_t n, const double* a, const double* x,
                           const double* b, double* out0, double* out1, void* stream);
 

@@ -136,6 +136,24 @@ def test_float32_floor_sampler_returns_the_plain_samplers_values(engine, a, b):
         assert frac < 0.05
 
 
+@pytest.mark.parametrize("a,b", [(1e-6, 1e-6), (5e-7, 1.0), (2e-6, 0.4), (1e-4, 1e-6), (0.01, 1e-5), (0.7, 3e-6), (2.0, 1e-6)])
+def test_double_floor_sampler_returns_the_plain_samplers_values(engine, a, b):
+    """The wide tiling kernel keeps max(g, DBL_MIN) of each allele gamma; its sampler leaves the rejection loop
+    out where U^(1/alpha) has already put the draw below DBL_MIN.  Same generator position, same values as the
+    plain sampler, draw for draw, also where only one of the pair - or neither - ends on the floor."""
+    n = 300_000
+    seed = np.zeros(n)
+    seed[:1] = np.frombuffer(np.uint64(977).tobytes(), dtype=np.float64)
+    g0, g1 = engine.test_special(8, np.full(n, a), seed, np.full(n, b))
+    f0, f1 = engine.test_special(9, np.full(n, a), seed, np.full(n, b))
+    assert torch.equal(g0, f0) and torch.equal(g1, f1)
+    frac = float((g0.cpu().numpy() == np.finfo(np.float64).tiny).mean())
+    if a <= 2e-6:
+        assert frac > 0.995  # masked alleles: P(U^(1/a) > DBL_MIN) = 708 a
+    elif a >= 0.01:
+        assert frac < 1e-3
+
+
 # ------------------------------------------------------------------ ELBO parity
 def _compare(engine, family, data, kw, seed=7, step=3, tol_loss=(1e-9, 1e-6), tol_grad=(5e-7, 2e-5),
              perturb=0.3, eng_kw=None):
