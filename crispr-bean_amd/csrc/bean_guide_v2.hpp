@@ -74,9 +74,41 @@ __device__ __forceinline__ void w2_row_store(double* p, double v) {
 //   dps           thread-private column of B doubles, dps[b * LS]
 //   m_*           per-guide values staged by the caller (a0, a0_bcmatch, control allele counts) and two
 //                 thread-private slots for the model-side concentrations
+// The pi site's draw of one (replicate, guide) (model.py:439-450 / guide 812-826): needs the guide's alpha_pi and
+// pi_a0 only - none of the counts or tables - so k_guide_wave2 runs it while those loads are still in flight.
+// Leaves the model-side concentrations in the thread-private slots m_cp0 / m_cp1 for guide_pair_math.
+template <int FAM>
+__device__ __forceinline__ void guide_pair_draw(const DevArgs& c, const StepCtr& ctr, int r, int g, float api0,
+                                                float api1, double pa0, const uint4* philox_first, double* m_cp0,
+                                                double* m_cp1, double& pi0, double& pi1) {
+    if (FAM != kMixture) return;
+    const double al0 = (double)expf(api0), al1 = (double)expf(api1);
+    const double rs = frcp(al0 + al1) * pa0;
+    const double cp0 = al0 * rs, cp1 = al1 * rs;
+    *m_cp0 = cp0;  // needed again after the likelihoods
+    *m_cp1 = cp1;
+    const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
+#if BEAN_GW_DIAG == 1
+    pi0 = 0.3 + 1e-3 * cq0;
+    pi1 = 0.7 - 1e-3 * cq1;
+#else
+    // (draws handed in - DevArgs::pi_in, tests - are read by guide_pair_math: a load on either side of this
+    // branch would make the compiler drain the loads in flight before the sampler may reuse its register)
+    if (!c.pi_in) {
+        Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+        const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng, philox_first);
+        const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
+        const double rs2 = frcp(gm0 + gm1);
+        pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
+        pi1 = fmin(fmax(gm1 * rs2, kDblMin), kOneMinus);
+    }
+#endif
+}
+
+// (pi0, pi1: the pair's draw, guide_pair_draw)
 template <int FAM, bool ACC, bool STEP, int LS>
 __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCtr& ctr, int r, int g, bool rgm,
-                                                  float api0, float api1, double pa0, const uint4* philox_first,
+                                                  double pi0, double pi1,
                                                   const double* tp, int ntm, const double* c_sf, const double* c_sm,
                                                   const double* c_p0, float* xl, double* dps, const double* m_a0,
                                                   const double* m_a0bc, const double* m_cnt0, const double* m_cnt1,
@@ -86,33 +118,19 @@ __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCt
     const bool use_bc = (c.flags & kUseBc) != 0;
     const long rgi = (long)r * G + g;
     const long RG = (long)R * G;
-    double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0;
+    double pe1 = 1.0;
     double dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
+    if (!MIX) {
+        pi0 = 0.0;
+        pi1 = 1.0;
+    }
     if (MIX) {
-        const double al0 = (double)expf(api0), al1 = (double)expf(api1);
-        const double rs = frcp(al0 + al1) * pa0;
-        const double cp0 = al0 * rs, cp1 = al1 * rs;
-        *m_cp0 = cp0;  // needed again after the likelihoods
-        *m_cp1 = cp1;
-        const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
-#if BEAN_GW_DIAG == 1
-        if (true) {
-            pi0 = 0.3 + 1e-3 * cq0;
-            pi1 = 0.7 - 1e-3 * cq1;
-        } else {
-#else
+#if BEAN_GW_DIAG != 1
         if (c.pi_in) {
             pi0 = c.pi_in[rgi * 2];
             pi1 = c.pi_in[rgi * 2 + 1];
-        } else {
-#endif
-            Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
-            const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng, philox_first);
-            const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
-            const double rs2 = frcp(gm0 + gm1);
-            pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
-            pi1 = fmin(fmax(gm1 * rs2, kDblMin), kOneMinus);
         }
+#endif
         if (c.flags & kDumpPi) {
             c.pi_out[rgi * 2] = pi0;
             c.pi_out[rgi * 2 + 1] = pi1;
@@ -420,11 +438,17 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     uint4 philox_first = make_uint4(0u, 0u, 0u, 0u);
     bool rgm = false;
     float api0 = 0.f, api1 = 0.f;
-    double pa0 = 0.0;
+    double pa0 = 0.0, pi0 = 0.0, pi1 = 1.0;
     {
         // everything the wave reads from global memory, issued as one batch before the first wait
         const int gc = valid ? g : (g < 0 ? 0 : G - 1);
         const long rgc = (long)r * G + gc;
+        // (first in the batch: loads return in issue order, and the draw below waits for these three only)
+        if (MIX) {
+            api0 = c.p[4][2 * gc];
+            api1 = c.p[4][2 * gc + 1];
+            pa0 = c.pi_a0[gc];
+        }
         float xv[2][kBMax];
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
@@ -442,13 +466,22 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
         const long covoff = c.n_cov ? (long)r * B * T : 0;  // sample covariates: tables per replicate
         double tv[kTabLoads];
         int wbv[kTabLoads];
+        // (the three table pointers as register values: left to itself the compiler turns the selection below into
+        // a per-lane LOAD of the pointer from the kernel-argument segment, i.e. one more round trip before the
+        // table loads can be issued)
+        // (and as GLOBAL pointers: through the asm the compiler no longer knows the address space, and a flat load
+        // in flight makes every later wait a full one)
+        typedef const double __attribute__((address_space(1))) * GlobalTab;
+        const double *tabP_ = c.tabP, *tabPmu_ = c.tabPmu, *tabPy_ = c.tabPy;
+        asm volatile("" : "+s"(tabP_), "+s"(tabPmu_), "+s"(tabPy_));
+        const GlobalTab tabP = (GlobalTab)tabP_, tabPmu = (GlobalTab)tabPmu_, tabPy = (GlobalTab)tabPy_;
 #pragma unroll
         for (int q = 0; q < kTabLoads; ++q) {
             const int wb = q * per + sub;
             const bool ok = wb < n_rows && j < nt;
             const int wbc = ok ? wb : 0;
             const int which = (wbc >= B) + (wbc >= 2 * B), bb = wbc - which * B;
-            const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
+            const GlobalTab tab = which == 0 ? tabP : (which == 1 ? tabPmu : tabPy);
             tv[q] = tab[covoff + (long)bb * T + t0 + (ok ? j : 0)];
             wbv[q] = ok ? wb : -1;
         }
@@ -462,11 +495,6 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
         }
         tcol = c.g2t[gc] - t0;
         rgm = c.rg[rgc] != 0;
-        if (MIX) {
-            api0 = c.p[4][2 * gc];
-            api1 = c.p[4][2 * gc + 1];
-            pa0 = c.pi_a0[gc];
-        }
         const double a00 = c.a0[gc], a01 = use_bc ? c.a0_bc[gc] : 0.0;
         // the draw's first Philox block needs the step and the guide index only: computed here, while
         // the loads above are in flight (after a kernel boundary they take ~3.5 us and every wave of the
@@ -474,9 +502,24 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
         if (MIX && !c.pi_in) philox_first = philox_block(c.seed, ((unsigned long long)kSitePi << 48) +
                                                                    ((unsigned long long)r * c.G_tot + (c.g_off + gc)),
                                                          ctr.step * 256ull);
-        double cnt0 = 0.0, cnt1 = 0.0;
+        // control allele counts of the first control condition (a branch-free load: with no control condition
+        // two words of pi_a0 are read in their place and dropped below)
+        float alc0 = 0.f, alc1 = 0.f;
+        if (MIX) {
+            const float* al = c.C > 0 ? c.allele + ((long)r * c.C * G + gc) * 2 : (const float*)(c.pi_a0 + gc);
+            alc0 = al[0];
+            alc1 = al[1];
+        }
+        // ---- the draw, under the loads: it is a fifth of a wave's arithmetic and needs none of the counts or
+        // tables; after a kernel boundary all waves of the chip issue their loads within 1.6 us and wait ~3.5 us
+        // for them - with nothing to issue from, since every wave of a SIMD is at the same point
+        asm volatile("" ::: "memory");  // (the loads above are issued here, not sunk below the draw to their uses)
+        if (valid) guide_pair_draw<FAM>(c, ctr, r, g, api0, api1, pa0, &philox_first, ms + 4 * 64, ms + 5 * 64, pi0, pi1);
+        // (opaque to the compiler, or it converts the two counts where they are loaded - a full wait before the draw)
+        asm volatile("" : "+v"(alc0), "+v"(alc1));
+        double cnt0 = c.C > 0 ? (double)alc0 : 0.0, cnt1 = c.C > 0 ? (double)alc1 : 0.0;
         if (MIX)
-            for (int cc = 0; cc < c.C; ++cc) {
+            for (int cc = 1; cc < c.C; ++cc) {
                 const float* al = c.allele + (((long)r * c.C + cc) * G + gc) * 2;
                 cnt0 += (double)al[0];
                 cnt1 += (double)al[1];
@@ -523,7 +566,7 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
 
     double a_mu = 0.0, a_y = 0.0;
     if (valid)
-        loss = guide_pair_math<FAM, ACC, STEP, 64>(c, ctr, r, g, rgm, api0, api1, pa0, &philox_first, tabs + tcol, ntm, cst,
+        loss = guide_pair_math<FAM, ACC, STEP, 64>(c, ctr, r, g, rgm, pi0, pi1, tabs + tcol, ntm, cst,
                                                    cst + 2 * B, cst + 3 * B, xs + lane, dps, ms, ms + 64, ms + 2 * 64,
                                                    ms + 3 * 64, ms + 4 * 64, ms + 5 * 64, a_mu, a_y);
     target_part_sums<STEP>(c, lane, tile, r, valid ? tcol : -1, valid, a_mu, a_y, t0, tof_first < g_first);

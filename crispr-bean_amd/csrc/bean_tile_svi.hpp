@@ -333,7 +333,9 @@ __device__ __noinline__ void tile_guide_step(const DevArgs* cp, int g0, int t0, 
         // (this kernel keeps d/dmu_t, d/dy_t as per-guide rows: its finish phase adds them in the order k_param
         // used until round 4; k_guide_wave2 now sums per target inside its waves)
         double a_mu = 0.0, a_y = 0.0;
-        loss = guide_pair_math<FAM, ACC, true, NT>(c, ctr, r, g, rgm, api0, api1, pa0, nullptr, tabs + tcol, ntm,
+        double pi0 = 0.0, pi1 = 1.0;
+        guide_pair_draw<FAM>(c, ctr, r, g, api0, api1, pa0, nullptr, mper + 2 * gbm + j, mper + 3 * gbm + j, pi0, pi1);
+        loss = guide_pair_math<FAM, ACC, true, NT>(c, ctr, r, g, rgm, pi0, pi1, tabs + tcol, ntm,
                                                    c_sf, c_sf + 2 * B, c_sf + 3 * B, xs + tid, dcol + tid, mper + j,
                                                    mper + gbm + j, mcnt + tid, mcnt + NT + tid, mper + 2 * gbm + j,
                                                    mper + 3 * gbm + j, a_mu, a_y);

@@ -23,8 +23,8 @@ no kernel is safe by inspection of its source.  Every build is therefore scanned
 
     python scripts/check_exec_join.py crispr-bean_amd/lib/libbean_hip.so [...]
 
-For every ``s_cbranch_execz L`` the instructions from ``L`` up to the first write of ``exec`` are
-looked at; if that write is ``s_or_b64 exec, exec, sX`` (a join) and a vector instruction (lane-crossing
+For every ``s_and_saveexec_b64 sX, ... ; s_cbranch_execz L`` the instructions from ``L`` up to the first write
+of ``exec`` are looked at; if that write is ``s_or_b64 exec, exec, sX`` (the join of that ``if``) and a vector instruction (lane-crossing
 ``v_readlane`` / ``v_writelane`` excepted: they ignore exec) stands in front of it, that is a finding.
 ``_lib.build_library`` fails the build on any finding; ``tests/test_isa_check.py`` keeps the committed
 build honest and pins the detector on a minimal code object with the pattern.
@@ -113,12 +113,28 @@ def scan(path):
             tgt = st + tg[a]
             if tgt not in idx or tgt in seen:
                 continue
+            # the mask this branch's `if` saved: the s_and_saveexec_b64 (else form: s_xor_b64 exec, exec, sX) right
+            # in front of it.  A branch without one is not the head of an `if`: the compiler also emits
+            # `s_cbranch_execz 1 ; s_branch n` hops INSIDE a divergent region, whose target is ordinary region code
+            # in front of the region's own restore.
+            saved = None
+            for k in range(i - 1, max(i - 4, -1), -1):
+                m = re.match(r"(?:s_and_saveexec_b64|s_andn2_saveexec_b64)\s+(s\[\d+:\d+\]|vcc)\s*,", ins[od[k]]) or \
+                    re.match(r"s_xor_b64\s+exec,\s*exec,\s*(s\[\d+:\d+\]|vcc)\s*$", ins[od[k]])
+                if m:
+                    saved = m.group(1)
+                    break
+                if not ins[od[k]].startswith("s_") or EXEC_RESTORE.match(ins[od[k]]):
+                    break
+            if saved is None:
+                continue
             seen.add(tgt)
             pre, restored = [], False
             for j in range(idx[tgt], min(idx[tgt] + 64, len(od))):
                 tx = ins[od[j]]
-                if re.match(r"s_or_b64\s+exec,\s*exec,\s*(s\[\d+:\d+\]|vcc)\s*$", tx):
-                    restored = True
+                m = re.match(r"s_or_b64\s+exec,\s*exec,\s*(s\[\d+:\d+\]|vcc)\s*$", tx)
+                if m:
+                    restored = m.group(1) == saved
                     break
                 if EXEC_RESTORE.match(tx) or tx.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
                     break
