@@ -79,9 +79,18 @@ void k_guide_survival_wave(DevArgs c) {
     float api0 = 0.f, api1 = 0.f;
     double pa0 = 0.0, mu_t = 0.0, u = 0.0, gam = 0.0, a00 = 0.0, a01 = 0.0;
     double n_x = 0.0, n_bc = 0.0;
+    double pi0 = 0.0, pi1 = 1.0;
     {
         const int gc = valid ? g : G - 1;
         const long rgc = (long)r * G + gc;
+        // (first in the batch: loads return in issue order; the target index has a load depending on it, issued last
+        // - and the draw below waits for the next three only)
+        const int tix = c.g2t[gc];
+        if (MIX) {
+            api0 = c.p[4][2 * gc];
+            api1 = c.p[4][2 * gc + 1];
+            pa0 = c.pi_a0[gc];
+        }
         // totals of the guide's counts over the timepoints (the loads in flight together; the likelihood
         // loop reads the counts again, one coalesced row per timepoint)
         float xv[2][kBMax];
@@ -101,7 +110,6 @@ void k_guide_survival_wave(DevArgs c) {
         rgm = c.rg[rgc] != 0;
         // survival NormalModel: mu of negative-control guides is forced to 0 (survival_model.py:59-60)
         negc = q0lik && c.negctrl && c.negctrl[gc] != 0;
-        mu_t = c.mu_t[c.g2t[gc]];
         a00 = c.a0[gc];
         a01 = use_bc ? c.a0_bc[gc] : 0.0;
         // the pi draw's first Philox block, under the latency of the loads above (as in k_guide_wave2)
@@ -111,9 +119,6 @@ void k_guide_survival_wave(DevArgs c) {
         double lobs = 0.0;
         float p7 = 0.f;
         if (MIX) {
-            api0 = c.p[4][2 * gc];
-            api1 = c.p[4][2 * gc + 1];
-            pa0 = c.pi_a0[gc];
             u = c.u_g[gc];
             lobs = c.log_obs0[rgc];
         }
@@ -121,6 +126,27 @@ void k_guide_survival_wave(DevArgs c) {
             p7 = c.p[7][gc];
             gam = c.gam[rgc];
         }
+        // ---- the pi draw, under the loads (as in k_guide_wave2: it needs alpha_pi and pi_a0 only; draws handed in
+        // - DevArgs::pi_in, tests - are read further down, a load on either side of this branch would drain the
+        // loads in flight first)
+        mu_t = c.mu_t[tix];
+        asm volatile("" ::: "memory");
+        if (MIX && valid && !c.pi_in) {
+            const double al0 = (double)expf(api0), al1 = (double)expf(api1);
+            const double rs = frcp(al0 + al1) * pa0;
+            const double cp0 = al0 * rs, cp1 = al1 * rs;
+            const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
+            Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+            const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng, &philox_first);
+            const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
+            const double rs2 = frcp(gm0 + gm1);
+            pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
+            pi1 = fmin(fmax(gm1 * rs2, kDblMin), kOneMinus);
+        }
+        // (the counts as sixteen values in flight: left alone the compiler adds each one up where it is loaded,
+        // one full wait per timepoint)
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) asm volatile("" : "+v"(xv[0][b]), "+v"(xv[1][b]));
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
             if (b < B) {
@@ -178,22 +204,11 @@ void k_guide_survival_wave(DevArgs c) {
         // (a compiler-level fence after a park: without it the stored value is forwarded to its later load, i.e.
         // stays in its register, and nothing is gained)
         asm volatile("" ::: "memory");
-        double pi0 = 0.0, pi1 = 1.0, pe1 = 1.0, dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
+        double pe1 = 1.0, dpe1_dpi1 = 0.0, dpe1_dl = 0.0;
         if (MIX) {
-            const double al0 = (double)expf(api0), al1 = (double)expf(api1);
-            const double rs = frcp(al0 + al1) * pa0;
-            const double cp0 = al0 * rs, cp1 = al1 * rs;
-            const double cq0 = cp0 < 1e-5 ? 1e-5 : cp0, cq1 = cp1 < 1e-5 ? 1e-5 : cp1;
             if (c.pi_in) {
                 pi0 = c.pi_in[rgi * 2];
                 pi1 = c.pi_in[rgi * 2 + 1];
-            } else {
-                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
-                const GammaPair gp = sample_gamma_pair_inl(cq0, cq1, rng, &philox_first);
-                const double gm0 = fmax(gp.g0, kDblMin), gm1 = fmax(gp.g1, kDblMin);
-                const double rs2 = frcp(gm0 + gm1);
-                pi0 = fmin(fmax(gm0 * rs2, kDblMin), kOneMinus);
-                pi1 = fmin(fmax(gm1 * rs2, kDblMin), kOneMinus);
             }
             if (c.flags & kDumpPi) {
                 c.pi_out[rgi * 2] = pi0;
