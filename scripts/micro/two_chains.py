@@ -1,35 +1,66 @@
-"""Experiment: does one GPU finish a 50k-guide fit sooner as K independent target-aligned shards whose
-launch chains (k_param -> guide kernel -> k_param ...) run concurrently on K streams?  (k_param is
-latency-bound and the guide kernel has a ramp and a tail: another shard's kernels can fill both.)"""
-import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import torch
-import bean_amd
-from bean_amd import engine, parallel
-from bean_amd.preprocessing import synthetic as syn
+"""Does one GPU step faster when the screen is fitted as K independent target-aligned parts on K streams?
+(variant sorting families share no parameter across targets: the parts are what `torchrun` ranks would hold, here
+all on one device - one part's latency-bound k_param under another part's guide kernel.)  Diagnostic.
 
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
-KS = [int(k) for k in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 3, 4]
-steps = 1024
-d = syn.make_sorting_variant_screen(G, 5, seed=syn.BASE_SEED + 1)
-res = {}
-for K in KS:
-    shards = parallel.plan_shards(d.target_lengths.numpy(), K)
-    engs, streams = [], []
-    for sh in shards:
-        sc = parallel.shard_screen(d, sh).to("cuda:0")
-        engs.append(engine.HipSVI("MixtureNormal", sc, num_steps=2 * steps + 200, guide_offset=sh[0],
-                                  target_offset=sh[2], n_guides_total=d.n_guides))
-        streams.append(torch.cuda.Stream())
-    def go(n):
-        for e, s in zip(engs, streams):
-            with torch.cuda.stream(s):
-                e.run(n)
-    go(128); torch.cuda.synchronize()
-    t = time.perf_counter(); go(steps); torch.cuda.synchronize(); dt = time.perf_counter() - t
-    loss = sum(e.losses()[-1] for e in engs)
-    res[K] = {"us_per_step": dt / steps * 1e6, "loss_last": loss}
-    print(K, res[K], flush=True)
-    for e in engs: e.close()
-os.makedirs("gpurun_out", exist_ok=True)
+    python scripts/micro/two_chains.py [guides] [steps]
+"""
+import ctypes
+import json
+import os
+import sys
+import time
 
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import bean_amd  # noqa: F401,E402
+from bean_amd import engine, parallel  # noqa: E402
+from bean_amd.preprocessing import synthetic as syn  # noqa: E402
+
+
+def main():
+    G = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    data = syn.make_sorting_variant_screen(G, 5, seed=20240502)
+    out = {}
+    ref_loss = None
+    ks = [int(k) for k in os.environ.get("CHAINS", "1,2,3,4,8").split(",")]
+    for K in ks:
+        shards = parallel.plan_shards(data.target_lengths.numpy(), K)
+        engs = []
+        for sh in shards:
+            part = parallel.shard_screen(data, sh).to("cuda:0")
+            engs.append(engine.HipSVI("MixtureNormal", part, num_steps=steps + 200, guide_offset=sh[0],
+                                      target_offset=sh[2], n_guides_total=G))
+
+        def enqueue(n):
+            # straight to the library: HipSVI.run orders its stream against the current one on both sides,
+            # which would put the parts one after another
+            for e in engs:
+                e._check(e.lib.bean_hip_svi_resume(e._h, 101, e.steps_done, n, 50, e._sptr()), "svi_resume")
+                e.steps_done += n
+
+        for e in engs:
+            e.stream.wait_stream(torch.cuda.current_stream())
+        enqueue(100)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        enqueue(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        loss = sum(float(e.loss_hist[e.steps_done - 1]) for e in engs)
+        if ref_loss is None:
+            ref_loss = loss
+        out[f"{K}_{len(out)}"] = {"us_per_step": round(dt / steps * 1e6, 2), "loss_last": loss, "loss_rel": abs(loss - ref_loss) / abs(ref_loss),
+                  "guides": [s[1] - s[0] for s in shards]}
+        print(K, json.dumps(list(out.values())[-1]), flush=True)
+        for e in engs:
+            e.close()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "two_chains.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
