@@ -355,6 +355,11 @@ class Leg:
             self.offsets = dict(guide_offset=rank * guides, target_offset=rank * n_t, n_guides_total=world * guides)
             if tiling or survival:
                 self.offsets = {}  # independent screens: these families couple guides through shared quantities
+        if tiling:
+            # as run_inference hands a tiling screen to its engine: guides ordered by their number of alleles
+            self.shard_cpu, ids = parallel.order_by_alleles(self.shard_cpu, self.offsets.get("guide_offset", 0))
+            if ids is not None:
+                self.offsets["guide_ids"] = ids
         self.data = self.shard_cpu.to(dev)
         self.eng = engine.HipSVI(fam, self.data, num_steps=max(total_steps, 1), loss_capacity=total_steps + 64,
                                  device=dev, **self.eng_kw, **self.offsets)

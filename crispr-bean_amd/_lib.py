@@ -73,7 +73,7 @@ BUF = {
     "P": 32, "G": 48, "M": 64, "V": 80,
     "EPS_MU_IN": 96, "EPS_SD_IN": 97, "PI_IN": 98, "EPS_NOISE_IN": 99,
     "EPS_MU_OUT": 100, "EPS_SD_OUT": 101, "PI_OUT": 102, "EPS_NOISE_OUT": 103,
-    "X0_IN": 104, "EPS_U_IN": 105, "X0_OUT": 106, "EPS_U_OUT": 107, "PRIOR_IA": 108, "XCHG_COV": 109,
+    "X0_IN": 104, "EPS_U_IN": 105, "X0_OUT": 106, "EPS_U_OUT": 107, "PRIOR_IA": 108, "XCHG_COV": 109, "GUIDE_IDS": 110,
     "LOSS_HIST": 112,
 }
 PARAM_ORDER = ("mu_loc", "mu_scale", "sd_loc", "sd_scale", "alpha_pi", "noise_loc", "noise_scale", "q0")

@@ -143,6 +143,7 @@ static uint64_t expected_bytes(const bean_hip_shape& s, int slot) {
         case BEAN_BUF_XCHG_TGRAD: return 8 * 2 * T;
         case BEAN_BUF_XCHG_COV: return s.n_sample_covariates > 0 ? 8 * R : 0;
         case BEAN_BUF_EPS_U_IN: case BEAN_BUF_EPS_U_OUT: return (is_survival(s) && is_mixture(s)) ? 8 * G : 0;
+        case BEAN_BUF_GUIDE_IDS: return is_tiling(s) ? 4 * G : 0;
         case BEAN_BUF_PRIOR_IA: return (is_surv_normal(s) && s.prior_ia_total > 0.0) ? 8 * G : 0;
         case BEAN_BUF_TARGET_OFFSETS: return is_tiling(s) ? 0 : 4 * (T + 1);
         case BEAN_BUF_GUIDE_TO_TARGET: return is_tiling(s) ? 0 : 4 * G;
@@ -212,6 +213,7 @@ static void sync_devargs(bean_hip_ctx* c) {
     d.negctrl = (const uint8_t*)P(BEAN_BUF_NEGCTRL_MASK);
     d.rbc = (const double*)P(BEAN_BUF_REP_BY_COV);
     d.prior_ia = (const double*)P(BEAN_BUF_PRIOR_IA);
+    d.gid = (const int*)P(BEAN_BUF_GUIDE_IDS);
     d.prior_ia_total = c->shape.prior_ia_total;
     if (P(BEAN_BUF_XCHG_GSUM)) d.gsum = (double*)P(BEAN_BUF_XCHG_GSUM);
     else d.gsum = c->gsum_ws;

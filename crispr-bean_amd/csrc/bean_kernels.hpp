@@ -145,6 +145,7 @@ struct DevArgs {
     // survival NormalModel: prior_params["initial_abundance"] (survival_model.py:38-49): per-guide prior
     // concentration of the Dirichlet-over-guides site and its sum over the WHOLE screen; null: ones / G
     const double* prior_ia;
+    const int* gid;  // tiling, optional: the guide's index in the caller's whole screen (keys its random streams)
     double prior_ia_total;
     int trow_summed;                   // k_sum_trow has reduced trow into part
     int wide_alleles;                  // tiling with more alleles per guide than kAMax: bean_tiling_wide.hpp
@@ -273,6 +274,12 @@ __device__ __forceinline__ long slot_off(const DevArgs& c, int a1, long g) {
 __device__ __forceinline__ int uniform_ld_i(const int* p, int i) {
     typedef const int __attribute__((address_space(4))) * cptr;
     return ((cptr)(unsigned long long)p)[i];
+}
+
+// The index that keys a guide's random streams: its position in the whole screen - guide_offset + g, or, where the
+// caller handed the guides over in another order (tiling: by allele count), what it says it is.
+__device__ __forceinline__ unsigned long long guide_stream_id(const DevArgs& c, int g) {
+    return (unsigned long long)(c.gid ? c.gid[g] : c.g_off + g);
 }
 
 // ---------------------------------------------------------------- loss accumulation
@@ -683,7 +690,7 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int guide_b
             eps = c.eps_noise_in[g];
         } else {
             rocrand_state_philox4x32_10 st;
-            rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)(c.g_off + g),
+            rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + guide_stream_id(c, g),
                          s_prep * 4ull, &st);
             eps = (double)rocrand_normal(&st);
         }
@@ -2891,7 +2898,7 @@ void k_guide_tiling(DevArgs c) {
 #pragma unroll
                 for (int a = 0; a < kAMax; ++a) pi[a] = a < A ? c.pi_in[((long)r * G + g) * A + a] : 0.0;
             } else {
-                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + guide_stream_id(c, g), ctr.step * 256ull);
                 double sum = 0.0;
 #pragma unroll
                 for (int a = 0; a < kAMax; a += 2) {
@@ -3224,7 +3231,7 @@ void k_guide_tiling_wave(DevArgs c) {
 #pragma unroll
                 for (int a = 0; a < kAMax; ++a) pi[a] = a < A ? c.pi_in[((long)r * G + g) * A + a] : 0.0;
             } else {
-                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+                Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + guide_stream_id(c, g), ctr.step * 256ull);
                 double sum = 0.0;
 #pragma unroll
                 for (int a = 0; a < kAMax; a += 2) {

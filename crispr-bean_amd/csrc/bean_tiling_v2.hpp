@@ -148,7 +148,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
 #pragma unroll
             for (int a = 0; a < kAMax; ++a) pi[a] = a < A ? c.pi_in[((long)r * G + g) * A + a] : 0.0;
         } else {
-            Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + (c.g_off + g), ctr.step * 256ull);
+            Rng rng(c.seed, kSitePi, (unsigned long long)r * c.G_tot + guide_stream_id(c, g), ctr.step * 256ull);
             double sum = 0.0;
 #pragma unroll
             for (int a = 0; a < kAMax; a += 2) {

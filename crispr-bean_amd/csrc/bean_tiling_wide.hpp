@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
                 if (a < A) pi[j] = c.pi_in[((long)r * G + g) * A + a];
                 if (a2 < A) pi[j + 1] = c.pi_in[((long)r * G + g) * A + a2];
             } else if (a < A) {
-                Rng rng(c.seed, kSitePi, ((unsigned long long)r * c.G_tot + (c.g_off + g)) * kWideMaxA + a,
+                Rng rng(c.seed, kSitePi, ((unsigned long long)r * c.G_tot + guide_stream_id(c, g)) * kWideMaxA + a,
                         ctr.step * 256ull);
                 // (a draw whose boost factor has already put it below DBL_MIN skips the rejection loop: with both
                 // slots of the pair masked - concentrations of ~1e-6 - that is most waves; same values after the floor)
@@ -467,7 +467,7 @@ __device__ __forceinline__ void param_guide_tiling_wide(const DevArgs& c, int gu
             eps = c.eps_noise_in[g];
         } else {
             rocrand_state_philox4x32_10 st;
-            rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)(c.g_off + g),
+            rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + guide_stream_id(c, g),
                          s_prep * 4ull, &st);
             eps = (double)rocrand_normal(&st);
         }

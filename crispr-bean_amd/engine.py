@@ -20,6 +20,7 @@ import torch
 from . import _lib
 
 PI_NOISE_SD = 0.655  # bean/model/utils.py:133
+PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale", "q0", "initial_abundance")  # parameters with a guide axis
 POSITIVE = ("mu_scale", "sd_scale", "alpha_pi", "noise_scale", "q0", "initial_abundance", "mu_cov_scale")
 
 
@@ -63,6 +64,7 @@ class HipSVI:
         loss_owner: bool = True,
         alpha_prior: float = 1.0,
         lib_variant: Optional[str] = None,
+        guide_ids: Optional[torch.Tensor] = None,
     ):
         if family not in _lib.FAMILY:
             raise ValueError(f"unknown model family {family!r}")
@@ -238,6 +240,19 @@ class HipSVI:
             z_hi, z_lo = _quantile_edges(data.upper_bounds, data.lower_bounds)
             self._bind("Z_HI", f64(z_hi))
             self._bind("Z_LO", f64(z_lo))
+        # tiling: `data` may hold the guides in another order than the caller's screen (parallel.order_by_alleles);
+        # guide_ids[i] is then the index of this engine's guide i in the WHOLE screen.  It keys the guide's random
+        # streams (same draws as the screen order), and constrained() hands per-guide values back in screen order.
+        self.guide_order = None
+        if guide_ids is not None:
+            if not tiling:
+                raise ValueError("guide_ids: only the tiling family takes its guides in another order")
+            gi = torch.as_tensor(guide_ids).to(torch.int64).cpu().reshape(-1)
+            local = gi - int(guide_offset)
+            if gi.numel() != G or not torch.equal(torch.sort(local).values, torch.arange(G)):
+                raise ValueError("guide_ids must be a permutation of guide_offset ... guide_offset + n_guides - 1")
+            self.guide_order = local.to(dev)
+            self._bind("GUIDE_IDS", gi.to(torch.int32).to(dev).contiguous())
         if tiling:
             self._bind("A2E_PTR", a2e_ptr.to(dev).contiguous())
             self._bind("E2A_PTR", e2a_ptr.to(dev).contiguous())
@@ -658,6 +673,13 @@ class HipSVI:
             g_all = int(self._shape.n_guides_total) or self.data.n_guides
             out["initial_abundance"] = torch.full((self.data.n_guides,), 1.0 / g_all, dtype=torch.float32,
                                                   device=self.device)
+        if self.guide_order is not None:
+            # engine guide i is the screen's guide guide_order[i]: per-guide values go back in screen order
+            for k in PER_GUIDE:
+                if k in out:
+                    back = torch.empty_like(out[k])
+                    back[self.guide_order] = out[k]
+                    out[k] = back
         return out
 
 

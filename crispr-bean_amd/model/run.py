@@ -121,6 +121,12 @@ def run_inference(model, guide, data, initial_lr=0.01, gamma=0.1, num_steps=2000
     engines = []
 
     def factory(shard_data, shard, n_total, **extra):
+        if spec.family == "MultiMixtureNormal":
+            # tiling: this engine's guides ordered by their number of alleles (parallel.order_by_alleles); draws
+            # and returned parameters are those of the screen order
+            shard_data, ids = parallel.order_by_alleles(shard_data, shard[0])
+            if ids is not None:
+                extra = dict(extra, guide_ids=ids)
         eng = build_engine(
             model, guide, shard_data.to(device), initial_lr=initial_lr, gamma=gamma, num_steps=num_steps,
             device=device, guide_offset=shard[0], target_offset=shard[2], n_guides_total=n_total, **extra,

@@ -77,6 +77,30 @@ def plan_guide_shards(n_guides: int, world_size: int, n_targets: int = 0) -> Lis
     return [(cuts[k], cuts[k + 1], 0, n_targets) for k in range(world_size)]
 
 
+def order_by_alleles(data, guide_offset: int = 0):
+    """Tiling screens: the guides ordered by their number of alleles, most first (stable), and the index of each
+    in the caller's whole screen - ``(ordered_data, guide_ids)``, or ``(data, None)`` when there is nothing to
+    reorder.
+
+    The register-resident tiling kernels give every (replicate, guide) a lane and walk the allele SLOTS; a masked
+    slot takes other branches of the implicit-gradient and count code than a slot that holds an allele, so a
+    wave whose guides have 2 ... 8 alleles in screen order runs both sides of each.  With its guides' alleles
+    in the same slots it runs one: 179 -> 159 us per step on BASELINE configs[2]'s shape
+    (``scripts/micro/tiling_sorted.py``).  ``HipSVI(..., guide_ids=)`` keys the random streams by the screen
+    index, so the draws are those of the screen order, and returns per-guide values in screen order.
+    ``BEAN_HIP_ORDER_GUIDES=0`` keeps the screen order."""
+    import os
+
+    mask = getattr(data, "allele_mask", None)
+    if mask is None or os.environ.get("BEAN_HIP_ORDER_GUIDES", "1") == "0":
+        return data, None
+    n_al = mask.sum(1).cpu().numpy()
+    perm = np.argsort(-n_al, kind="stable")
+    if np.array_equal(perm, np.arange(perm.size)):
+        return data, None
+    return data[perm], torch.as_tensor(perm + int(guide_offset), dtype=torch.int64)
+
+
 def shard_screen(data, shard: Shard):
     """Per-rank view of the screen.  Per-sample tensors (size factors, masks,
     bin edges) are global and shared; per-guide tensors are sliced."""
@@ -128,7 +152,7 @@ def check_window_finite(window: torch.Tensor, first_step: int) -> None:
 
 
 PER_TARGET = ("mu_loc", "mu_scale", "sd_loc", "sd_scale")
-PER_GUIDE = ("alpha_pi", "noise_loc", "noise_scale", "q0", "initial_abundance")
+from .engine import PER_GUIDE  # noqa: E402  (parameters with a guide axis)
 REPLICATED = ("mu_cov_loc", "mu_cov_scale")  # shared by every guide: identical on every rank
 
 

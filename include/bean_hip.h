@@ -205,6 +205,11 @@ enum bean_hip_buf {
                                  rank's guides of each replicate's d nll / d mu row (the likelihood gradient of
                                  the shared mu_cov site), all-reduced by the caller between
                                  bean_hip_sharded_guide and bean_hip_sharded_update                opt  */
+    BEAN_BUF_GUIDE_IDS,       /* i32 (G)   tiling: each guide's index in the caller's whole screen.  The per-guide
+                                 random streams (pi draws, accessibility noise) are keyed by it instead of
+                                 guide_offset + position, so a caller may hand the guides over in ANOTHER ORDER
+                                 - crispr-bean_amd orders them by their number of alleles, which makes the lanes
+                                 of a wave take the same branches - and still draw what the screen order draws  opt  */
     /* ---- loss */
     BEAN_BUF_LOSS_HIST = 112, /* f64 (capacity) one entry per SVI step                */
     BEAN_BUF_COUNT = 128

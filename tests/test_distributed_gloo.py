@@ -289,3 +289,23 @@ def test_two_rank_exchange_families_plumbing(tmp_path, kind):
             assert o["params"]["q0"].shape == (data.n_guides,)  # per-guide q0 gathered
             assert o["params"]["mu_loc"].shape == (data.n_targets, 1)  # per-target: gathered by target counts
             np.testing.assert_allclose(o["params"]["mu_loc"].numpy(), float(shared[0]), rtol=1e-12)
+
+
+def test_order_by_alleles_is_a_stable_permutation_with_screen_indices(monkeypatch):
+    from bean_amd.preprocessing.synthetic import make_sorting_tiling_screen, make_sorting_variant_screen
+
+    data = make_sorting_tiling_screen(257, 2, seed=4)
+    ordered, ids = parallel.order_by_alleles(data, 1000)
+    n = data.allele_mask.sum(1).numpy()
+    perm = (ids - 1000).numpy()
+    assert sorted(perm.tolist()) == list(range(257))
+    assert np.all(np.diff(n[perm]) <= 0)
+    for c in np.unique(n):  # stable: screen order inside a class
+        assert np.all(np.diff(perm[n[perm] == c]) > 0)
+    assert torch.equal(ordered.allele_mask, data.allele_mask[perm])
+    assert torch.equal(ordered.X, data.X[:, :, perm])
+    # nothing to reorder: variant screens, or switched off
+    v = make_sorting_variant_screen(50, 2, seed=1)
+    assert parallel.order_by_alleles(v)[1] is None
+    monkeypatch.setenv("BEAN_HIP_ORDER_GUIDES", "0")
+    assert parallel.order_by_alleles(data)[1] is None
