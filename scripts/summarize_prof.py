@@ -20,7 +20,16 @@ root, tag = sys.argv[1], sys.argv[2]
 config = sys.argv[3] if len(sys.argv) > 3 else "metric"
 suf = "" if config == "metric" else "_" + config
 os.makedirs("profiles", exist_ok=True)
-for f in glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recursive=True):
+
+
+def newest(pattern):
+    """The newest match only: gpurun MERGES a call's files into gpurun_out/, so an earlier call's CSVs (other
+    process ids in their names) are still lying beside this one's."""
+    fs = glob.glob(pattern, recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
+for f in newest(os.path.join(root, "kt", "**", "*kernel_stats.csv")):
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if "bean::" in r[0]]
     with open(f"profiles/{tag}_kernel_stats{suf}.csv", "w", newline="") as out:
@@ -57,7 +66,7 @@ def resources(k):
 lines, traffic, calib = [], {}, {}
 dominant = None
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
-    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(root, sub, "**", "*counter_collection.csv")):
         agg = defaultdict(lambda: defaultdict(list))
         meta = {}
         for row in csv.DictReader(open(f)):
