@@ -25,7 +25,7 @@ def main():
     data = syn.make_sorting_tiling_screen(G, 5, seed=20240503)
     n_al = data.allele_mask.sum(1).numpy()
     out = {}
-    for name in ("screen", "sorted", "screen", "sorted"):
+    for name in os.environ.get("ORDERS", "screen,sorted,screen,sorted").split(","):
         d = data
         if name == "sorted":
             d = data[np.argsort(-n_al, kind="stable")]
