@@ -68,7 +68,8 @@ def workload(name, guides, rank, acc=False):
         kw = dict(sparse=True, scale_by_accessibility=True) if acc else dict(sparse=True)
         return ("MultiMixtureNormal", data, elbo.multi_mixture_normal_loss, kw, elbo.init_params,
                 f"tiling sorting MultiMixtureNormal{'+Acc' if acc else ''}: {guides} guides, {n_alleles} edited alleles, "
-                f"{data.n_edits} edits x 5 reps x (4 sort bins + bulk)")
+                f"{data.n_edits} edits x 5 reps x (4 sort bins + bulk); guides reach the engine ordered by allele "
+                f"count, as run_inference hands them over (parallel.order_by_alleles)")
     if name == "survival":
         data = syn.make_survival_variant_screen(guides, 3, seed=20240506 + rank, with_accessibility=acc)
         return ("MixtureNormal", data, osurv.mixture_normal_loss, dict(scale_by_accessibility=True) if acc else {},

@@ -138,7 +138,7 @@ __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCt
         pe1 = pi1;
         if (ACC) {
             // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
-            const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+            const double kacc = c.kacc[g];
             const double s1 = pi1 * kacc;
             const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
             const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);

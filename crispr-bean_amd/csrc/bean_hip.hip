@@ -462,7 +462,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     const uint64_t n_dgq_t = (c->tiling_wave || c->tiling_rep) ? (uint64_t)(kAMax + 1) * G : 0;
     // arrival counters of the fused step kernel: per tile and per tile boundary (ints, zero between launches)
     const uint64_t n_ctr = c->wave2 ? ((uint64_t)d.n_tiles + 7) / 8 * 8 + 2 + 3 * B + 2 : 0;
-    const uint64_t n_dbl = n_ctr + 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
+    const uint64_t n_kacc = (s->flags & BEAN_FLAG_SCALE_BY_ACC) ? G : 0;
+    const uint64_t n_dbl = n_kacc + n_ctr + 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
                            n_split + n_dbg + n_trow + 3 * n_lpart + n_dgq + n_dgq_t + 2 * n_cov + 2 * Rr + 1;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
@@ -490,6 +491,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     d.sig_a = w; w += A1 * G;
     d.lpn = w; w += G;
     d.eps_noise = w; w += G;
+    if (n_kacc) {
+        d.kacc = w; w += G;  // filled by bean_hip_prepare (k_acc_scale)
+    }
     d.loss_const = w; w += 1;
     d.const_acc = (long long*)w; w += kLossWords;
     c->tile_targets_dev = (int*)w; w += 1;
@@ -664,6 +668,12 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
     const long n = (long)c->d.R * c->d.G;
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c->d);
     HIP_OK(hipGetLastError());
+    if (c->d.kacc) {
+        if (!c->d.acc) return fail("bean_hip_prepare: BEAN_FLAG_SCALE_BY_ACC needs BEAN_BUF_ACCESSIBILITY");
+        hipLaunchKernelGGL(k_acc_scale, dim3((unsigned)((c->d.G + 255) / 256)), dim3(256), 0, stream, c->d.acc, c->d.G,
+                           c->d.kacc);
+        HIP_OK(hipGetLastError());
+    }
     if (c->wave_guide) {
         // LDS sizing of k_guide_wave: a host read-back (4 bytes, setup only; the other one is the tiling work list below)
         HIP_OK(hipMemsetAsync(c->tile_targets_dev, 0, 2 * sizeof(int), stream));

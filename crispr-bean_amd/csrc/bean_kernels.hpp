@@ -145,6 +145,7 @@ struct DevArgs {
     // survival NormalModel: prior_params["initial_abundance"] (survival_model.py:38-49): per-guide prior
     // concentration of the Dirichlet-over-guides site and its sum over the WHOLE screen; null: ones / G
     const double* prior_ia;
+    double* kacc;    // +Acc: exp(b) acc[g]^a of utils.py:106-131, per guide - data, formed once by bean_hip_prepare
     const int* gid;  // tiling, optional: the guide's index in the caller's whole screen (keys its random streams)
     double prior_ia_total;
     int trow_summed;                   // k_sum_trow has reduced trow into part
@@ -1982,7 +1983,7 @@ void k_guide_wave(DevArgs c) {
             pe1 = pi1;
             if (ACC) {
                 // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
-                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double kacc = c.kacc[g];
                 const double s1 = pi1 * kacc;
                 const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
                 const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
@@ -2268,7 +2269,7 @@ void k_lik(DevArgs c) {
             pe1 = pi1;
             if (ACC) {
                 // scale_pi_by_accessibility + add_noise_to_pi, A = 2 (utils.py:106-178)
-                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double kacc = c.kacc[g];
                 const double s1 = pi1 * kacc;
                 const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
                 const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
@@ -2538,7 +2539,7 @@ void k_guide_survival(DevArgs c) {
             cq[1] = cl[1] ? 1e-5 : cp[1];
             q0 = (double)expf(c.p[7][g]);
             if (ACC) {
-                kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                kacc = c.kacc[g];
                 lpn = c.lpn[g];
             }
         }
@@ -2876,7 +2877,7 @@ void k_guide_tiling(DevArgs c) {
         }
         double kacc = 0.0, lpn = 0.0;
         if (ACC) {
-            kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+            kacc = c.kacc[g];
             lpn = c.lpn[g];
         }
         // unedited allele: the sorting bins' P0[b], or the guide's baseline growth exp(u_g t_b)
@@ -3261,7 +3262,7 @@ void k_guide_tiling_wave(DevArgs c) {
             // ---- accessibility transform (utils.py:106-178); its per-allele pieces live in LDS
             double pe0 = pi[0];
             if (ACC) {
-                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double kacc = c.kacc[g];
                 const double lpn = c.lpn[g];
                 double sum = 0.0;
 #pragma unroll
@@ -3566,6 +3567,14 @@ __global__ __launch_bounds__(256) void k_prepare(DevArgs c) {
 
 // most targets spanned by one 64-guide tile (guides are target-sorted; tile k = local guides
 // [64 k - sh, 64 k - sh + 64), sh = g_off % 64); *out must start at 0
+// The accessibility factor of `scale_pi_by_accessibility` (utils.py:106-131), exp(b) * acc^a with exp(b) taken in
+// float32 as the reference does: it depends on the data only, and a float64 pow is some 200 instructions - every
+// +Acc kernel used to evaluate it per (replicate, guide) and step (the allele-parallel tiling kernel per allele).
+__global__ __launch_bounds__(256) void k_acc_scale(const double* acc, int G, double* out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) out[g] = (double)expf(kAccBf) * pow(acc[g], kAccA);
+}
+
 __global__ __launch_bounds__(256) void k_tile_targets(const int* g2t, int G, int sh, int* out) {
     const int tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile * 64 - sh >= G) return;

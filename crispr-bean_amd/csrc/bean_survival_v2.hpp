@@ -216,7 +216,7 @@ void k_guide_survival_wave(DevArgs c) {
             }
             pe1 = pi1;
             if (ACC) {
-                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double kacc = c.kacc[g];
                 const double s1 = pi1 * kacc;
                 const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
                 const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);

@@ -184,7 +184,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
     // ---- accessibility transform (utils.py:106-178); its per-allele pieces live in LDS
     double pe0 = pi[0];
     if (ACC) {
-        const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+        const double kacc = c.kacc[g];
         const double lpn = c.lpn[g];
         double sum = 0.0;
 #pragma unroll

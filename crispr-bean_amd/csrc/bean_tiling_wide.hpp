@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
             dpe_dpi[j] = 1.0;
             dpe_dl[j] = 0.0;
             if (ACC && a >= 1 && a < A) {
-                const double kacc = (double)expf(kAccBf) * pow(c.acc[g], kAccA);
+                const double kacc = c.kacc[g];
                 const double s1 = pi[j] * kacc;
                 const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
                 const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);

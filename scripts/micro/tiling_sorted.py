@@ -26,10 +26,15 @@ def main():
     n_al = data.allele_mask.sum(1).numpy()
     out = {}
     for name in os.environ.get("ORDERS", "screen,sorted,screen,sorted").split(","):
-        d = data
+        d, kw = data, {}
         if name == "sorted":
             d = data[np.argsort(-n_al, kind="stable")]
-        eng = engine.HipSVI("MultiMixtureNormal", d.to("cuda:0"), num_steps=steps + 100)
+        if name == "ordered":  # as run_inference does it: with the screen indices that key the random streams
+            from bean_amd import parallel
+
+            d, ids = parallel.order_by_alleles(data)
+            kw = dict(guide_ids=ids)
+        eng = engine.HipSVI("MultiMixtureNormal", d.to("cuda:0"), num_steps=steps + 100, **kw)
         eng.run(50)
         torch.cuda.synchronize()
         t = time.perf_counter()

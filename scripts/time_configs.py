@@ -11,6 +11,11 @@ from bean_amd import engine
 from bean_amd.preprocessing import synthetic as syn
 
 def fit(family, data, steps, **kw):
+    if family == "MultiMixtureNormal":  # as run_inference hands a tiling screen over: guides ordered by allele count
+        from bean_amd import parallel
+        data, ids = parallel.order_by_alleles(data)
+        if ids is not None:
+            kw = dict(kw, guide_ids=ids)
     data = data.to("cuda:0")
     eng = engine.HipSVI(family, data, num_steps=steps + 200, **kw)
     eng.run(50); torch.cuda.synchronize()
