@@ -23,7 +23,11 @@ elif [ "$PART" = "2" ]; then
   step 300 bash scripts/profile_wide.sh $TAG > gpurun_out/prof_wide.log 2>&1
 else
   step 500 python scripts/time_configs.py > gpurun_out/time_configs.log 2>&1
-  step 400 python scripts/time_exchange.py > gpurun_out/exchange.log 2>&1
+  XCHG_CASES=tiling/8 python scripts/time_exchange.py warm > /dev/null 2>&1   # (the first process on a fresh box pages the image in)
+  rm -f gpurun_out/exchange_1rank.json   # one case per process (a host-bound loop is sensitive to what ran before it)
+  for cs in tiling/1 tiling/8 survival/1 survival/8; do
+    XCHG_CASES=$cs step 200 python scripts/time_exchange.py >> gpurun_out/exchange.log 2>&1
+  done
   step 400 python bench.py > gpurun_out/bench_metric.json 2> gpurun_out/bench_metric.err
   step 300 python bench.py --config tiling --steps 500 --warmup 50 > gpurun_out/bench_tiling.json 2> gpurun_out/bench_tiling.err
   step 300 python bench.py --config survival --steps 1000 --warmup 50 > gpurun_out/bench_survival.json 2> gpurun_out/bench_survival.err

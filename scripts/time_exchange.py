@@ -77,6 +77,9 @@ res = {}
 for name, make, family, full in (("config3 tiling", lambda g: syn.make_sorting_tiling_screen(g, 5, seed=20240503), "MultiMixtureNormal", 50000),
                                  ("config5 survival", lambda g: syn.make_survival_variant_screen(g, 3, seed=20240506), "MixtureNormal", 100000)):
     for frac in (1, 8):
+        only = os.environ.get("XCHG_CASES")  # e.g. "tiling/8,survival/1"
+        if only and f"{name.split()[1]}/{frac}" not in only.split(","):
+            continue
         g = full // frac
         data = make(g)
         kw = {}
@@ -86,5 +89,8 @@ for name, make, family, full in (("config3 tiling", lambda g: syn.make_sorting_t
         print(json.dumps(res, indent=1), flush=True)
 tag = ("_" + sys.argv[1]) if len(sys.argv) > 1 else ""
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(res, open(f"gpurun_out/exchange_1rank{tag}.json", "w"), indent=1)
+out_path = f"gpurun_out/exchange_1rank{tag}.json"
+if os.environ.get("XCHG_CASES") and os.path.exists(out_path):  # one case per process: merge into the file
+    res = dict(json.load(open(out_path)), **res)
+json.dump(res, open(out_path, "w"), indent=1)
 dist.destroy_process_group()
