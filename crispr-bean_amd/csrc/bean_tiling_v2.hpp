@@ -135,11 +135,17 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
     const double pa0 = c.pi_a0[g];
     // ---- draw: the concentrations of the guide's Dirichlet live only until the draw is done
     double pi[kAMax];
+    // Aw: one more than the highest allele slot that any guide of this WAVE fills.  The tables of an empty slot are
+    // zero (k_allele leaves them), so the two loops over (slot, condition) below stop at Aw instead of A - with
+    // the guides ordered by allele count (parallel.order_by_alleles) most waves stop early: same sums (the terms
+    // left out are exact zeros), fewer loads of zeros
+    int Aw = 1;
     {
         double alpha[kAMax], Ssum = 0.0;
 #pragma unroll
         for (int a = 0; a < kAMax; ++a) {
             const bool am = a < A && c.amask[(long)g * A + a] != 0;
+            if (__any(am)) Aw = a + 1;
             alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
             Ssum += alpha[a];
         }
@@ -214,7 +220,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
         double v = pe0 * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
 #pragma unroll
         for (int a = 1; a < kAMax; ++a)
-            if (a < A)
+            if (a < Aw)
                 v += (ACC ? ps[(0 * kAMax + a) * NT] : pi[a]) * c.tabP[((long)b * A1 + (a - 1)) * G + g];
         es[b * NT] = v;
         gs[b * NT] = 0.0;
@@ -349,13 +355,15 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
         gpi[a] = 0.0;
         if (a < A) {
             double sa = 0.0, dm = 0.0, dsg = 0.0;
+            if (a < Aw) {
 #pragma unroll 1
-            for (int b = 0; b < B; ++b) {
-                const long o = ((long)b * A1 + (a - 1)) * G + g;
-                const double ge = gs[b * NT];
-                sa += ge * c.tabP[o];
-                dm += ge * c.tabPmu[o];
-                if (!SURV) dsg += ge * c.tabPy[o];
+                for (int b = 0; b < B; ++b) {
+                    const long o = ((long)b * A1 + (a - 1)) * G + g;
+                    const double ge = gs[b * NT];
+                    sa += ge * c.tabP[o];
+                    dm += ge * c.tabPmu[o];
+                    if (!SURV) dsg += ge * c.tabPy[o];
+                }
             }
             const double pea = ACC ? ps[(0 * kAMax + a) * NT] : pi[a];
             if (ACC) {
@@ -381,14 +389,17 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
 #pragma unroll
         for (int a = 0; a < kAMax; ++a) {
             if (a < A) {
-                const double pr = pi[a] * rsum;
-                const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
-                const double lg = inside ? flog(pi[a]) - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
                 double cnt = 0.0;
                 for (int cc = 0; cc < c.C; ++cc)
                     cnt += (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
-                nll -= cnt * lg;
-                if (inside) gpi[a] -= cnt * frcp(pi[a]);
+                // (a slot without a count anywhere in the wave - the empty slots - adds exact zeros)
+                if (__any(cnt != 0.0)) {
+                    const double pr = pi[a] * rsum;
+                    const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
+                    const double lg = inside ? flog(pi[a]) - ls : flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
+                    nll -= cnt * lg;
+                    if (inside) gpi[a] -= cnt * frcp(pi[a]);
+                }
             }
         }
     }
