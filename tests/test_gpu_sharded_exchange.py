@@ -63,7 +63,10 @@ def _close(a, b, tol, what):
     assert err <= tol * max(1.0, b.abs().max().item()), (what, err)
 
 
-def test_tiling_guide_shards_share_the_edit_parameters(engine):
+# ordered: every shard hands its guides over ordered by allele count, as run_inference's engine factory does
+# (parallel.order_by_alleles) - the whole-screen fit in screen order is still what the shards reproduce
+@pytest.mark.parametrize("ordered", [False, True])
+def test_tiling_guide_shards_share_the_edit_parameters(engine, ordered):
     data = make_sorting_tiling_screen(420, 2, seed=31, n_max_alleles=5)
     whole = engine.HipSVI("MultiMixtureNormal", data.to(DEV), num_steps=200)
     whole.run(N, seed=9)
@@ -71,9 +74,13 @@ def test_tiling_guide_shards_share_the_edit_parameters(engine):
     cuts = [0, 150, 290, 420]  # guides need no target alignment here: the edits are shared
     engines = []
     for k in range(3):
-        sub = data[np.arange(cuts[k], cuts[k + 1])]
+        sub, kw = data[np.arange(cuts[k], cuts[k + 1])], {}
+        if ordered:
+            sub, ids = parallel.order_by_alleles(sub, cuts[k])
+            assert ids is not None
+            kw = dict(guide_ids=ids)
         engines.append(engine.HipSVI("MultiMixtureNormal", sub.to(DEV), num_steps=200, guide_offset=cuts[k],
-                                     n_guides_total=data.n_guides, loss_owner=(k == 0)))
+                                     n_guides_total=data.n_guides, loss_owner=(k == 0), **kw))
     _run_interleaved(engines, N, seed=9)
     for name in ("mu_loc", "mu_scale", "sd_loc", "sd_scale"):
         for e in engines:  # replicated parameters stay identical on every shard
