@@ -690,10 +690,8 @@ __device__ __forceinline__ void param_guide_tiling(const DevArgs& c, int guide_b
         if (c.eps_noise_in) {
             eps = c.eps_noise_in[g];
         } else {
-            rocrand_state_philox4x32_10 st;
-            rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + guide_stream_id(c, g),
-                         s_prep * 4ull, &st);
-            eps = (double)rocrand_normal(&st);
+            eps = (double)normal2_at(c.seed, ((unsigned long long)kSiteNoise << 48) + guide_stream_id(c, g),
+                                         s_prep * 4ull).x;
         }
         const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
         c.eps_noise[g] = eps;
@@ -1154,10 +1152,8 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
         if (c.eps_noise_in) {
             eps = c.eps_noise_in[g];
         } else {
-            rocrand_state_philox4x32_10 st;
-            rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)(c.g_off + g),
-                         s_prep * 4ull, &st);
-            eps = (double)rocrand_normal(&st);
+            eps = (double)normal2_at(c.seed, ((unsigned long long)kSiteNoise << 48) + (unsigned long long)(c.g_off + g),
+                                         s_prep * 4ull).x;
         }
         const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
         c.eps_noise[g] = eps;
@@ -1409,10 +1405,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 if (c.eps_u_in) {
                     eps = c.eps_u_in[g];
                 } else {
-                    rocrand_state_philox4x32_10 st;
-                    rocrand_init(c.seed, ((unsigned long long)kSiteAux << 48) + (unsigned long long)(c.g_off + g),
-                                 s_prep * 4ull, &st);
-                    eps = (double)rocrand_normal(&st);
+                    eps = (double)normal2_at(c.seed, ((unsigned long long)kSiteAux << 48) + (unsigned long long)(c.g_off + g),
+                                                 s_prep * 4ull).x;
                 }
                 c.eps_u[g] = eps;
                 c.u_g[g] = (double)(float)c.neg_loc + eps * (double)(float)c.neg_scale;
@@ -1457,10 +1451,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         // scaled by (Philox + Box-Muller are ~250 instructions of this kernel's one-lane-per-target chain)
         float2 nrm_next = make_float2(0.f, 0.f);
         if (PREP && active && !c.eps_mu_in) {
-            rocrand_state_philox4x32_10 st;
-            rocrand_init(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + t),
-                         s_prep * 4ull, &st);
-            nrm_next = rocrand_normal2(&st);
+            nrm_next = normal2_at(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + t),
+                                  s_prep * 4ull);
         }
         if (FINISH) {
             if (c.tgrad) {
@@ -1641,10 +1633,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                     if (c.eps_u_in) {
                         eps = c.eps_u_in[g];
                     } else {
-                        rocrand_state_philox4x32_10 st;
-                        rocrand_init(c.seed, ((unsigned long long)kSiteAux << 48) + (unsigned long long)(c.g_off + g),
-                                     s_prep * 4ull, &st);
-                        eps = (double)rocrand_normal(&st);
+                        eps = (double)normal2_at(c.seed, ((unsigned long long)kSiteAux << 48) + (unsigned long long)(c.g_off + g),
+                                         s_prep * 4ull).x;
                     }
                     c.eps_u[g] = eps;
                     c.u_g[g] = (double)(float)c.neg_loc + eps * (double)(float)c.neg_scale;
@@ -3689,9 +3679,7 @@ __global__ __launch_bounds__(64) void k_cov_step(DevArgs c) {
             if (c.eps_noise_in) {
                 eps = c.eps_noise_in[i];
             } else {
-                rocrand_state_philox4x32_10 st;
-                rocrand_init(c.seed, ((unsigned long long)kSiteCov << 48) + (unsigned long long)i, s_prep * 4ull, &st);
-                eps = (double)rocrand_normal(&st);
+                eps = (double)normal2_at(c.seed, ((unsigned long long)kSiteCov << 48) + (unsigned long long)i, s_prep * 4ull).x;
             }
             const double m = (double)loc + eps * exp((double)su);
             c.cov_eps[i] = eps;

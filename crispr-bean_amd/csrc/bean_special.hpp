@@ -490,11 +490,36 @@ struct Pair {
 
 // Philox4x32-10 block at an absolute position; out of line so that its ~35
 // registers are not multiplied by inlining into the rejection loop.
+// = rocrand4 of a rocrand_state_philox4x32_10 set up by rocrand_init(seed, sub, offset), for an offset that is a
+// multiple of four words (every offset of this library is: a block per draw round): the ten Philox rounds on
+// counter (offset / 4, subsequence) with key seed (rocrand_philox4x32_10.h; Random123), written out so that no
+// generator state object exists - held by address it was the one user of scratch memory in k_param.
 __device__ __forceinline__ uint4 philox_block(unsigned long long seed, unsigned long long sub,
                                               unsigned long long offset) {
-    rocrand_state_philox4x32_10 st;
-    rocrand_init(seed, sub, offset, &st);
-    return rocrand4(&st);
+    const unsigned long long blk = offset >> 2;
+    unsigned int c0 = (unsigned int)blk, c1 = (unsigned int)(blk >> 32), c2 = (unsigned int)sub,
+                 c3 = (unsigned int)(sub >> 32);
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long m0 = (unsigned long long)0xD2511F53u * c0, m1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(m1 >> 32) ^ c1 ^ k0, n2 = (unsigned int)(m0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned int)m1;
+        c3 = (unsigned int)m0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// What rocrand_normal2 (.x: rocrand_normal) returns from a generator set up by rocrand_init(seed, sub, offset):
+// the Box-Muller pair of the first two words of its first Philox block (rocrand_normal.h) - the same values,
+// without a generator state held by address (the cached second normal and its flag made that state the one user
+// of scratch memory in k_param).
+__device__ __forceinline__ float2 normal2_at(unsigned long long seed, unsigned long long sub, unsigned long long offset) {
+    const uint4 v = philox_block(seed, sub, offset);
+    return rocrand_device::detail::box_muller(v.x, v.y);
 }
 __device__ __noinline__ uint4 philox_at(unsigned long long seed, unsigned long long sub,
                                         unsigned long long offset) {

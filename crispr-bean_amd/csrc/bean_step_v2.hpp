@@ -197,10 +197,8 @@ void k_step_wave2(DevArgs c, int flip) {
                 V[t] = vj;
             }
             // PREP of the next step: the draw (Philox keyed by the global target index and the step)
-            rocrand_state_philox4x32_10 st;
-            rocrand_init(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + tc),
-                         s_prep * 4ull, &st);
-            const float2 nrm = rocrand_normal2(&st);
+            const float2 nrm = normal2_at(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + tc),
+                                          s_prep * 4ull);
             const double en = j < 2 ? (double)nrm.x : (double)nrm.y;
             const float p_scale = __shfl_xor(pj, 1, 64);  // even lanes: the updated log scale of their pair
             const double val = tgt_draw(pj, en, p_scale);

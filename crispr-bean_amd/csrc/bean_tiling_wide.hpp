@@ -466,10 +466,8 @@ __device__ __forceinline__ void param_guide_tiling_wide(const DevArgs& c, int gu
         if (c.eps_noise_in) {
             eps = c.eps_noise_in[g];
         } else {
-            rocrand_state_philox4x32_10 st;
-            rocrand_init(c.seed, ((unsigned long long)kSiteNoise << 48) + guide_stream_id(c, g),
-                         s_prep * 4ull, &st);
-            eps = (double)rocrand_normal(&st);
+            eps = (double)normal2_at(c.seed, ((unsigned long long)kSiteNoise << 48) + guide_stream_id(c, g),
+                                         s_prep * 4ull).x;
         }
         const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
         c.eps_noise[g] = eps;
