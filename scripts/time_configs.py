@@ -17,8 +17,10 @@ def fit(family, data, steps, **kw):
         if ids is not None:
             kw = dict(kw, guide_ids=ids)
     data = data.to("cuda:0")
-    eng = engine.HipSVI(family, data, num_steps=steps + 200, **kw)
-    eng.run(50); torch.cuda.synchronize()
+    eng = engine.HipSVI(family, data, num_steps=2 * steps + 200, **kw)
+    # (one untimed call of the timed call's shape: whatever the first such call sets up - graphs of the chunk sizes it
+    # needs - is then in place)
+    eng.run(50); eng.run(steps); torch.cuda.synchronize()
     t = time.perf_counter(); eng.run(steps); torch.cuda.synchronize(); dt = time.perf_counter() - t
     out = {"us_per_step": dt / steps * 1e6, "loss_first": eng.losses()[0], "loss_last": eng.losses()[-1]}
     eng.close()
