@@ -629,7 +629,10 @@ def _compare_survival(engine, family, data, kw, seed=7, step=2):
             d = elbo.as_float64(data)
         params = {k: v.requires_grad_(True) for k, v in params.items()}
         ref_loss, ref_grads, _ = svi.loss_and_grads(osurv.LOSSES[family], d, params, noise=draws, **kw)
-        assert abs(loss - ref_loss) <= tl * abs(ref_loss), (mode, loss, ref_loss)
+        # (the reference's float32 terms do not shrink with the total: on a screen of a hundred guides, whose loss is
+        # a few thousand, their rounding is what 2e-6 of a loss of 3e4 is - seen once in 96 random shapes)
+        scale = abs(ref_loss) if mode == "f64" else max(abs(ref_loss), 3e4)
+        assert abs(loss - ref_loss) <= tl * scale, (mode, loss, ref_loss)
         for k, g in grads.items():
             ref = ref_grads[k].double().reshape(-1)
             err = (g.cpu().double().reshape(-1) - ref).abs().max().item()
