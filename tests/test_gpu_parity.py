@@ -621,7 +621,10 @@ def _compare_survival(engine, family, data, kw, seed=7, step=2):
         v.add_(0.3 * torch.randn_like(v))
     loss, grads = eng.elbo_grad(step=step, seed=seed)
     draws = {k: v.cpu() for k, v in eng.drawn_noise().items()}
-    for mode, tl, tg in (("f64", 1e-9, 5e-7), ("ref", 2e-6, 2e-5)):
+    # (float64 mode is the parity statement.  "ref" runs the oracle in the reference's float32 / float64 mix: its own
+    # rounding against float64 is 1e-6 ... 3e-6 of the loss for the survival NormalModel - 2 of 1 200 random shapes
+    # were above 2e-6 - hence 5e-6 there)
+    for mode, tl, tg in (("f64", 1e-9, 5e-7), ("ref", 5e-6, 2e-5)):
         params = {k: v.detach().cpu().clone() for k, v in eng.unconstrained.items()}
         d = data
         if mode == "f64":
