@@ -70,3 +70,10 @@ def test_bench_two_ranks_on_one_gpu_times_weak_and_strong_legs():
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads(lines[0])
     assert "all-reduce gsum" in out["strong"]["exchange"] and out["strong"]["value"] > 0
+    # tiling: every rank orders its shard's guides by allele count; the per-edit gradients are exchanged
+    res, lines = _run({"BEAN_BENCH_REHEARSAL": "1"}, "--gpus", "2", "--config", "tiling", "--steps", "20", "--warmup",
+                      "3", "--guides", "3000", "--strong-guides", "6000", "--no-cpu-baseline")
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert "all-reduce tgrad" in out["strong"]["exchange"] and out["strong"]["value"] > 0
+    assert "ordered by allele count" in out["config"]["workload"]
