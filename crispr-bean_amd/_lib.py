@@ -113,17 +113,19 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [INCLUDE]
 
 
-# Two builds of the same source: the kernels keep per-allele / per-condition state in registers and
+# Three builds of the same source: the kernels keep per-allele / per-condition state in registers and
 # unrolled loops, so the number of alleles per guide and of conditions (sorting bins / timepoints)
 # they hold are compile-time constants.  libbean_hip.so holds 8 of each (the fast path);
-# libbean_hip_a16.so holds 16 of each and is loaded for the screens that need it.
-AMAX_BUILDS = (8, 16)
+# libbean_hip_a16.so holds 16 of each and is loaded for the screens that need it; libbean_hip_a32.so holds 32
+# alleles per guide (and 16 conditions): it spills ~300 registers and is still 1.5 - 2.5 x faster than the
+# allele-parallel kernels, which take over beyond 32 alleles (scripts/micro/tiling_sorted.py, TILING_AMAX).
+AMAX_BUILDS = (8, 16, 32)
 # A third build of the same source, libbean_hip_ab.so (-DBEAN_AB_KERNELS): the default library plus every
 # superseded or opt-in kernel form (first wave form, split form, block forms, the one-launch step, the
 # tile-persistent loop) that the BEAN_HIP_* switches select - the A/B references of DESIGN.md and of the
 # bit-identity tests.  The product libraries contain the default kernels only.
 AB = "ab"
-ALL_BUILDS = (8, 16, AB)
+ALL_BUILDS = (8, 16, 32, AB)
 
 
 def lib_path(amax=8) -> str:
@@ -143,7 +145,7 @@ def is_stale(amax=8) -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False, amax=8) -> str:
-    """Compile ``csrc/bean_hip.hip`` for gfx950 into ``lib/libbean_hip[_a16].so``."""
+    """Compile ``csrc/bean_hip.hip`` for gfx950 into ``lib/libbean_hip[_a16|_a32|_ab].so``."""
     path = lib_path(amax)
     if not force and not is_stale(amax):
         return path
@@ -151,7 +153,8 @@ def build_library(force: bool = False, verbose: bool = False, amax=8) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libbean_hip.so")
     os.makedirs(LIB_DIR, exist_ok=True)
-    extra = [] if amax == 8 else (["-DBEAN_AB_KERNELS"] if amax == AB else [f"-DBEAN_AMAX={amax}", f"-DBEAN_BMAX={amax}"])
+    extra = [] if amax == 8 else (["-DBEAN_AB_KERNELS"] if amax == AB else
+                                  [f"-DBEAN_AMAX={amax}", f"-DBEAN_BMAX={min(amax, 16)}"])
     cmd = [hipcc] + HIPCC_FLAGS + extra + [os.path.join(CSRC, "bean_hip.hip"), "-o", path]
     if verbose:
         print(" ".join(cmd))

@@ -83,7 +83,9 @@ struct bean_hip_ctx {
 };
 
 extern "C" const char* bean_hip_version(void) {
-    return BEAN_AMAX <= 8 ? "bean_hip 0.1.0 (gfx950)" : "bean_hip 0.1.0 (gfx950, 16 alleles per guide / 16 conditions)";
+    return BEAN_AMAX <= 8 ? "bean_hip 0.1.0 (gfx950)"
+                          : (BEAN_AMAX <= 16 ? "bean_hip 0.1.0 (gfx950, 16 alleles per guide / 16 conditions)"
+                                             : "bean_hip 0.1.0 (gfx950, 32 alleles per guide / 16 conditions)");
 }
 extern "C" const char* bean_hip_last_error(void) { return g_err.c_str(); }
 

@@ -75,12 +75,15 @@ class HipSVI:
         if not torch.cuda.is_available():
             raise RuntimeError("crispr-bean_amd needs a ROCm GPU: there is no CPU fallback")
         # the register-resident tiling kernels hold 8 alleles per guide (and 8 conditions) in the default
-        # build, 16 in the second one; more alleles per guide run in the allele-parallel kernels of
-        # either build (csrc/bean_tiling_wide.hpp), so only the condition count decides then
+        # build, 16 in the second one, 32 alleles (16 conditions) in the third; more alleles per guide run in
+        # the allele-parallel kernels of any build (csrc/bean_tiling_wide.hpp), so only the condition count
+        # decides then
         amax = 8
         n_al = int(getattr(data, "n_max_alleles", 2)) if family == "MultiMixtureNormal" else 2
         if (8 < n_al <= 16) or data.n_condits > 8:
             amax = 16
+        if 16 < n_al <= 32:
+            amax = 32
         if lib_variant is not None:
             # "ab": libbean_hip_ab.so, the default kernels plus the superseded / opt-in forms the BEAN_HIP_*
             # switches select (A/B measurements, bit-identity tests); 8 alleles / conditions only

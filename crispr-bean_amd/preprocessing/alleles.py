@@ -14,8 +14,8 @@ Two deliberate differences, both stated to the user when they apply:
   objects whose hash depends on the process' string-hash seed, so its edit numbering is not
   reproducible run to run; any numbering is equivalent up to a permutation of the rows of the
   result table);
-* alleles per guide: up to 16 (the unedited one included) run in the register-resident kernels
-  (``libbean_hip.so`` holds 8, ``libbean_hip_a16.so`` 16), up to ``MAX_ALLELES`` = 256 in the
+* alleles per guide: up to 32 (the unedited one included) run in the register-resident kernels
+  (``libbean_hip.so`` holds 8, ``libbean_hip_a16.so`` 16, ``libbean_hip_a32.so`` 32), up to ``MAX_ALLELES`` = 256 in the
   allele-parallel kernels (``csrc/bean_tiling_wide.hpp``), so unfiltered tables fit as they are (the
   reference's own ``tests/data/tiling_mini_screen.h5ad`` has 230).  Beyond 256 the build stops with an
   error that names ``bean filter``; ``BEAN_MAX_ALLELES_PER_GUIDE=N`` opts in to keeping each guide's

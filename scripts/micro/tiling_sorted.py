@@ -22,7 +22,9 @@ from bean_amd.preprocessing import synthetic as syn  # noqa: E402
 def main():
     G = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-    data = syn.make_sorting_tiling_screen(G, 5, seed=20240503)
+    # TILING_AMAX / TILING_AMEAN: allele slots per guide and mean edited alleles (defaults: BASELINE config 3's)
+    amax, amean = int(os.environ.get("TILING_AMAX", "8")), float(os.environ.get("TILING_AMEAN", "3.0"))
+    data = syn.make_sorting_tiling_screen(G, 5, seed=20240503, n_max_alleles=amax, alleles_mean=amean)
     n_al = data.allele_mask.sum(1).numpy()
     out = {}
     for name in os.environ.get("ORDERS", "screen,sorted,screen,sorted").split(","):

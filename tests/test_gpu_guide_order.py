@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-# (12 alleles per guide: the 16-allele build; 24: the allele-parallel kernels)
-@pytest.mark.parametrize("acc,offset,n_al", [(False, 0, 8), (True, 0, 8), (False, 7000, 8), (False, 0, 12), (True, 300, 24)])
+# (12 alleles per guide: the 16-allele build; 24: the 32-allele build; 40: the allele-parallel kernels)
+@pytest.mark.parametrize("acc,offset,n_al", [(False, 0, 8), (True, 0, 8), (False, 7000, 8), (False, 0, 12), (True, 300, 24),
+                                             (False, 100, 40)])
 def test_ordered_engine_draws_and_fits_what_the_screen_order_does(acc, offset, n_al):
     data = make_sorting_tiling_screen(700, 3, seed=5, with_accessibility=acc, n_max_alleles=n_al,
                                       alleles_mean=3.0 if n_al == 8 else n_al / 2.5)

@@ -520,25 +520,35 @@ def test_tiling_screen_built_from_h5ad_matches_oracle(engine):
     _compare_tiling(engine, data, {})
 
 
-@pytest.mark.parametrize("gen_kw,kw", [
-    (dict(n_guides=150, n_reps=3, n_max_alleles=20, mask_fraction=0.05), {}),
-    (dict(n_guides=70, n_reps=2, n_max_alleles=40, with_accessibility=True), dict(scale_by_accessibility=True)),
-    (dict(n_guides=40, n_reps=2, n_max_alleles=100), {}),  # two alleles per lane
-    (dict(n_guides=65, n_reps=1, n_max_alleles=17, bins=tuple((i / 10, (i + 1) / 10) for i in range(10))), {}),
+@pytest.mark.parametrize("gen_kw,kw,kernel", [
+    # 17 ... 32 alleles per guide: the 32-allele build of the register-resident kernels (libbean_hip_a32.so)
+    (dict(n_guides=150, n_reps=3, n_max_alleles=20, mask_fraction=0.05), {}, "k_guide_tiling_rep"),
+    (dict(n_guides=65, n_reps=1, n_max_alleles=17, bins=tuple((i / 10, (i + 1) / 10) for i in range(10))), {},
+     "k_guide_tiling_rep"),
+    (dict(n_guides=90, n_reps=2, n_max_alleles=32, with_accessibility=True), dict(scale_by_accessibility=True),
+     "k_guide_tiling_rep"),
+    # more: the allele-parallel path (one wave per (replicate, guide), lanes over alleles)
+    (dict(n_guides=70, n_reps=2, n_max_alleles=40, with_accessibility=True), dict(scale_by_accessibility=True),
+     "k_guide_tiling_wide"),
+    (dict(n_guides=40, n_reps=2, n_max_alleles=100), {}, "k_guide_tiling_wide"),  # two alleles per lane
+    (dict(n_guides=60, n_reps=3, n_max_alleles=33, mask_fraction=0.05), {}, "k_guide_tiling_wide"),
 ])
-def test_wide_tiling_matches_oracle(engine, gen_kw, kw):
-    """More alleles per guide than the register-resident kernels hold (16): the allele-parallel path
-    (one wave per (replicate, guide), lanes over alleles), against the same oracle."""
+def test_wide_tiling_matches_oracle(engine, gen_kw, kw, kernel):
+    """More alleles per guide than the default builds hold (8, 16), against the same oracle."""
     data = make_sorting_tiling_screen(seed=14, **gen_kw)
     assert data.n_max_alleles == gen_kw["n_max_alleles"]
+    probe = engine.HipSVI("MultiMixtureNormal", data.to(DEV), num_steps=10, **kw)
+    assert probe.dominant_kernel == kernel
+    probe.close()
     _compare_tiling(engine, data, kw)
 
 
-def test_wide_tiling_trajectory_fused_loop_and_shards(engine):
-    data = make_sorting_tiling_screen(120, 2, seed=15, n_max_alleles=24)
+@pytest.mark.parametrize("n_al,kernel", [(24, "k_guide_tiling_rep"), (48, "k_guide_tiling_wide")])
+def test_wide_tiling_trajectory_fused_loop_and_shards(engine, n_al, kernel):
+    data = make_sorting_tiling_screen(120, 2, seed=15, n_max_alleles=n_al)
     n = 12
     eng = engine.HipSVI("MultiMixtureNormal", data.to(DEV), dump_noise=True, num_steps=2000)
-    assert eng.dominant_kernel == "k_guide_tiling_wide"
+    assert eng.dominant_kernel == kernel
     params = elbo.init_params("MultiMixtureNormal", data)
     optim = svi.ClippedAdam(params, lr=0.01, lrd=0.1 ** (1 / 2000))
     for t in range(n):
@@ -812,7 +822,8 @@ def _compare_survival_tiling(engine, data, kw, seed=7, step=2):
     (dict(n_guides=300, n_reps=2, with_accessibility=True, n_max_alleles=5), dict(scale_by_accessibility=True)),
     (dict(n_guides=130, n_reps=4, n_max_alleles=3, times=(0.0, 3.0, 6.0, 9.0, 12.0)), {}),
     (dict(n_guides=200, n_reps=2, n_max_alleles=8), dict(mu_negctrl=(0.05, 0.2))),
-    (dict(n_guides=90, n_reps=2, n_max_alleles=30), {}),  # allele-parallel path
+    (dict(n_guides=90, n_reps=2, n_max_alleles=30), {}),  # the 32-allele build
+    (dict(n_guides=80, n_reps=2, n_max_alleles=45, with_accessibility=True), dict(scale_by_accessibility=True)),  # allele-parallel path
 ])
 def test_survival_tiling_matches_oracle(engine, gen_kw, kw):
     data = make_survival_tiling_screen(seed=11, **gen_kw)
