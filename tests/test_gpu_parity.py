@@ -443,6 +443,10 @@ def _compare_tiling(engine, data, kw, seed=7, step=2):
         v.add_(noise)
     loss, grads = eng.elbo_grad(step=step, seed=seed)
     draws = {k: v.cpu() for k, v in eng.drawn_noise().items()}
+    # (float64 mode is the parity statement.  "ref" runs the oracle in the reference's float32 / float64 mix; where
+    # that mix is itself further from the float64 oracle than the band - ill-conditioned parameter points, seen in
+    # 3 of 480 random shapes at up to 3e-4 - the kernels are asked to be as close to it as three times that)
+    ref64 = {}
     for mode, tl, tg in (("f64", 1e-9, 5e-7), ("ref", 1e-6, 2e-5)):
         params = {k: v.detach().cpu().clone() for k, v in eng.unconstrained.items()}
         d = data
@@ -455,7 +459,12 @@ def _compare_tiling(engine, data, kw, seed=7, step=2):
         for k, g in grads.items():
             ref = ref_grads[k].double().reshape(-1)
             err = (g.cpu().double().reshape(-1) - ref).abs().max().item()
-            assert err <= tg * (ref.abs().max().item() + 1e-30), (mode, k, err)
+            own = 0.0
+            if mode == "f64":
+                ref64[k] = ref
+            else:
+                own = 3.0 * (ref - ref64[k]).abs().max().item()
+            assert err <= tg * (ref.abs().max().item() + 1e-30) + own, (mode, k, err)
     # gradient of masked alleles' alpha is exactly zero (in-place write at model.py:645)
     assert torch.all(grads["alpha_pi"][~data.allele_mask.to(DEV)] == 0)
     eng.set_noise(draws)
