@@ -133,7 +133,8 @@ def lib_path(amax=8) -> str:
         return LIB_PATH
     if amax == AB:
         return os.path.join(LIB_DIR, "libbean_hip_ab.so")
-    return os.path.join(LIB_DIR, f"libbean_hip_a{amax}.so")
+    # (BEAN_HIP_LIB_A16 / _A32: another build of that library, kernel A/B experiments - as BEAN_HIP_LIB for the default)
+    return os.environ.get(f"BEAN_HIP_LIB_A{amax}") or os.path.join(LIB_DIR, f"libbean_hip_a{amax}.so")
 
 
 def is_stale(amax=8) -> bool:
