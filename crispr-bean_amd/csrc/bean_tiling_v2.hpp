@@ -63,7 +63,10 @@ __host__ inline int tiling_rep_waves(int R, int B, bool acc) {
 }
 
 template <bool ACC, bool SURV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+// (the 32-allele build: two waves per SIMD and 251 VGPRs instead of four and 128 + ~300 spilled - 274 -> 200 us at
+// 20 000 guides with 24 slots, 464 -> 445 at 50 000 with 32; three waves per SIMD are slower than either.  The
+// 16-allele build stays at four: without its 60 spills it is 3 % faster at 20 000 guides and 32 % slower at 50 000.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BEAN_AMAX > 16 ? 2 : 4)))
 void k_guide_tiling_rep(DevArgs c, int Gw) {
     extern __shared__ double tls[];
     const int lane = threadIdx.x;  // thread of the workgroup: columns in LDS have NT entries
