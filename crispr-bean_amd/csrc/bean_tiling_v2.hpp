@@ -30,6 +30,12 @@
 // workgroup barriers.
 #pragma once
 
+// Diagnostic builds only (wrong results): -DBEAN_TL_DIAG=n removes one piece of k_guide_tiling_rep so that A/B timings
+// (scripts/micro/tiling_sorted.py with BEAN_HIP_LIB / BEAN_HIP_LIB_A16) give that piece's cost in place: 1 the rejection
+// loops of the draw, 2 the implicit-gradient calls, 3 the lgamma / digamma differences.
+#ifndef BEAN_TL_DIAG
+#define BEAN_TL_DIAG 0
+#endif
 namespace bean {
 
 // Dynamic LDS of the register-resident tiling guide kernels, nt threads per workgroup: three columns of B
@@ -169,7 +175,14 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
                         cq0 = cq0 < 1e-5 ? 1e-5 : cq0;
                         if (a + 1 < A) cq1 = cq1 < 1e-5 ? 1e-5 : cq1;
                     }
+#if BEAN_TL_DIAG == 1
+                    GammaPair gp;
+                    gp.g0 = 0.3 + cq0;
+                    gp.g1 = 0.2 + cq1;
+                    gp.k = rng.k;
+#else
                     const GammaPair gp = sample_gamma_pair(cq0, cq1, rng);
+#endif
                     rng.k = gp.k;
                     pi[a] = fmax(gp.g0, kDblMin);
                     sum += pi[a];
@@ -254,7 +267,13 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
                 anyfl = anyfl || floored;
                 const double al = floored ? kEps : araw;
                 A0 += al;
+#if BEAN_TL_DIAG == 3
+                DD db;
+                db.d = al * 0.5;
+                db.dp = (double)xp[(long)b * G] * 1e-3;
+#else
                 const DD db = lgamma_digamma_diff_inl(al, (double)xp[(long)b * G]);
+#endif
                 lsum += db.d;
                 ds[b * NT] = db.dp;
                 Ua += floored ? 0.0 : araw;
@@ -442,8 +461,12 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
             if (a < A) {
                 double cqa = alpha[a] * rsq;
                 if (SURV && cqa < 1e-5) cqa = 1e-5;
+#if BEAN_TL_DIAG == 2
+                row_out(kTPath + a, (pi[a] + cqa) * (gpi[a] - proj));
+#else
                 row_out(kTPath + a,
                         dirichlet_grad_one_pre(pi[a], cqa, total, c.dgq_t[(long)a * G + g], dgS_t) * (gpi[a] - proj));
+#endif
             }
     }
     if (ACC) row_out(kTGnoise, gnoise);
