@@ -117,7 +117,7 @@ def sources():
 # unrolled loops, so the number of alleles per guide and of conditions (sorting bins / timepoints)
 # they hold are compile-time constants.  libbean_hip.so holds 8 of each (the fast path);
 # libbean_hip_a16.so holds 16 of each and is loaded for the screens that need it; libbean_hip_a32.so holds 32
-# alleles per guide (and 16 conditions): it spills ~300 registers and is still 1.5 - 2.5 x faster than the
+# alleles per guide (and 16 conditions) at two waves per SIMD, nothing spilled: 1.5 - 2.8 x faster than the
 # allele-parallel kernels, which take over beyond 32 alleles (scripts/micro/tiling_sorted.py, TILING_AMAX).
 AMAX_BUILDS = (8, 16, 32)
 # A third build of the same source, libbean_hip_ab.so (-DBEAN_AB_KERNELS): the default library plus every
@@ -128,17 +128,28 @@ AB = "ab"
 ALL_BUILDS = (8, 16, 32, AB)
 
 
+def tree_path(amax=8) -> str:
+    """Where build_library() puts the build that holds ``amax`` alleles per guide: always in-tree."""
+    if amax == 8:
+        return os.path.join(LIB_DIR, "libbean_hip.so")
+    if amax == AB:
+        return os.path.join(LIB_DIR, "libbean_hip_ab.so")
+    return os.path.join(LIB_DIR, f"libbean_hip_a{amax}.so")
+
+
 def lib_path(amax=8) -> str:
+    """What load() opens: the in-tree build unless BEAN_HIP_LIB / BEAN_HIP_LIB_A16 / _A32 name another build of
+    that library (kernel A/B experiments).  The overrides are honoured by load() alone: building and the
+    staleness check never touch a file outside the tree."""
     if amax == 8:
         return LIB_PATH
     if amax == AB:
-        return os.path.join(LIB_DIR, "libbean_hip_ab.so")
-    # (BEAN_HIP_LIB_A16 / _A32: another build of that library, kernel A/B experiments - as BEAN_HIP_LIB for the default)
-    return os.environ.get(f"BEAN_HIP_LIB_A{amax}") or os.path.join(LIB_DIR, f"libbean_hip_a{amax}.so")
+        return tree_path(AB)
+    return os.environ.get(f"BEAN_HIP_LIB_A{amax}") or tree_path(amax)
 
 
 def is_stale(amax=8) -> bool:
-    path = lib_path(amax)
+    path = tree_path(amax)
     if not os.path.exists(path):
         return True
     t = os.path.getmtime(path)
@@ -147,7 +158,7 @@ def is_stale(amax=8) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False, amax=8) -> str:
     """Compile ``csrc/bean_hip.hip`` for gfx950 into ``lib/libbean_hip[_a16|_a32|_ab].so``."""
-    path = lib_path(amax)
+    path = tree_path(amax)
     if not force and not is_stale(amax):
         return path
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -156,21 +167,29 @@ def build_library(force: bool = False, verbose: bool = False, amax=8) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     extra = [] if amax == 8 else (["-DBEAN_AB_KERNELS"] if amax == AB else
                                   [f"-DBEAN_AMAX={amax}", f"-DBEAN_BMAX={min(amax, 16)}"])
-    cmd = [hipcc] + HIPCC_FLAGS + extra + [os.path.join(CSRC, "bean_hip.hip"), "-o", path]
+    # compiled beside the final path and moved there only after a clean scan: an unchecked build never sits
+    # where load() (or the next staleness check) would take it for a good one
+    tmp = path + ".tmp"
+    cmd = [hipcc] + HIPCC_FLAGS + extra + [os.path.join(CSRC, "bean_hip.hip"), "-o", tmp]
     if verbose:
         print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
-    # the toolchain's misplaced live-range copies (isa_check.py): a build that has one is not usable
-    from . import isa_check
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+        # the toolchain's misplaced live-range copies (isa_check.py): a build that has one is not usable
+        from . import isa_check
 
-    bad = isa_check.findings_of(path)
-    if bad:
-        os.replace(path, path + ".rejected")
-        lines = [f"{name} @ {addr:#x}: " + "; ".join(tx for _, tx in pre) for name, addr, _, pre in bad]
-        raise RuntimeError(f"{path}: vector instructions in front of an exec restore at a control-flow join "
-                           "(compiler fault, see crispr-bean_amd/isa_check.py):\n  " + "\n  ".join(lines))
+        bad = isa_check.findings_of(tmp)
+        if bad:
+            os.replace(tmp, path + ".rejected")
+            lines = [f"{name} @ {addr:#x}: " + "; ".join(tx for _, tx in pre) for name, addr, _, pre in bad]
+            raise RuntimeError(f"{path}: vector instructions in front of an exec restore at a control-flow join "
+                               "(compiler fault, see crispr-bean_amd/isa_check.py):\n  " + "\n  ".join(lines))
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return path
 
 

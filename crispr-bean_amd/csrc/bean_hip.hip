@@ -248,6 +248,14 @@ static void drop_graph(bean_hip_ctx* c) {
     c->resume_ok = false;  // (called whenever a buffer, the shape-dependent state or the seed changes)
 }
 
+// The captured launches hold DevArgs - and with it the seed - BY VALUE, and the four graph families share ONE
+// graph_seed: every stepping entry point therefore drops ALL the families when the seed changes, whichever of them
+// it replays itself (run(A), resume(B), run(B) used to replay run's graphs with A baked in).
+static void drop_graph_on_seed_change(bean_hip_ctx* c, unsigned long long seed) {
+    const bool any = !c->graphs.empty() || !c->graphs_fused.empty() || !c->graphs_xchg.empty() || !c->graphs_resume.empty();
+    if (any && c->graph_seed != seed) drop_graph(c);
+}
+
 extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     if (!s || !out) return fail("bean_hip_create: null argument");
     if (s->selection != BEAN_SELECTION_SORTING && s->selection != BEAN_SELECTION_SURVIVAL)
@@ -665,6 +673,7 @@ static int check_bound(bean_hip_ctx* c, bool need_grads, bool need_moments) {
 extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
     if (!c) return fail("bean_hip_prepare: null handle");
     if (check_bound(c, false, false)) return -1;
+    c->resume_ok = false;  // (bean_hip.h: a prepare between two windows forbids a resume, in every family)
     hipStream_t stream = (hipStream_t)stream_;
     HIP_OK(hipMemsetAsync(c->d.const_acc, 0, kLossWords * sizeof(long long), stream));
     const long n = (long)c->d.R * c->d.G;
@@ -1436,7 +1445,7 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
     if (first_step + n_steps > c->loss_capacity)
         return fail("bean_hip_svi_run: loss_hist too small for first_step + n_steps");
     hipStream_t stream = (hipStream_t)stream_;
-    if ((!c->graphs.empty() || !c->graphs_fused.empty()) && (c->graph_seed != seed)) drop_graph(c);
+    drop_graph_on_seed_change(c, seed);
     c->d.seed = seed;
     c->resume_ok = false;
     const bool tile_candidate = c->tile_svi && c->tile_ready && !c->profile_param && !c->d.eps_mu_in && !c->d.eps_sd_in &&
@@ -1592,7 +1601,7 @@ extern "C" int bean_hip_svi_resume(bean_hip_ctx* c, uint64_t seed, uint64_t firs
     if (first_step + n_steps > c->loss_capacity)
         return fail("bean_hip_svi_resume: loss_hist too small for first_step + n_steps");
     hipStream_t stream = (hipStream_t)stream_;
-    if (!c->graphs_resume.empty() && c->graph_seed != seed) drop_graph(c);
+    drop_graph_on_seed_change(c, seed);
     const bool resumed = c->resume_ok && c->resume_next == first_step && c->resume_seed == seed &&
                          c->resume_stream == stream_;
     c->resume_ok = false;
@@ -1841,7 +1850,7 @@ extern "C" int bean_hip_svi_run_exchanged(bean_hip_ctx* c, uint64_t seed, uint64
     if (!c->comm) return fail("bean_hip_svi_run_exchanged: call bean_hip_comm_init first");
     if (n_steps == 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
-    if (!c->graphs_xchg.empty() && c->graph_seed != seed) drop_graph(c);
+    drop_graph_on_seed_change(c, seed);
     if (bean_hip_sharded_begin(c, seed, first_step, n_steps, stream_)) return -1;  // checks, loss window, draw of step 0
     uint64_t left = n_steps;
     // hipGraphs of 2, 4, ... <= graph_chunk exchanged steps (never holding a run's last step, whose update

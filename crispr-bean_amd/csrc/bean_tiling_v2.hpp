@@ -39,10 +39,36 @@
 namespace bean {
 
 // Dynamic LDS of the register-resident tiling guide kernels, nt threads per workgroup: three columns of B
-// doubles per thread (+ the accessibility pieces); k_guide_tiling_wave also stages the counts.
-__host__ __device__ inline size_t guide_tiling_lds(int B, bool acc, size_t nt, bool stages_counts) {
-    return (size_t)(3 * B + (acc ? 3 * kAMax : 0)) * nt * sizeof(double) +
-           (stages_counts ? (size_t)2 * B * nt * sizeof(float) : 0);
+// doubles per thread; k_guide_tiling_wave (the per-replicate wave form) also parks the accessibility pieces of
+// every allele (3 kAMax columns) and stages the counts.  k_guide_tiling_rep parks NOTHING for accessibility
+// (round 5): with those columns a 256-thread workgroup asked for 79 872 B at config 3, two workgroups per CU,
+// 512 places for 981 workgroups - the launch ran as two rounds, 156.8 us against 110.4 without accessibility.
+__host__ __device__ inline size_t guide_tiling_lds(int B, bool acc, size_t nt, bool wave_form) {
+    return (size_t)(3 * B + (acc && wave_form ? 3 * kAMax : 0)) * nt * sizeof(double) +
+           (wave_form ? (size_t)2 * B * nt * sizeof(float) : 0);
+}
+
+// The accessibility transform of one edited allele's share pi_a (utils.py:106-178; kacc = exp(b) acc^a, formed once
+// by k_acc_scale; lpn the guide's logit-noise draw): scaled share s1, clamp, logit + noise, sigmoid, clamp.
+//   pea = the share the mixture sees; dpi = d pea / d pi_a; dl = d pea / d noise.
+// Cheap enough (one log, one exp, three reciprocals) to be formed where it is used, forward AND backward, instead of
+// parked across the likelihoods: same expressions, same values.
+struct AccShare {
+    double pea, dpi, dl;
+};
+__device__ __forceinline__ AccShare acc_share(double pia, double kacc, double lpn) {
+    const double s1 = pia * kacc;
+    const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
+    const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
+    const double l = flog(p1c * frcp(1.0 - p1c)) + lpn;
+    const double el = exp(l);
+    const double pn = el * frcp(1.0 + el);
+    const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
+    AccShare o;
+    o.pea = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
+    o.dl = in2 ? pn * (1.0 - pn) : 0.0;
+    o.dpi = in1 ? o.dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
+    return o;
 }
 
 
@@ -58,7 +84,9 @@ __host__ inline int tiling_rep_waves(int R, int B, bool acc) {
     for (int w = 1; w <= 4; w *= 2) {
         const double eff = (double)((64 * w / R) * R) / (double)(64 * w);
         const size_t lds = guide_tiling_lds(B, acc, (size_t)64 * w, false);
-        const size_t wgs = lds ? (size_t)160 * 1024 / lds : 16;
+        // (a request of EXACTLY a quarter / an eighth ... of the CU's 160 KB does not reliably fit that many times -
+        // round 3's 40 960 B workgroups ran as one or as two rounds from run to run - so 2 KB per CU are left out)
+        const size_t wgs = lds ? (size_t)158 * 1024 / lds : 16;
         const double waves = (double)(wgs * w < 16 ? wgs * w : 16) / 16.0;
         if (eff * waves > best_score + 1e-12) {
             best_score = eff * waves;
@@ -90,7 +118,6 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
     double* es = tls + lane;                 // e[b]              at es[b * NT]
     double* gs = tls + B * NT + lane;        // d nll / d e[b]    at gs[b * NT]
     double* ds = tls + 2 * B * NT + lane;    // digamma diffs     at ds[b * NT]
-    double* ps = tls + 3 * B * NT + lane;    // ACC: pe, d pe / d pi, d pe / d l at ps[(k * kAMax + a) * NT]
 
     const bool rgm = c.rg[(long)r * G + g] != 0;
     // both pi sites, the Multinomial and the count likelihoods are masked by repguide_mask in tiling
@@ -203,43 +230,36 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
         for (int a = 0; a < kAMax; ++a)
             if (a < A) c.pi_out[((long)r * G + g) * A + a] = rgm ? pi[a] : 1.0 / A;
     }
-    // ---- accessibility transform (utils.py:106-178); its per-allele pieces live in LDS
-    double pe0 = pi[0];
-    if (ACC) {
-        const double kacc = c.kacc[g];
-        const double lpn = c.lpn[g];
-        double sum = 0.0;
-#pragma unroll
-        for (int a = 1; a < kAMax; ++a) {
-            if (a < A) {
-                const double s1 = pi[a] * kacc;
-                const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
-                const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
-                const double l = flog(p1c * frcp(1.0 - p1c)) + lpn;
-                const double el = exp(l);
-                const double pn = el * frcp(1.0 + el);
-                const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
-                const double pea = fmin(fmax(pn, 1e-3), 1.0 - 1e-3);
-                const double dl = in2 ? pn * (1.0 - pn) : 0.0;
-                ps[(0 * kAMax + a) * NT] = pea;
-                ps[(1 * kAMax + a) * NT] = in1 ? dl * frcp(p1c * (1.0 - p1c)) * kacc : 0.0;
-                ps[(2 * kAMax + a) * NT] = dl;
-                sum += pea;
-            }
-        }
-        pe0 = 1.0 - sum;
-    }
     const double u = SURV ? c.u_g[g] : 0.0;
-    // ---- e[b] = sum_a pe_a P_a[b]
-#pragma unroll 1
-    for (int b = 0; b < B; ++b) {
-        double v = pe0 * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
+    // ---- accessibility transform (utils.py:106-178) and e[b] = sum_a pe_a P_a[b].  The transformed shares live in
+    // registers for the mix only; the backward loop forms each allele's share again (acc_share) where it needs it
+    {
+        double pe[kAMax];
+        pe[0] = pi[0];
 #pragma unroll
-        for (int a = 1; a < kAMax; ++a)
-            if (a < Aw)
-                v += (ACC ? ps[(0 * kAMax + a) * NT] : pi[a]) * c.tabP[((long)b * A1 + (a - 1)) * G + g];
-        es[b * NT] = v;
-        gs[b * NT] = 0.0;
+        for (int a = 1; a < kAMax; ++a) pe[a] = pi[a];
+        if (ACC) {
+            const double kacc = c.kacc[g];
+            const double lpn = c.lpn[g];
+            double sum = 0.0;
+#pragma unroll
+            for (int a = 1; a < kAMax; ++a) {
+                if (a < A) {
+                    pe[a] = acc_share(pi[a], kacc, lpn).pea;
+                    sum += pe[a];
+                }
+            }
+            pe[0] = 1.0 - sum;
+        }
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            double v = pe[0] * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
+#pragma unroll
+            for (int a = 1; a < kAMax; ++a)
+                if (a < Aw) v += pe[a] * c.tabP[((long)b * A1 + (a - 1)) * G + g];
+            es[b * NT] = v;
+            gs[b * NT] = 0.0;
+        }
     }
     // ---- both Dirichlet-Multinomial terms, d nll / d e[b] accumulated in gs
     double nll = 0.0;
@@ -304,31 +324,38 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
         }
     }
     // ---- back through the mixture: d loss / d pi_a and the per-allele-slot rows
+    // (survival: the guide's baseline growth draw is loaded again rather than carried across the likelihoods)
+    double u_b = 0.0;
+    if (SURV) {
+        __asm__ volatile("" ::: "memory");
+        u_b = c.u_g[g];
+    }
     double s0 = 0.0;
 #pragma unroll 1
     for (int b = 0; b < B; ++b)
-        s0 += gs[b * NT] * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
+        s0 += gs[b * NT] * (SURV ? exp(u_b * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
     // survival: control_allele_count ~ Multinomial(pi * exp(mu * t_ctrl)), mu = [u, u + mu_a]
     // (survival_model.py:535-548) adds to d / d pi_a AND to d / d mu_a.  Its per-control-timepoint normaliser
     // 1 / W and in-range count n_in are formed FIRST (they need every allele), so that the loop over alleles
     // below finishes d / d mu_a of an allele and hands the row over at once: no array of kAMax - 1 partial
     // results is carried across the control term (round 3: 14 - 22 spilled VGPRs in the survival builds).
-    // Up to kCtrlRegs control timepoints are kept in registers (the reference's screens have one); further ones
+    // kCtrlRegs control timepoints are kept in registers (ONE: what the reference's screens have - a second pair cost
+    // the accessibility build four of its six spilled VGPRs); further ones
     // are re-formed per allele.
-    constexpr int kCtrlRegs = 2;
+    constexpr int kCtrlRegs = 1;
     double ctl_rW[kCtrlRegs], ctl_nin[kCtrlRegs];
     auto ctrl_norm = [&](int cc, double& rW, double& n_in) {
         const double tc = c.ctrl_time[cc];
         double W = 0.0;
 #pragma unroll
         for (int a = 0; a < kAMax; ++a)
-            if (a < A) W += pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+            if (a < A) W += pi[a] * exp((a == 0 ? u_b : u_b + c.mu_a[(long)(a - 1) * G + g]) * tc);
         rW = frcp(W);
         n_in = 0.0;
 #pragma unroll
         for (int a = 0; a < kAMax; ++a)
             if (a < A) {
-                const double wv = pi[a] * exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+                const double wv = pi[a] * exp((a == 0 ? u_b : u_b + c.mu_a[(long)(a - 1) * G + g]) * tc);
                 const double pr = wv * rW;
                 const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
                 nll -= cnt * flog(fmin(fmax(pr, kProbEps), 1.0 - kProbEps));
@@ -349,8 +376,8 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
         for (int cc = 0; cc < c.C; ++cc) {
             double rW, n_in;
             if (cc < kCtrlRegs) {
-                rW = cc == 0 ? ctl_rW[0] : ctl_rW[1];
-                n_in = cc == 0 ? ctl_nin[0] : ctl_nin[1];
+                rW = ctl_rW[0];
+                n_in = ctl_nin[0];
             } else {
                 // re-formed; the loss terms ctrl_norm adds are counted once, by allele 0 (the first call)
                 const double nll_keep = nll;
@@ -358,7 +385,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
                 if (a != 0) nll = nll_keep;
             }
             const double tc = c.ctrl_time[cc];
-            const double gr = exp((a == 0 ? u : u + c.mu_a[(long)(a - 1) * G + g]) * tc);
+            const double gr = exp((a == 0 ? u_b : u_b + c.mu_a[(long)(a - 1) * G + g]) * tc);
             const double wv = pi[a] * gr, pr = wv * rW;
             const bool inside = pr > kProbEps && pr < 1.0 - kProbEps;
             const double cnt = (double)c.allele[(((long)r * c.C + cc) * G + g) * A + a];
@@ -368,6 +395,15 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
     };
     double gpi[kAMax], gnoise = 0.0;
     gpi[0] = ACC ? 0.0 : s0;
+    // accessibility: the guide's factor and noise draw are loaded AGAIN here (the compiler barrier makes them new
+    // values to it), so neither they nor the shares formed from them in the forward pass are carried across the
+    // likelihoods in registers - which is what the parked LDS columns were for
+    double kacc_b = 0.0, lpn_b = 0.0;
+    if (ACC) {
+        __asm__ volatile("" ::: "memory");
+        kacc_b = c.kacc[g];
+        lpn_b = c.lpn[g];
+    }
     if (SURV) {
         double unused = 0.0;
         ctrl_allele(0, gpi[0], unused);
@@ -387,10 +423,12 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
                     if (!SURV) dsg += ge * c.tabPy[o];
                 }
             }
-            const double pea = ACC ? ps[(0 * kAMax + a) * NT] : pi[a];
+            double pea = pi[a];
             if (ACC) {
-                gpi[a] = (sa - s0) * ps[(1 * kAMax + a) * NT];
-                gnoise += (sa - s0) * ps[(2 * kAMax + a) * NT];
+                const AccShare sh = acc_share(pi[a], kacc_b, lpn_b);
+                pea = sh.pea;
+                gpi[a] = (sa - s0) * sh.dpi;
+                gnoise += (sa - s0) * sh.dl;
             } else {
                 gpi[a] = sa;
             }
@@ -430,16 +468,21 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
     // from carrying them across the likelihoods instead (which is what spilled).
     __asm__ volatile("" ::: "memory");
     {
+        // (the guide index as a new value: otherwise the 64-bit addresses formed from it before the draw are kept
+        // - and spilled - to be used again here)
+        int ge = g;
+        asm volatile("" : "+v"(ge));
         double alpha[kAMax], Ssum = 0.0;
 #pragma unroll
         for (int a = 0; a < kAMax; ++a) {
-            const bool am = a < A && c.amask[(long)g * A + a] != 0;
-            alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
+            const bool am = a < A && c.amask[(long)ge * A + a] != 0;
+            alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)ge * A + a]) : kEps) : 0.0;
             Ssum += alpha[a];
         }
-        const double rsq = frcp(Ssum) * pa0;
+        const double pa0e = c.pi_a0[ge];  // (loaded again behind the barrier, not carried: see above)
+        const double rsq = frcp(Ssum) * pa0e;
         // model-side floored concentration c_p (model.py:640-651) for - d log p / d pi
-        const double rSe = frcp(Ssum + kEps) * pa0;
+        const double rSe = frcp(Ssum + kEps) * pa0e;
         double total = 0.0, proj = 0.0;
 #pragma unroll
         for (int a = 0; a < kAMax; ++a) {
@@ -455,7 +498,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
                 proj += pi[a] * gpi[a];
             }
         }
-        const double dgS_t = c.dgq_t[(long)kAMax * G + g];  // digamma(sum c_q), tabulated by k_param
+        const double dgS_t = c.dgq_t[(long)kAMax * G + ge];  // digamma(sum c_q), tabulated by k_param
 #pragma unroll
         for (int a = 0; a < kAMax; ++a)
             if (a < A) {
@@ -465,7 +508,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
                 row_out(kTPath + a, (pi[a] + cqa) * (gpi[a] - proj));
 #else
                 row_out(kTPath + a,
-                        dirichlet_grad_one_pre(pi[a], cqa, total, c.dgq_t[(long)a * G + g], dgS_t) * (gpi[a] - proj));
+                        dirichlet_grad_one_pre(pi[a], cqa, total, c.dgq_t[(long)a * G + ge], dgS_t) * (gpi[a] - proj));
 #endif
             }
     }

@@ -571,9 +571,25 @@ class HipSVI:
             t = torch.as_tensor(t).to(dev, torch.float64)
             if key == "pi":
                 t = t.reshape(self.data.n_reps, self.data.n_guides, self.A)
+                t = self._to_engine_order(t, 1)
+            elif slot == "X0_IN":
+                t = self._to_engine_order(t.reshape(self.data.n_reps, self.data.n_guides), 1).reshape(-1)
             else:
                 t = t.reshape(-1)
+                if key in ("eps_noise", "eps_u"):
+                    t = self._to_engine_order(t, 0)
             self._bind(slot, t.contiguous())
+
+    # With guide_ids the engine holds its guides in another order than the caller's screen: engine guide i is the
+    # screen's (shard's) guide guide_order[i].  Everything per-guide that crosses this class - injected and exported
+    # draws, gradients, constrained() - is in SCREEN order.
+    def _to_engine_order(self, t: torch.Tensor, axis: int) -> torch.Tensor:
+        return t if self.guide_order is None else t.index_select(axis, self.guide_order)
+
+    def _to_screen_order(self, t: torch.Tensor, axis: int) -> torch.Tensor:
+        if self.guide_order is None:
+            return t
+        return torch.empty_like(t).index_copy_(axis, self.guide_order, t)
 
     def elbo_grad(self, step: int = 0, seed: int = 101, loss_index: int = 0):
         """One ELBO evaluation: returns ``(loss, {name: grad})`` w.r.t. the
@@ -584,11 +600,17 @@ class HipSVI:
                 "elbo_grad",
             )
         torch.cuda.synchronize(self.device)
-        return float(self.loss_hist[loss_index]), {k: v.clone() for k, v in self.grads.items()}
+        grads = {k: (self._to_screen_order(v, 0) if k in PER_GUIDE and self.guide_order is not None else v.clone())
+                 for k, v in self.grads.items()}
+        return float(self.loss_hist[loss_index]), grads
 
     def drawn_noise(self) -> Dict[str, torch.Tensor]:
         """Draws used by the last evaluation (needs ``dump_noise=True``)."""
         out = {k: v.clone() for k, v in self._noise_out.items()}
+        if self.guide_order is not None:  # per-guide draws go back in screen order (see _to_screen_order)
+            for k, axis in (("pi", 1), ("eps_noise", 0), ("eps_u", 0), ("initial_abundance", 1), ("q_0", 1)):
+                if k in out and not (k == "eps_noise" and self.n_cov):
+                    out[k] = self._to_screen_order(out[k], axis)
         if "pi" in out:
             out["pi"] = out["pi"].unsqueeze(1)  # (R, 1, G, A) as the reference shapes it
         if "eps_u" in out:  # the oracle takes the baseline draw itself: u = m0 + s0 * eps (float32 constants)
@@ -621,11 +643,30 @@ class HipSVI:
         first = self.steps_done if first_step is None else int(first_step)
         if first + n_steps > self.loss_hist.numel():
             raise ValueError("loss history too small: raise num_steps / loss_capacity")
+        # a write to a parameter or moment tensor between two windows (warm start, clamping, a loaded checkpoint)
+        # bumps the tensor's version counter - the kernels' own writes do not: the draw and the tables the previous
+        # window left on the device belong to the OLD values then, so this window goes through the plain loop, as
+        # include/bean_hip.h asks after such a write (the library cannot see it; a first_step / seed that does not
+        # continue it does see)
+        versions = self._tensor_versions()
+        prev = getattr(self, "_resume_versions", None)
+        if resume and ((prev is not None and versions != prev) or getattr(self, "_resume_broken", False)):
+            resume = False
+        self._resume_broken = False
         fn = self.lib.bean_hip_svi_resume if resume else self.lib.bean_hip_svi_run
         with self._on_stream():
             self._check(fn(self._h, int(seed), first, int(n_steps), int(graph_chunk), self._sptr()),
                         "svi_resume" if resume else "svi_run")
+        self._resume_versions = versions
         self.steps_done = first + n_steps
+
+    def _tensor_versions(self):
+        return tuple(t._version for d in (self.unconstrained, self._m, self._v) for t in d.values())
+
+    def invalidate_resume(self):
+        """Break the chain of resumed windows after writing parameters or moments through raw pointers (writes
+        through torch are seen by themselves): the next ``run(resume=True)`` is a plain ``bean_hip_svi_run``."""
+        self._resume_broken = True
 
     def losses(self):
         torch.cuda.synchronize(self.device)
@@ -680,9 +721,7 @@ class HipSVI:
             # engine guide i is the screen's guide guide_order[i]: per-guide values go back in screen order
             for k in PER_GUIDE:
                 if k in out:
-                    back = torch.empty_like(out[k])
-                    back[self.guide_order] = out[k]
-                    out[k] = back
+                    out[k] = self._to_screen_order(out[k], 0)
         return out
 
 

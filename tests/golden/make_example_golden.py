@@ -5,8 +5,8 @@ element / sgRNA tables it wrote from them (`bean_element_result.MixtureNormal+Ac
 
 Run in the build container only (it reads /root/reference; nothing of the reference is executed):
     python tests/golden/make_example_golden.py
-The pickle is read with a restricted unpickler that admits torch tensors / storages, torch's constraint
-singletons and OrderedDict - no class of the reference or of Pyro.  The pickle predates the current
+The pickle is read with a restricted unpickler that admits an exact list of five globals (tensor rebuild, a
+weights-only storage loader, OrderedDict, two torch constraint classes) - no class of the reference or of Pyro.  The pickle predates the current
 `save_dict` layout: `params` is the parameter store's `get_state()`, i.e. UNCONSTRAINED values (log of the
 positive ones); they are stored here as they are, the test applies `exp` as `pyro.param` would.
 
@@ -23,9 +23,32 @@ REF = "/root/reference/docs/example_run_output/variant"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _storage_from_bytes(b):
+    """What the pickle calls as torch.storage._load_from_bytes - which is torch.load(..., weights_only=False), an
+    unrestricted nested unpickle; the nested stream holds a bare storage, so the weights-only loader reads it."""
+    import io
+
+    import torch
+
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
 class TensorsOnly(pickle.Unpickler):
+    """Admits exactly the globals this pickle names (listed with pickletools, nothing executed): the tensor
+    rebuild function, the storage loader (replaced by its weights-only form), OrderedDict and the two constraint
+    classes of the parameter store's state.  Everything else - torch.load, torch.hub, cpp_extension ... - is refused."""
+
+    ALLOWED = {
+        ("torch._utils", "_rebuild_tensor_v2"),
+        ("collections", "OrderedDict"),
+        ("torch.distributions.constraints", "_Real"),
+        ("torch.distributions.constraints", "_GreaterThan"),
+    }
+
     def find_class(self, module, name):
-        if module.split(".")[0] in ("torch", "collections"):
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            return _storage_from_bytes
+        if (module, name) in self.ALLOWED:
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"refused {module}.{name}")
 

@@ -82,3 +82,57 @@ def test_a_broken_chain_takes_the_full_head_again():
         assert torch.equal(ref.unconstrained[k], eng.unconstrained[k]), k
     ref.close()
     eng.close()
+
+
+def test_alternating_run_and_resume_with_two_seeds_never_replays_the_other_seeds_graphs():
+    """The graph families share one recorded seed (the captured launches hold it by value): run(A), resume(B),
+    run(B) used to replay run's graphs with A baked in.  Every call is compared with a FRESH engine stepped
+    through the same entry point with the same seed from the same parameters."""
+    from bean_amd import engine
+
+    data = make_sorting_variant_screen(1500, 3, seed=48).to(DEV)
+
+    def fresh_copy(src):
+        e = engine.HipSVI("MixtureNormal", data, num_steps=200)
+        for d_src, d_dst in ((src.unconstrained, e.unconstrained), (src._m, e._m), (src._v, e._v)):
+            for k in d_src:
+                d_dst[k].copy_(d_src[k])
+        return e
+
+    eng = engine.HipSVI("MixtureNormal", data, num_steps=200)
+    first = 0
+    for seed, resume in [(11, False), (12, True), (12, False), (11, True), (12, True), (11, False), (11, True)]:
+        ref = fresh_copy(eng)
+        ref.run(16, seed=seed, first_step=first, resume=resume)
+        eng.run(16, seed=seed, first_step=first, resume=resume)
+        torch.cuda.synchronize()
+        for k in ref.unconstrained:
+            assert torch.equal(ref.unconstrained[k], eng.unconstrained[k]), (seed, resume, k)
+        assert ref.losses()[first:first + 16] == eng.losses()[first:first + 16], (seed, resume)
+        ref.close()
+        first += 16
+    eng.close()
+
+
+def test_a_torch_write_to_the_parameters_between_windows_breaks_the_chain():
+    """run(resume=True) after the caller has written a parameter tensor: the draw and tables left on the device
+    belong to the old values; the engine sees the tensor's version counter and steps through the plain loop."""
+    from bean_amd import engine
+
+    data = make_sorting_variant_screen(1500, 3, seed=49).to(DEV)
+    a = engine.HipSVI("MixtureNormal", data, num_steps=64)
+    b = engine.HipSVI("MixtureNormal", data, num_steps=64)
+    a.run(10, seed=9, resume=True)
+    b.run(10, seed=9)
+    for e in (a, b):
+        e.unconstrained["mu_loc"].mul_(0.5)  # warm start / clamp
+    a.run(10, seed=9, resume=True)
+    b.run(10, seed=9)
+    a.run(10, seed=9, resume=True)
+    b.run(10, seed=9)
+    torch.cuda.synchronize()
+    for k in a.unconstrained:
+        assert torch.equal(a.unconstrained[k], b.unconstrained[k]), k
+    assert a.losses() == b.losses()
+    a.close()
+    b.close()
