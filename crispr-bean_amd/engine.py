@@ -425,19 +425,27 @@ class HipSVI:
         if getattr(self, "_xchg", None) is None:
             self._xchg = {}
             R = self.data.n_reps
+            # what is exchanged BEHIND the guide kernel lives in one allocation, so a step's post-guide exchange is
+            # ONE all-reduce whatever the family (tgrad | sq | cov are views of `_xchg_post`)
+            sizes = []
+            if self.family in ("ControlNormal", "MultiMixtureNormal"):
+                sizes.append(("tgrad", 2 * self.T, "XCHG_TGRAD"))
+            if self.surv_normal:
+                sizes.append(("sq", R, "XCHG_SQ"))
+            if self.n_cov and int(self._shape.n_guides_total) not in (0, self.data.n_guides):
+                # guide shard of a screen with sample covariates: mu_cov is shared by every guide
+                sizes.append(("cov", R, "XCHG_COV"))
+            self._xchg_post = None
+            if sizes:
+                self._xchg_post = torch.zeros(sum(n for _, n, _ in sizes), dtype=torch.float64, device=self.device)
+                at = 0
+                for name, n, slot in sizes:
+                    self._xchg[name] = self._xchg_post[at:at + n]
+                    self._bind(slot, self._xchg[name])
+                    at += n
             if self.survival and self.family in ("MixtureNormal", "Normal"):
                 self._xchg["gsum"] = torch.zeros(R + 1, dtype=torch.float64, device=self.device)
                 self._bind("XCHG_GSUM", self._xchg["gsum"])
-            if self.surv_normal:
-                self._xchg["sq"] = torch.zeros(R, dtype=torch.float64, device=self.device)
-                self._bind("XCHG_SQ", self._xchg["sq"])
-            if self.family in ("ControlNormal", "MultiMixtureNormal"):
-                self._xchg["tgrad"] = torch.zeros(2 * self.T, dtype=torch.float64, device=self.device)
-                self._bind("XCHG_TGRAD", self._xchg["tgrad"])
-            if self.n_cov and int(self._shape.n_guides_total) not in (0, self.data.n_guides):
-                # guide shard of a screen with sample covariates: mu_cov is shared by every guide
-                self._xchg["cov"] = torch.zeros(R, dtype=torch.float64, device=self.device)
-                self._bind("XCHG_COV", self._xchg["cov"])
         return self._xchg
 
     def init_native_comm(self, group=None) -> bool:
@@ -506,22 +514,23 @@ class HipSVI:
                                        + (f", hipGraphs of up to {chunk} steps" if chunk > 1 else ", eager launches"))
             self.steps_done = first + n_steps
             return
-        self.last_exchange_path = "python loop: 3 ctypes calls + torch.distributed.all_reduce per step"
+        self.last_exchange_path = ("python loop: 3 ctypes calls + at most 2 torch.distributed.all_reduce per step "
+                                   "(one in front of the guide kernel, one packed behind it)")
+        lib, h = self.lib, self._h
+        sums, guide, update = lib.bean_hip_sharded_sums, lib.bean_hip_sharded_guide, lib.bean_hip_sharded_update
+        pre, post = x.get("gsum"), self._xchg_post
         with self._on_stream(), torch.cuda.stream(self.stream):
-            self._check(self.lib.bean_hip_sharded_begin(self._h, int(seed), first, int(n_steps), sp), "sharded_begin")
+            self._check(lib.bean_hip_sharded_begin(h, int(seed), first, int(n_steps), sp), "sharded_begin")
             for i in range(n_steps):
-                self._check(self.lib.bean_hip_sharded_sums(self._h, sp), "sharded_sums")
-                if "gsum" in x:
-                    all_reduce(x["gsum"])
-                self._check(self.lib.bean_hip_sharded_guide(self._h, sp), "sharded_guide")
-                if "tgrad" in x:
-                    all_reduce(x["tgrad"])
-                if "sq" in x:
-                    all_reduce(x["sq"])
-                if "cov" in x:
-                    all_reduce(x["cov"])
-                self._check(self.lib.bean_hip_sharded_update(self._h, 1 if i == n_steps - 1 else 0, sp),
-                           "sharded_update")
+                rc = sums(h, sp)
+                if pre is not None:
+                    all_reduce(pre)
+                rc |= guide(h, sp)
+                if post is not None:
+                    all_reduce(post)
+                rc |= update(h, 1 if i == n_steps - 1 else 0, sp)
+                if rc:
+                    self._check(rc, "sharded step (sums / guide / update)")
         self.steps_done = first + n_steps
 
     # the four phases, for drivers that interleave several engines in one process (tests)

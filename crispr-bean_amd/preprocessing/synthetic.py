@@ -413,3 +413,46 @@ def make_survival_tiling_screen(n_guides: int = 2000, n_reps: int = 3, times=(0.
     data.control_timepoint = data.timepoints[control_index:control_index + 1].clone()
     data.upper_bounds = data.lower_bounds = None
     return data
+
+
+def variant_reporter_screen(data: ScreenTensors):
+    """The ``ReporterScreen`` a variant sorting ``ScreenTensors`` of this module would have come from: counts as a
+    (guides x samples) matrix with layers ``X_bcmatch`` and ``edits``, a guide table (``target``, ``target_group``
+    with the negative controls, ``accessibility`` when the screen has it) and a sample table (``replicate``,
+    ``condition``, quantiles, ``mask``) - what ``bean run sorting variant`` reads from an ``.h5ad``.  For the
+    ``bench.py`` leg that times the whole command on the one shape the reference publishes a run time for
+    (README.md:83) and for CLI tests on screens larger than the reference's 30-guide fixture."""
+    import pandas as pd
+
+    from ..framework.ReporterScreen import ReporterScreen
+
+    R, B, G = data.n_reps, data.n_condits, data.n_guides
+    lo, hi = data.lower_bounds.numpy(), data.upper_bounds.numpy()
+    names = []
+    for l, h in zip(lo, hi):
+        names.append("bulk" if (l == 0.0 and h == 1.0) else f"q{int(round(l * 100)):02d}_{int(round(h * 100)):02d}")
+    samples = pd.DataFrame({
+        "replicate": [f"rep{r + 1}" for r in range(R) for _ in range(B)],
+        "condition": [names[b] for _ in range(R) for b in range(B)],
+        "lower_quantile": [float(lo[b]) for _ in range(R) for b in range(B)],
+        "upper_quantile": [float(hi[b]) for _ in range(R) for b in range(B)],
+        "mask": 1,
+    }, index=[f"rep{r + 1}_{names[b]}" for r in range(R) for b in range(B)])
+    to_gs = lambda t: t.double().numpy().reshape(R * B, G).T.copy()  # (R, B, G) -> (G, R * B)
+    X, Xbc = to_gs(data.X), to_gs(data.X_bcmatch)
+    edits = np.zeros_like(X)
+    ctrl = names.index("bulk")
+    edited = data.allele_counts_control[:, 0, :, 1].double().numpy()  # (R, G): edited reads of the bulk sample
+    for r in range(R):
+        edits[:, r * B + ctrl] = edited[r]
+    g2t = data.guide_to_target.numpy()
+    neg = np.asarray(data.truth["negctrl_target"])[g2t]
+    width = len(str(int(g2t.max())))
+    guides = pd.DataFrame({
+        "target": [f"t{t:0{width}d}" for t in g2t],
+        "target_group": np.where(neg, "NegCtrl", "Variant"),
+    }, index=pd.Index([f"g{i:0{len(str(G))}d}" for i in range(G)], name="name"))
+    if data.guide_accessibility is not None:
+        guides["accessibility"] = data.guide_accessibility.numpy()
+    return ReporterScreen(X.astype(np.float32), guides, samples, {"X_bcmatch": Xbc, "edits": edits},
+                          {"target_base_changes": "A>G", "tiling": False})

@@ -276,7 +276,9 @@ int bean_hip_svi_resume(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step,
  *                                -> BEAN_BUF_XCHG_SQ     (survival NormalModel: projection sums)
  *                                -> BEAN_BUF_XCHG_COV    (sorting NormalModel with sample covariates: the
  *                                                         replicates' gradient sums of the shared mu_cov site)
- *     bean_hip_sharded_update(last)                       gradients, ClippedAdam, draws of the next step
+ *     bean_hip_sharded_update(last)                       gradients, ClippedAdam, draws of the next step;
+ *                                                         last != 0 on the run's final step: no further draw, and
+ *                                                         loss_hist of ALL the run's steps is written (once, here)
  *
  * Families whose parameters are all per-target or per-guide with target-aligned shards (sorting
  * Normal / MixtureNormal) need none of this: bean_hip_svi_run on every rank is the sharded fit. */

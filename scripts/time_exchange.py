@@ -31,13 +31,24 @@ torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
 
-def time_it(fn, steps):
+REPEATS = int(os.environ.get("XCHG_REPEATS", "5"))
+
+
+def time_it(fn, steps, spread=None, key=None):
+    """us per step of `steps` steps: the median of REPEATS timings in this process (min / median / max recorded
+    in `spread[key]`: a host-driven loop is what a noisy neighbour or a bad stream -> queue mapping shows up in)."""
     fn(20)
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    fn(steps)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / steps * 1e6
+    ts = []
+    for _ in range(REPEATS):
+        t = time.perf_counter()
+        fn(steps)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t) / steps * 1e6)
+    ts.sort()
+    if spread is not None:
+        spread[key] = {"min": round(ts[0], 2), "median": round(ts[len(ts) // 2], 2), "max": round(ts[-1], 2), "n": len(ts)}
+    return ts[len(ts) // 2]
 
 
 def case(family, data, steps=300, **kw):
@@ -48,23 +59,25 @@ def case(family, data, steps=300, **kw):
         if ids is not None:
             kw = dict(kw, guide_ids=ids)
     data = data.to(dev)
-    eng = engine.HipSVI(family, data, num_steps=steps + 100, device=dev, **kw)
-    out["svi_run_us"] = round(time_it(lambda n: eng.run(n), steps), 2)
+    cap = (REPEATS + 1) * steps + 100
+    spread = out["spread_us"] = {}
+    eng = engine.HipSVI(family, data, num_steps=cap, device=dev, **kw)
+    out["svi_run_us"] = round(time_it(lambda n: eng.run(n), steps, spread, "svi_run"), 2)
     eng.close()
-    eng = engine.HipSVI(family, data, num_steps=steps + 100, device=dev, **kw)
+    eng = engine.HipSVI(family, data, num_steps=cap, device=dev, **kw)
     x = eng.exchange_buffers()
     out["exchange"] = {k: int(v.numel()) for k, v in x.items()}
-    out["exchanged_us"] = round(time_it(lambda n: eng.run_exchanged(n, dist.all_reduce), steps), 2)
+    out["exchanged_us"] = round(time_it(lambda n: eng.run_exchanged(n, dist.all_reduce), steps, spread, "exchanged"), 2)
     out["exchanged_path"] = getattr(eng, "last_exchange_path", "python loop: 3 ctypes calls + torch.distributed.all_reduce per step")
     eng.close()
     out["overhead_us"] = round(out["exchanged_us"] - out["svi_run_us"], 2)
     for key, chunk in (("native_us", 0), ("native_graph_us", 32)):
-        eng = engine.HipSVI(family, data, num_steps=steps + 100, device=dev, **kw)
+        eng = engine.HipSVI(family, data, num_steps=cap, device=dev, **kw)
         if not eng.init_native_comm():
             out[key] = None
             eng.close()
             continue
-        out[key] = round(time_it(lambda n: eng.run_exchanged(n, None, graph_chunk=chunk), steps), 2)
+        out[key] = round(time_it(lambda n: eng.run_exchanged(n, None, graph_chunk=chunk), steps, spread, key[:-3]), 2)
         out[key.replace("_us", "_path")] = eng.last_exchange_path
         msg = eng.lib.bean_hip_last_error().decode()
         if chunk and "could not be captured" in msg:
