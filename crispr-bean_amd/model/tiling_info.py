@@ -99,14 +99,17 @@ def variant_table(ndata, guide_names, guide_target_group, control_tag=None, spli
 
 def guide_to_variant_df(target_info_df: pd.DataFrame) -> pd.DataFrame:
     """``_get_guide_to_variant_df`` (``bean/model/run.py:311-344``): per guide, the variants it
-    produces and their per-variant editing rates."""
+    produces and their per-variant editing rates.  As in the reference, an edit that no guide produces
+    (empty ``editing_guides``) is listed under the guide name ``""`` with a missing rate; ``bean run`` joins
+    the table on the screen's guides, so that row goes nowhere.  Pinned by ``tests/test_edit_golden.py``."""
     rows = []
     for edit, guides, rates in zip(target_info_df["edit"], target_info_df["editing_guides"],
                                    target_info_df["per_guide_editing_rates"]):
-        gl = [g for g in str(guides).strip(",").split(",") if g]
-        rl = [float(x) if x else np.nan for x in str(rates).strip(",").split(",")] if gl else []
-        for g, r in zip(gl, rl):
-            rows.append((g, edit, r))
+        if guides and pd.isnull(guides):
+            continue
+        names = str(guides).strip(",").split(",")
+        values = [float(x) if x else np.nan for x in str(rates).strip(",").split(",")]
+        rows.extend((g, edit, r) for g, r in zip(names, values))
     if not rows:
         return pd.DataFrame(columns=["variants", "per_variant_edit_rate"])
     df = pd.DataFrame(rows, columns=["guide", "variants", "per_variant_edit_rate"])

@@ -37,6 +37,7 @@ import torch
 MAX_ALLELES = 256  # csrc/bean_tiling_wide.hpp: kWideMaxA
 _REV = {"A": "T", "C": "G", "T": "A", "G": "C", "-": "-"}
 _NT_EDIT = re.compile(r"(((chr)?\w+|nan):)?-?\d+:-?\d+:[+-]:[A-Z*-]>[A-Z*-]")
+_NT_EDIT_UID = re.compile(r"[\w*]!-?\d+:-?\d+:[+-]:[A-Z*-]>[A-Z*-]")
 
 
 def nt_edit_abs(edit_str: str, uid: Optional[str] = None) -> Tuple[str, int]:
@@ -44,11 +45,11 @@ def nt_edit_abs(edit_str: str, uid: Optional[str] = None) -> Tuple[str, int]:
     ``[chrom:]pos:ref>alt``; with a uid (control guides) ``uid![chrom:]rel_pos:ref>alt``.
     Also returns the position used for sorting."""
     s = edit_str
+    if not (_NT_EDIT.fullmatch(s) or _NT_EDIT_UID.fullmatch(s)):  # (a uid inside the string is ONE character, Edit.py:71-72)
+        raise ValueError(f"{edit_str} doesn't match with Edit string format.")
     if "!" in s:
         uid_in, s = s.split("!")
         uid = uid if uid is not None else uid_in
-    if not _NT_EDIT.fullmatch(s):
-        raise ValueError(f"{edit_str} doesn't match with Edit string format.")
     parts = s.split(":")
     chrom = None
     if len(parts) == 5:
