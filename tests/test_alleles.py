@@ -110,7 +110,7 @@ def test_tiling_mini_screen_builds_consistent_tensors():
     assert len(vt) == d.n_edits and (vt["n_guides"] >= 1).all() and (vt["coding"] == "noncoding").all()
     assert (vt["effective_edit_rate"] >= 0).all() and vt["editing_guides"].map(len).gt(0).any()
     g2v = guide_to_variant_df(vt)
-    assert set(g2v.index) - {""} <= set(s.guides.index) and  # ("" = edits no guide produces, as in the reference)
+    assert set(g2v.index) - {""} <= set(s.guides.index)  # ("" = edits no guide produces, as in the reference)
     assert {"variants", "per_variant_edit_rate"} <= set(g2v.columns)
 
 
