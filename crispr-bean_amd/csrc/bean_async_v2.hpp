@@ -1,0 +1,502 @@
+// k_svi_async: ALL the SVI steps of a call in one launch, with no grid-wide boundary between steps
+// (variant sorting families whose parameters are all per target or per guide - the metric workload).
+//
+// What the two launches per step cost ("What one launch costs"): ~25 of the metric step's 55 us are
+// not arithmetic but structure - 3.5 us until a launch's first loads arrive, ~10 us in which the SIMDs drain (each SIMD's
+// youngest wave finishes alone, latency-bound), and a k_param launch of ~10 us that is a chain of memory round
+// trips.  The fused step kernel (bean_step_v2.hpp) removed the second launch and lost: all tiles finish together, so the
+// finishing waves run alone at the end of the launch.  The tile-persistent loop (bean_tile_svi.hpp) removed the
+// launches and lost: a workgroup owned a tile for the whole call and its waves waited for each other at two barriers
+// per step.
+//
+// Here nothing waits for the chip.  Single-wave workgroups stay resident and PULL work items (step, tile, replicate)
+// from a queue; an item is k_guide_wave2's wave work (guide_wave2_tile, the same code, the same bits); the wave that
+// completes a tile last finishes it - k_step_wave2's hand-over and k_param's per-target / per-guide code - and then
+// publishes "tile k has completed step s".  An item of step s + 1 waits (a bounded poll) for that word of its own tile
+// and of the two neighbours it may share a target with, and for nothing else: one tile's finish chain runs while other
+// tiles' waves keep the SIMDs busy, and a step never drains.
+//
+// Order and progress.  The queue is one counter per XCD group (blockIdx & 7, a label: the blocks that share a label
+// share an L2; nothing depends on it but speed), items in (step, tile, replicate) order; tile k belongs to group
+// k & 7, so whatever a tile reads and writes over the steps stays in one L2 except the targets it shares with its
+// neighbours.  An item depends only on items of the PREVIOUS step, and a group hands out all items of step s before any
+// of step s + 1: a wave that polls waits for waves that hold earlier items and do not wait for it - no cycle, whatever
+// the residency.  Every poll is bounded (kAsyncSpinMax) and watches an abort word; a wave that gives up sets it, every
+// wave then leaves at its next poll or pull, the grid drains, and k_async_tail turns the call's loss slots into NaN
+// (the host halts a fit on a non-finite loss window).
+//
+// Visibility (MI355X_MICROARCH.md, "inter-workgroup visibility"; the forms measured valid there).  Per-XCD L2s are not
+// coherent with each other and a CU's L1 is never refreshed by another CU's stores.  Everything one wave writes and
+// another wave of this launch reads - rows, per-target sums, loss parts (guide waves -> finisher); parameters, moments,
+// draws, Phi tables, digamma tables (finisher -> the tile's next step) - is STORED at agent scope (sc1: written
+// through) and LOADED at agent scope (sc1: bypasses L1); the writer waits for its stores (s_waitcnt vmcnt(0)) before
+// the relaxed agent-scope atomic that signals them (arrival counter, completed-step word); the reader issues its loads
+// after the atomic it polled has returned.  No fences (an agent-scope fence per wave was measured at 46 -> 189 us per
+// launch).  Data that no wave writes (counts, masks, size factors, a0, offsets) is read with plain loads.
+//
+// Bit-identical to the two launches per step (tests/test_gpu_async.py): same per-pair math, same summation orders,
+// integer loss accumulation.
+#pragma once
+
+#include "bean_devargs_sgpr.hpp"
+
+#ifndef BEAN_ASYNC_INLINE
+#define BEAN_ASYNC_INLINE __noinline__
+#endif
+#ifndef BEAN_ASYNC_PRIO
+#define BEAN_ASYNC_PRIO 1
+#endif
+#ifndef BEAN_ASYNC_SLEEP
+#define BEAN_ASYNC_SLEEP 8
+#endif
+#ifndef BEAN_ASYNC_EU
+#define BEAN_ASYNC_EU BEAN_WAVE_EU
+#endif
+
+namespace bean {
+
+// When it is the default (BEAN_HIP_STEP=async forces it for any eligible screen, =pair switches it off), measured on
+// MI355X against the two launches per step (scripts/time_async.py, R = 5; us per step, async at its best grid / pair):
+// 25k guides 41.0 / 37.1, 37.5k 49.0 / 46.7, 50k 49.8 / 55.6, 62.5k 62.7 / 66.1, 75k 71.7 / 75.2, 87.5k 77.0 / 86.3,
+// 100k 83.6 / 96.5, 125k 101.8 / 113.7, 150k 120.6 / 132.2, 250k 190.9 / 204.5, 500k 387 / 384: from ~3 300 items
+// (tile, replicate) per step upwards.  Below that a step is one tile's dependency chain either way and k_param's
+// chip-wide launch is the shorter chain.
+constexpr long kAsyncMinItems = 3300;
+// Resident waves per SIMD.  Fewer waves than the chip holds is FASTER while a step has few items per wave: a wave's
+// guide work is a latency chain (20 us alone, 34 us with three neighbours on its SIMD), a tile's next step waits for the
+// slowest of its R waves plus the finish, and with ~2 items per wave and step every wave always finds an item whose
+// dependencies are met (measured wait: 0.8 us median at two waves per SIMD, 25 us at four - scripts/async_timeline.py).
+// 50k guides: 2 / 3 / 4 waves per SIMD 49.8 / 59.6 / 67.7 us per step; 100k: 99.8 / 83.6 / 93.9; 150k: - / 123.2 / 120.6.
+// Grids that do not give every SIMD the same number of waves lose 10 - 20 % (2304 blocks: 60.4 us at 50k guides).
+__host__ __device__ inline int async_waves_per_simd(long items) { return items <= 5400 ? 2 : (items <= 11000 ? 3 : 4); }
+constexpr int kAsyncQueueStride = 32;      // ints between two groups' queue counters (separate 128-byte lines)
+constexpr int kAsyncSpinMax = 1 << 21;     // polls before a wave gives up (~0.3 us each: over half a second)
+
+struct AsyncArgs {
+    unsigned long long step0, slot0;  // first step of the call and its loss slot
+    int n_steps;
+    int* queue;                // [8 * kAsyncQueueStride] next item of each group; zero when the call starts
+    int* done;                 // [n_tiles] steps of THIS call the tile has completed; zero when the call starts
+    int* abort_flag;           // [1] set by a wave whose poll ran out
+    const float* step_sizes;   // [n_steps] ClippedAdam step size of the update of step0 + i (k_step_sizes)
+    unsigned long long* stamps;  // diagnostic builds (-DBEAN_ASYNC_STAMP): kAsyncStampSteps x items x 8 words, or null
+};
+// diagnostic builds: the items of local steps [kAsyncStampStep0, + kAsyncStampSteps) of a call leave their timeline
+// (real-time clock, 100 MHz): pulled, dependencies seen, guide work done, arrived, finished / published
+constexpr int kAsyncStampStep0 = 40, kAsyncStampSteps = 4;
+#ifdef BEAN_ASYNC_STAMP
+#define BEAN_ASYNC_T(k)                                                                              \
+    if (st_row) {                                                                                    \
+        unsigned long long u_;                                                                       \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u_)::"memory");               \
+        if (lane == 0) st_row[k] = u_;                                                               \
+    }
+#else
+#define BEAN_ASYNC_T(k)
+#endif
+
+// DevArgs as the kernel received them -> their copy in global memory (stream-ordered, no host staging)
+__global__ __launch_bounds__(64) void k_put_args(DevArgs c, DevArgs* out) {
+    const unsigned int* src = (const unsigned int*)&c;
+    unsigned int* dst = (unsigned int*)out;
+    for (unsigned i = threadIdx.x; i < sizeof(DevArgs) / 4; i += 64) dst[i] = src[i];
+}
+
+// ClippedAdam step sizes of the n updates that follow update `step0` (update t = step + 1), one thread each, with the
+// device's exp / pow (adam_coef) so that every path holds the same float32 value
+__global__ __launch_bounds__(256) void k_step_sizes(DevArgs c, unsigned long long step0, int n, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = adam_coef(c, step0 + (unsigned long long)i + 1).step_size;
+}
+
+// After the call: the step counters as n {guide, k_param} pairs would have left them (so that the pair path, the
+// loss finalize and a later resume continue from here), and NaN in the call's loss slots if the launch gave up.
+__global__ __launch_bounds__(64) void k_async_tail(DevArgs c, AsyncArgs a) {
+    const bool aborted = *a.abort_flag != 0;
+    if (aborted)
+        for (int i = threadIdx.x; i < a.n_steps; i += 64)
+            atomicAdd((unsigned long long*)(c.loss_acc + ((long)(a.slot0 + i) * kLossSub) * kLossWords) + 2, 1ull);
+    if (threadIdx.x != 0) return;
+    StepCtr last, next;
+    last.step = a.step0 + a.n_steps - 1;
+    last.slot = a.slot0 + a.n_steps - 1;
+    last.step_size = adam_coef(c, last.step + 1).step_size;
+    last.pad_ = 0.f;
+    next.step = last.step + 1;
+    next.slot = last.slot + 1;
+    next.step_size = 0.f;
+    next.pad_ = 0.f;
+    *c.ctrA = last;
+    *c.ctrB = next;
+}
+
+// Finish tile `tile` of the step `ctr` describes: k_param's work for the tile's targets and guides (FINISH of this
+// step, PREP of the next), by the wave that arrived last.  The structure and the arithmetic are k_step_wave2's
+// (bean_step_v2.hpp; its comments explain the lane maps); what differs is that every access to state that lives
+// across steps is agent-scope, because the wave that finishes this tile's NEXT step runs on another CU.
+// Out of line, DevArgs from their copy in global memory into SGPRs (bean_devargs_sgpr.hpp): inlined into the item loop
+// the compiler hoists every loop-invariant value of the pair math and of this chain - the 64-bit constants of the
+// polynomials first - above the loop and spills them (measured: 249 spilled VGPRs, 576 B of scratch per lane).
+template <int FAM, bool ACC>
+__device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned long long step, unsigned long long slot,
+                                               float step_size, int tile, int t0, int nt) {
+    const DevArgs c = dev_args_in_sgprs(cp);
+    step = rfl_u64(step);
+    slot = rfl_u64(slot);
+    step_size = __builtin_bit_cast(float, rfl_i(__builtin_bit_cast(int, step_size)));
+    tile = rfl_i(tile);
+    t0 = rfl_i(t0);
+    nt = rfl_i(nt);
+    StepCtr ctr;
+    ctr.step = step;
+    ctr.slot = slot;
+    ctr.step_size = step_size;
+    ctr.pad_ = 0.f;
+    constexpr bool MIX = FAM == kMixture;
+    constexpr int COH = 2;
+    extern __shared__ double tabs[];
+    const int lane = threadIdx.x, R = c.R, G = c.G, B = c.B;
+    const int t1 = t0 + nt - 1;
+    const int tof0 = c.toff[t0], tof1 = c.toff[t1 + 1];
+    const unsigned long long s_prep = ctr.step + 1;
+    AdamCoef ak;
+    ak.step_size = ctr.step_size;
+    ak.clip = (float)c.clip;
+    const int g_first = tile * 64 - c.g_sh > 0 ? tile * 64 - c.g_sh : 0;
+    const int g_last = tile * 64 + 63 - c.g_sh < G ? tile * 64 + 63 - c.g_sh : G - 1;
+    const bool left_str = tof0 < g_first;
+    const bool right_str = tof1 > g_last + 1;
+    int own_left = left_str ? 0 : 1, own_right = right_str ? 0 : 1;
+    if (lane == 0) {
+        // a target that straddles two tiles goes to the tile that completes second (one counter per boundary)
+        int* const bl = c.bnd_ctr + (left_str ? tile - 1 : tile);
+        int* const br = c.bnd_ctr + tile;
+        int ol = 0, orr = 0;
+        if (left_str) ol = __hip_atomic_fetch_add(bl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (right_str) orr = __hip_atomic_fetch_add(br, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left_str && ol == 1) {
+            own_left = 1;
+            __hip_atomic_store(bl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (right_str && orr == 1) {
+            own_right = 1;
+            __hip_atomic_store(br, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    own_left = __builtin_amdgcn_readfirstlane(own_left);
+    own_right = __builtin_amdgcn_readfirstlane(own_right);
+    const int ta = own_left ? t0 : t0 + 1, tb = own_right ? t1 : t1 - 1;  // this wave's targets, ta > tb: none
+    // Which wave finishes a straddling target depends on timing, so the prior / entropy terms are not added up as
+    // doubles per wave: every TERM goes into the loss's fixed-point form by itself (fixed_add's split) and the wave
+    // adds integers - the loss history is bitwise reproducible run to run, whoever finished what.
+    long long loss_hi = 0, loss_lo = 0, loss_bad = 0;
+    auto loss_term = [&](double v) {
+        if (!(fabs(v) < kLossPartMax)) {
+            loss_bad = 1;
+            return;
+        }
+        const double hi = rint(v * 1024.0);
+        loss_hi += (long long)hi;
+        loss_lo += (long long)rint((v - hi * (1.0 / 1024.0)) * 1099511627776.0);
+    };
+    double* hmu = tabs;  // drawn mu / y of the targets, hmu[t - ta] (<= 64 targets per tile)
+    double* hy = tabs + 64;
+    __syncthreads();  // single-wave workgroup: the guide work's LDS is free from here
+
+    // ---- phases A + B: four lanes per target (lane j: unconstrained parameter j), 16 targets per pass
+    {
+        const int j = lane & 3;
+        float* const P = j == 0 ? c.p[0] : (j == 1 ? c.p[1] : (j == 2 ? c.p[2] : c.p[3]));
+        float* const M = j == 0 ? c.m[0] : (j == 1 ? c.m[1] : (j == 2 ? c.m[2] : c.m[3]));
+        float* const V = j == 0 ? c.v[0] : (j == 1 ? c.v[1] : (j == 2 ? c.v[2] : c.v[3]));
+        for (int base = ta; base <= tb; base += 16) {
+            const int t = base + (lane >> 2);
+            const bool act = t <= tb;
+            const int tc = act ? t : tb;
+            int2 dsc;
+            dsc.x = 0;
+            dsc.y = 2;
+            if (!c.tsum_direct) dsc = c.tdesc[tc];
+            const int n = dsc.y * R, ntm = c.tile_targets;
+            const long S = c.tsum_direct ? 2 * (long)c.T : (long)c.n_tiles * ntm;
+            float pj = coh_ld<COH>(P + tc), mj = coh_ld<COH>(M + tc), vj = coh_ld<COH>(V + tc);
+            const float p1 = coh_ld<COH>(c.p[1] + tc), p3 = coh_ld<COH>(c.p[3] + tc);
+            const double eps1 = coh_ld<COH>(c.eps_mu + tc), eps2 = coh_ld<COH>(c.eps_sd + tc);
+            const double mu = coh_ld<COH>(c.mu_t + tc), y = coh_ld<COH>(c.y_t + tc);
+            // the (part, replicate) sums of the target in k_param's order (16 lanes, xor tree 8, 4, 2, 1)
+            double am[4] = {0.0, 0.0, 0.0, 0.0}, ay[4] = {0.0, 0.0, 0.0, 0.0};
+            const float rR = 1.0f / (float)R;
+            for (int i0 = 0; i0 < n; i0 += 32) {
+                double xm[2][4], xy[2][4];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = i0 + 16 * mm + j + 4 * k;
+                        xm[mm][k] = 0.0;
+                        xy[mm][k] = 0.0;
+                        if (act && i < n) {
+                            const int part = (int)(((float)i + 0.5f) * rR), rr = i - part * R;
+                            const long o = (long)rr * S + (c.tsum_direct ? 2 * (long)tc + part
+                                                                         : (part == 0 ? dsc.x : (dsc.x / ntm + part) * ntm));
+                            xm[mm][k] = row_ld<true>(c.tsum + o);
+                            xy[mm][k] = row_ld<true>(c.tsum + (long)R * S + o);
+                        }
+                    }
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = i0 + 16 * mm + j + 4 * k;
+                        if (act && i < n) {  // (an absent entry must not add +0.0 to a -0.0 sum)
+                            am[k] += xm[mm][k];
+                            ay[k] += xy[mm][k];
+                        }
+                    }
+            }
+            double gmu = (am[0] + am[2]) + (am[1] + am[3]);
+            double gy = (ay[0] + ay[2]) + (ay[1] + ay[3]);
+            gmu += __shfl_xor(gmu, 2, 64);
+            gy += __shfl_xor(gy, 2, 64);
+            gmu += __shfl_xor(gmu, 1, 64);
+            gy += __shfl_xor(gy, 1, 64);
+            // FINISH of this step
+            double dlogp_mu, dlogp_dy, lt;
+            tgt_prior_terms(c, tc, tgt_sd_prior(c, tc), mu, y, eps1, eps2, p1, p3, dlogp_mu, dlogp_dy, lt);
+            if (act && j == 0) loss_term(lt);
+            const double Gd = j < 2 ? gmu - dlogp_mu : gy - dlogp_dy;
+            const double grad = tgt_grad(j, Gd, j < 2 ? eps1 : eps2, exp((double)pj));
+            adam_update(pj, mj, vj, (float)grad, ak);
+            if (act) {
+                coh_st<COH>(P + t, pj);
+                coh_st<COH>(M + t, mj);
+                coh_st<COH>(V + t, vj);
+            }
+            // PREP of the next step: the draw (Philox keyed by the global target index and the step)
+            const float2 nrm = normal2_at(c.seed, ((unsigned long long)kSiteTarget << 48) + (unsigned long long)(c.t_off + tc),
+                                          s_prep * 4ull);
+            const double en = j < 2 ? (double)nrm.x : (double)nrm.y;
+            const float p_scale = __shfl_xor(pj, 1, 64);  // even lanes: the updated log scale of their pair
+            const double val = tgt_draw(pj, en, p_scale);
+            if (act && (j & 1) == 0) {
+                coh_st<COH>((j == 0 ? c.eps_mu : c.eps_sd) + t, en);
+                coh_st<COH>((j == 0 ? c.mu_t : c.y_t) + t, val);
+                (j == 0 ? hmu : hy)[t - ta] = val;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase C: the Phi tables of the new draws (one lane per distinct finite bin edge, then one per (target, bin))
+    {
+#pragma clang fp contract(off)
+        const int nue = c.ue_idx[2 * B];
+        const int nu1 = nue > 0 ? nue : 1, per = 64 / nu1;
+        double* const ecdf = tabs + 128;
+        double* const epdf = ecdf + 64;
+        double* const eupd = epdf + 64;
+        for (int base = ta; base <= tb; base += per) {
+            const int grp = lane / nu1, ue = lane - grp * nu1;
+            const int t = base + grp;
+            const bool live = grp < per && t <= tb && nue > 0;
+            const int tl = live ? t - ta : 0;
+            {
+                const double mu = hmu[tl], y = hy[tl];
+                const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
+                const double inv = 1.0 / sigma;
+                const double u = (c.ue_z[live ? ue : 0] - mu) * inv;
+                const double pdf = norm_pdf(u);
+                if (live) {
+                    ecdf[lane] = norm_cdf(u);
+                    epdf[lane] = pdf;
+                    eupd[lane] = u * pdf;
+                }
+            }
+            __syncthreads();
+            const int cnt = (tb - base + 1 < per ? tb - base + 1 : per) * B;
+            for (int q = lane; q < cnt; q += 64) {
+                const int gq = q / B, b = q - gq * B, tq = base + gq;
+                const double y = hy[tq - ta];
+                const double sigma = c.family == kNormal ? exp(0.5 * y) : exp(y);
+                const double dsig_dy = c.family == kNormal ? 0.5 * sigma : sigma;
+                const double inv = 1.0 / sigma;
+                const int ih = c.ue_idx[b], il = c.ue_idx[B + b];
+                const double ch = ih < 0 ? 1.0 : ecdf[gq * nu1 + ih], cl = il < 0 ? 0.0 : ecdf[gq * nu1 + il];
+                const double fh = ih < 0 ? 0.0 : epdf[gq * nu1 + ih], fl = il < 0 ? 0.0 : epdf[gq * nu1 + il];
+                const double uh = ih < 0 ? 0.0 : eupd[gq * nu1 + ih], ul = il < 0 ? 0.0 : eupd[gq * nu1 + il];
+                const long o = (long)b * c.T + tq;
+                coh_st<COH>(c.tabP + o, ch - cl);
+                coh_st<COH>(c.tabPmu + o, -(fh - fl) * inv);
+                coh_st<COH>(c.tabPy + o, -(uh - ul) * inv * dsig_dy);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- the tile's guides: alpha_pi (and the accessibility noise site), tables for the next step
+    if (MIX) {
+        const int g = tile * 64 + lane - c.g_sh;
+        double lg = 0.0;
+        if (g >= 0 && g < G) {
+            param_guide_mix<true, true, true, COH>(c, g, ak, s_prep, lg);
+            loss_term(lg);
+        }
+    }
+    // ---- loss: the R waves' parts of this tile + this wave's prior / entropy terms, integer atomics
+    loss_hi = wave_sum_i64(loss_hi);
+    loss_lo = wave_sum_i64(loss_lo);
+    loss_bad = wave_sum_i64(loss_bad);
+    if (lane == 0) {
+        long long a = 0, b = 0, d = 0;
+        for (int r0 = 0; r0 < R; r0 += 8) {
+            long long w[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                w[u][0] = w[u][1] = w[u][2] = 0;
+                if (r0 + u < R) {
+                    const long long* o = c.lpart + 3 * (long)(((tile >> 3) * R + r0 + u) * 8 + (tile & 7));
+                    w[u][0] = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w[u][1] = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w[u][2] = __hip_atomic_load(o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a += w[u][0];
+                b += w[u][1];
+                d += w[u][2];
+            }
+        }
+        a += loss_hi;
+        b += loss_lo;
+        d += loss_bad;
+        long long* acc = c.loss_acc + ((long)ctr.slot * kLossSub + (tile & (kLossSub - 1))) * kLossWords;
+        atomicAdd((unsigned long long*)acc, (unsigned long long)a);
+        atomicAdd((unsigned long long*)acc + 1, (unsigned long long)b);
+        if (d) atomicAdd((unsigned long long*)acc + 2, (unsigned long long)d);
+    }
+}
+
+// One item: k_guide_wave2's wave work on (tile, r) at the step, this wave's loss part, the arrival.  Returns
+// {t0, number of the tile's targets} when this wave completed the tile (it then finishes it), {-1, 0} otherwise.
+template <int FAM, bool ACC>
+__device__ BEAN_ASYNC_INLINE int2 async_guide_item(const DevArgs* cp, unsigned long long step, unsigned long long slot,
+                                              float step_size, int tile, int r) {
+    const DevArgs c = dev_args_in_sgprs(cp);
+    tile = rfl_i(tile);
+    r = rfl_i(r);
+    StepCtr ctr;
+    ctr.step = rfl_u64(step);
+    ctr.slot = rfl_u64(slot);
+    ctr.step_size = __builtin_bit_cast(float, rfl_i(__builtin_bit_cast(int, step_size)));
+    ctr.pad_ = 0.f;
+    const int lane = threadIdx.x, R = c.R;
+    const int wg = ((tile >> 3) * R + r) * 8 + (tile & 7);  // the wave's id in the grid of padded tiles x replicates
+    int t0, nt;
+    double tot;
+    guide_wave2_tile<FAM, ACC, 2>(c, ctr, tile, r, wg, t0, nt, tot);
+    if (lane == 0) {
+        long long w0 = 0, w1 = 0, w2 = 1;
+        if (fabs(tot) < kLossPartMax) {
+            const double hi = rint(tot * 1024.0);
+            w0 = (long long)hi;
+            w1 = (long long)rint((tot - hi * (1.0 / 1024.0)) * 1099511627776.0);
+            w2 = 0;
+        }
+        long long* o = c.lpart + 3 * (long)wg;
+        __hip_atomic_store(o, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- arrival: every row / sum / loss-part store of this wave has completed before it is counted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 0;
+    if (lane == 0) {
+        const int old = __hip_atomic_fetch_add(c.tile_ctr + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == R - 1) {
+            last = 1;
+            __hip_atomic_store(c.tile_ctr + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    int2 res;
+    res.x = last ? rfl_i(t0) : -1;
+    res.y = last ? rfl_i(nt) : 0;
+    return res;
+}
+
+template <int FAM, bool ACC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BEAN_ASYNC_EU)))
+void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x & 7;               // XCD group of this wave and of the tiles it works on
+    const int nx = (n_tiles - x + 7) >> 3;      // tiles k with k & 7 == x
+    const int per_step = nx * R;
+    const long total = (long)per_step * a.n_steps;
+    int* const queue = a.queue + x * kAsyncQueueStride;
+    for (;;) {
+        // ---- pull the group's next item: (step, tile, replicate) in that order
+        int item = 0;
+        if (lane == 0) item = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= total) return;
+        const int s = item / per_step;
+#ifdef BEAN_ASYNC_STAMP
+        unsigned long long* st_row = nullptr;
+        if (a.stamps && s >= kAsyncStampStep0 && s < kAsyncStampStep0 + kAsyncStampSteps) {
+            const long all = (long)((n_tiles + 7) / 8 * 8) * R;
+            const int rem_ = item - s * per_step;
+            const int tile_ = (rem_ / R) * 8 + x;
+            st_row = a.stamps + ((long)(s - kAsyncStampStep0) * all + (long)tile_ * R + (rem_ % R)) * 8;
+            if (lane == 0) {
+                st_row[5] = (unsigned long long)blockIdx.x;
+                st_row[6] = (unsigned long long)tile_;
+                st_row[7] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
+            }
+        }
+#endif
+        BEAN_ASYNC_T(0);
+        const int rem = item - s * per_step;
+        const int jt = rem / R;
+        const int r = rem - jt * R;
+        const int tile = jt * 8 + x;
+        // ---- wait until the previous step of this tile and of its two neighbours (a target may straddle a tile
+        // boundary, and is finished by whichever of the two tiles completes second) has been finished: lanes 0 - 2
+        // poll one word each, lane 3 the abort word
+        {
+            const int tq = lane == 0 ? tile : (lane == 1 ? tile - 1 : tile + 1);
+            const bool need = s > 0 && lane < 3 && tq >= 0 && tq < n_tiles;
+            int spins = 0;
+            for (;;) {
+                int v = s;
+                if (need) v = __hip_atomic_load(a.done + tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int ab = 0;
+                if (lane == 3) ab = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any(ab != 0)) return;
+                if (__all(v >= s)) break;
+                if (++spins > kAsyncSpinMax) {
+                    if (lane == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(BEAN_ASYNC_SLEEP);
+            }
+            asm volatile("" ::: "memory");  // (nothing below is loaded before the poll has matched)
+        }
+        BEAN_ASYNC_T(1);
+        const unsigned long long step = a.step0 + (unsigned long long)s, slot = a.slot0 + (unsigned long long)s;
+        const float step_size = a.step_sizes[s];
+        const int2 fin = async_guide_item<FAM, ACC>(cp, step, slot, step_size, tile, r);
+        BEAN_ASYNC_T(2);
+        if (fin.x >= 0) {
+            // (the tile's next step waits for this chain: it goes first on its SIMD)
+            if (BEAN_ASYNC_PRIO) __builtin_amdgcn_s_setprio(3);
+            async_finish_tile<FAM, ACC>(cp, step, slot, step_size, tile, fin.x, fin.y);
+            if (BEAN_ASYNC_PRIO) __builtin_amdgcn_s_setprio(0);
+            // ---- publish: every store of the finish has completed before the tile's step count moves
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(a.done + tile, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            BEAN_ASYNC_T(3);
+        }
+        __syncthreads();  // (the next item restages the wave's LDS)
+    }
+}
+
+}  // namespace bean

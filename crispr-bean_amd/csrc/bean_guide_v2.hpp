@@ -55,12 +55,29 @@ __device__ __forceinline__ double alpha_raw(double w0, double p0, double w1, dou
 
 // A row of this (replicate, guide) for the launch that follows (k_param), or - fused step kernel, STEP -
 // for the wave of the SAME launch that finishes the tile: then an agent-scope store (global_store ... sc1).
-template <bool STEP>
+// STEP is a mode: 0 = two launches per step (plain accesses); 1 = k_step_wave2, one launch per step (rows, sums and
+// loss parts leave the wave through agent-scope stores); 2 = k_svi_async, one launch for MANY steps
+// (bean_async_v2.hpp): as 1, and everything a finishing wave of an earlier step of the SAME launch has written -
+// Phi tables, alpha_pi, the tabulated digammas, the noise draw - is read with agent-scope loads (sc1: they bypass
+// this CU's L1, which no other CU's store ever refreshes).
+template <int STEP>
 __device__ __forceinline__ void w2_row_store(double* p, double v) {
     if (STEP) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
 #define W2_ROW_STORE(ptr, val) w2_row_store<STEP>((ptr), (val))
+// value another wave of this launch may have written at an earlier step (STEP == 2), else a plain load
+template <int STEP, typename T>
+__device__ __forceinline__ T w2_ld(const T* p) {
+    if (STEP == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+// ... through a pointer the compiler knows to be global (a flat load in flight makes every later wait a full one)
+template <int STEP>
+__device__ __forceinline__ double w2_ld_g(const double __attribute__((address_space(1))) * p) {
+    if (STEP == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
 
 // The arithmetic of one (replicate, guide): draw, accessibility transform, both Dirichlet-Multinomial terms
 // with their gradients, Multinomial on the control allele counts, the pi site's densities and implicit
@@ -106,7 +123,7 @@ __device__ __forceinline__ void guide_pair_draw(const DevArgs& c, const StepCtr&
 }
 
 // (pi0, pi1: the pair's draw, guide_pair_draw)
-template <int FAM, bool ACC, bool STEP, int LS>
+template <int FAM, bool ACC, int STEP, int LS>
 __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCtr& ctr, int r, int g, bool rgm,
                                                   double pi0, double pi1,
                                                   const double* tp, int ntm, const double* c_sf, const double* c_sm,
@@ -142,7 +159,7 @@ __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCt
             const double s1 = pi1 * kacc;
             const bool in1 = s1 > 1e-3 && s1 < 1.0 - 1e-3;
             const double p1c = fmin(fmax(s1, 1e-3), 1.0 - 1e-3);
-            const double l = flog(p1c * frcp(1.0 - p1c)) + c.lpn[g];
+            const double l = flog(p1c * frcp(1.0 - p1c)) + w2_ld<STEP>(c.lpn + g);
             const double el = exp(l);
             const double pn = el * frcp(1.0 + el);
             const bool in2 = pn > 1e-3 && pn < 1.0 - 1e-3;
@@ -291,7 +308,8 @@ __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCt
         }
         // digamma of the concentrations, tabulated by k_param (DevArgs::dgq): issued here, used
         // by the implicit-gradient calls below
-        const double dgS = c.dgq[3 * (long)G + g], dg0 = c.dgq[4 * (long)G + g], dg1 = c.dgq[5 * (long)G + g];
+        const double dgS = w2_ld<STEP>(c.dgq + 3 * (long)G + g), dg0 = w2_ld<STEP>(c.dgq + 4 * (long)G + g),
+                     dg1 = w2_ld<STEP>(c.dgq + 5 * (long)G + g);
         const double lpi0 = flog(pi0), lpi1 = flog(pi1);
         const double rpi0 = frcp(pi0), rpi1 = frcp(pi1);
         if (rgm) {
@@ -359,7 +377,7 @@ __device__ __forceinline__ double guide_pair_math(const DevArgs& c, const StepCt
 // Lanes without a guide (the ends of a shard's first and last tile) carry tcol = -1 and zeros.
 // tsum_direct (no target longer than a tile): the slot is 2 t, or 2 t + 1 for the wave's FIRST segment when its
 // target began in the previous tile (`cont0`) - a target then has at most these two parts.
-template <bool STEP>
+template <int STEP>
 __device__ __forceinline__ void target_part_sums(const DevArgs& c, int lane, int tile, int r, int tcol, bool valid,
                                                  double a_mu, double a_y, int t0, bool cont0) {
     // head of a segment: lane 0, or another target than the lane below
@@ -393,22 +411,16 @@ __device__ __forceinline__ void target_part_sums(const DevArgs& c, int lane, int
 // g_off + g lies in [64 (k + g_off / 64), + 64): DevArgs::g_sh = g_off % 64 lanes of a shard's first tile
 // are empty).  Returns false for the padded tiles of the XCD-aware grid; otherwise the wave's part of the
 // loss in `tot` (valid in lane 0).
-template <int FAM, bool ACC, bool STEP>
-__device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr& ctr, int& tile_o, int& r_o,
-                                                 int& t0_o, int& nt_o, double& tot_o) {
+// guide_wave2_tile: the work on (tile, replicate r); `wg` = the wave's id in the 1-D grid of padded tiles x replicates
+// (index of its loss part, stamps).
+template <int FAM, bool ACC, int STEP>
+__device__ __forceinline__ void guide_wave2_tile(const DevArgs& c, const StepCtr& ctr, const int tile, const int r,
+                                                 const int wg, int& t0_o, int& nt_o, double& tot_o) {
     constexpr bool MIX = FAM == kMixture;
     extern __shared__ double tabs[];
     const int lane = threadIdx.x;
     const int G = c.G, T = c.T, B = c.B, R = c.R;
-    // ---- which (tile, replicate): blocks b and b + 8 share an XCD (observed placement; a speed
-    // choice only), so the R waves of a tile are given ids that are equal modulo 8
-    const int wg = blockIdx.x;
-    const int kk = wg >> 3;
-    const int r = kk % R;
-    const int tile = (kk / R) * 8 + (wg & 7);
-    if (tile >= c.n_tiles) return false;
-    tile_o = tile;
-    r_o = r;
+    (void)wg;
     const int g = tile * 64 + lane - c.g_sh;
     const bool valid = g >= 0 && g < G;
     double loss = 0.0;
@@ -445,8 +457,8 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
         const long rgc = (long)r * G + gc;
         // (first in the batch: loads return in issue order, and the draw below waits for these three only)
         if (MIX) {
-            api0 = c.p[4][2 * gc];
-            api1 = c.p[4][2 * gc + 1];
+            api0 = w2_ld<STEP>(c.p[4] + 2 * gc);
+            api1 = w2_ld<STEP>(c.p[4] + 2 * gc + 1);
             pa0 = c.pi_a0[gc];
         }
         float xv[2][kBMax];
@@ -482,7 +494,7 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
             const int wbc = ok ? wb : 0;
             const int which = (wbc >= B) + (wbc >= 2 * B), bb = wbc - which * B;
             const GlobalTab tab = which == 0 ? tabP : (which == 1 ? tabPmu : tabPy);
-            tv[q] = tab[covoff + (long)bb * T + t0 + (ok ? j : 0)];
+            tv[q] = w2_ld_g<STEP>(tab + (covoff + (long)bb * T + t0 + (ok ? j : 0)));
             wbv[q] = ok ? wb : -1;
         }
         // wave-uniform per-bin constants of this replicate: lane k * 8 + b loads constant k of bin b
@@ -543,7 +555,7 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
             if (wb < n_rows && j < nt) {
                 const int which = (wb >= B) + (wb >= 2 * B), bb = wb - which * B;
                 const double* tab = which == 0 ? c.tabP : (which == 1 ? c.tabPmu : c.tabPy);
-                tabs[wb * ntm + j] = tab[covoff + (long)bb * T + t0 + j];
+                tabs[wb * ntm + j] = w2_ld<STEP>(tab + (covoff + (long)bb * T + t0 + j));
             }
         }
         {
@@ -573,9 +585,25 @@ __device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr
     tot_o = wave_sum(loss);
     BEAN_STAMP_AT(7);
     BEAN_STAMP_CLK(2);
-    return true;
 }
 #undef W2_ROW_STORE
+
+// One wave of the 1-D grid of padded tiles x replicates: which (tile, replicate) it is - blocks b and b + 8 share an
+// XCD (observed placement; a speed choice only), so the R waves of a tile are given ids that are equal modulo 8 -
+// and its work.  Returns false for the padded tiles.
+template <int FAM, bool ACC, int STEP>
+__device__ __forceinline__ bool guide_wave2_body(const DevArgs& c, const StepCtr& ctr, int& tile_o, int& r_o,
+                                                 int& t0_o, int& nt_o, double& tot_o) {
+    const int wg = blockIdx.x;
+    const int kk = wg >> 3;
+    const int r = kk % c.R;
+    const int tile = (kk / c.R) * 8 + (wg & 7);
+    if (tile >= c.n_tiles) return false;
+    tile_o = tile;
+    r_o = r;
+    guide_wave2_tile<FAM, ACC, STEP>(c, ctr, tile, r, wg, t0_o, nt_o, tot_o);
+    return true;
+}
 
 template <int FAM, bool ACC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BEAN_WAVE_EU)))
@@ -583,7 +611,7 @@ void k_guide_wave2(DevArgs c) {
     const StepCtr ctr = *c.ctrB;
     int tile, r, t0, nt;
     double tot;
-    if (!guide_wave2_body<FAM, ACC, false>(c, ctr, tile, r, t0, nt, tot)) return;
+    if (!guide_wave2_body<FAM, ACC, 0>(c, ctr, tile, r, t0, nt, tot)) return;
     if (threadIdx.x == 0) {
         wave_loss_out(c, ctr.slot, blockIdx.x, tot);
         if (blockIdx.x == 0) publish_ctr(c, ctr);

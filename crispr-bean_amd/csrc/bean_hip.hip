@@ -81,6 +81,12 @@ struct bean_hip_ctx {
     uint64_t sharded_steps;  // bean_hip_sharded_update calls since bean_hip_sharded_begin: the slots its last call finalizes
     uint64_t resume_next, resume_seed;
     void* resume_stream;
+    // all the steps of a call in ONE launch, tile-asynchronous (bean_async_v2.hpp): eligible shape and switched on
+    bool async_step;
+    int* async_ws;      // device: 8 queue counters (kAsyncQueueStride apart), the abort word, done[n_tiles]
+    int async_blocks;   // grid: resident single-wave workgroups, a multiple of 8 (0: not yet measured)
+    unsigned long long* async_stamps;  // diagnostic builds (-DBEAN_ASYNC_STAMP): the last call's item timeline
+    size_t async_stamp_words;
 };
 
 extern "C" const char* bean_hip_version(void) {
@@ -339,6 +345,11 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->step_sizes = nullptr;
     c->step_sizes_cap = 0;
     c->dargs_dev = nullptr;
+    c->async_step = false;
+    c->async_ws = nullptr;
+    c->async_blocks = 0;
+    c->async_stamps = nullptr;
+    c->async_stamp_words = 0;
     c->loss_acc = nullptr;
     c->profile = false;
     c->profile_param = false;
@@ -458,6 +469,16 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->fused_step = false;
     c->tile_svi = false;
 #endif
+    {
+        // ALL the steps of a call in one launch, no grid-wide boundary between steps (bean_async_v2.hpp): the variant
+        // sorting families of k_guide_wave2 whose parameters are all per target or per guide, no target longer than a
+        // tile.  BEAN_HIP_STEP=async switches it on, =pair off.
+        const char* sm = getenv("BEAN_HIP_STEP");
+        const bool on = sm ? !strcmp(sm, "async") : (long)d.n_tiles * s->n_reps >= kAsyncMinItems;
+        c->async_step = on && c->wave2 && !d.wide_targets && s->max_target_len <= 64 && s->n_sample_covariates == 0 &&
+                        !c->fused_step && !c->tile_svi &&
+                        (s->family == BEAN_FAMILY_MIXTURE_NORMAL || s->family == BEAN_FAMILY_NORMAL) && !is_survival(*s);
+    }
     const uint64_t n_trow = c->tiling_wave ? (uint64_t)kTNumPart * Rr * G
                                            : (c->tiling_wide ? (uint64_t)tq_num(d.A) * Rr * G : 0);
     const uint64_t n_split = use_split ? (3 + (is_mixture(*s) ? 4 : 0)) * Rr * G
@@ -598,6 +619,7 @@ extern "C" int bean_hip_destroy(bean_hip_ctx* c) {
     if (c->tdesc_buf) (void)hipFree(c->tdesc_buf);
     if (c->step_sizes) (void)hipFree(c->step_sizes);
     if (c->dargs_dev) (void)hipFree(c->dargs_dev);
+    if (c->async_ws) (void)hipFree(c->async_ws);
     if (c->loss_acc) (void)hipFree(c->loss_acc);
     delete c;
     return 0;
@@ -1438,6 +1460,114 @@ static int launch_svi_tile(bean_hip_ctx* c, hipStream_t stream, uint64_t step0, 
 
 #endif  // BEAN_AB_KERNELS
 
+// ---- all the steps of a call in one launch: bean_async_v2.hpp
+static bool async_candidate(const bean_hip_ctx* c) {
+    const DevArgs& d = c->d;
+    return c->async_step && !c->profile_param && !d.eps_mu_in && !d.eps_sd_in && !d.pi_in && !d.eps_noise_in &&
+           !d.eps_mu_out && !d.eps_sd_out && !d.eps_noise_out && !(d.flags & kDumpPi) && d.lpart && d.tile_ctr &&
+           (d.family != kMixture || d.dgq);
+}
+
+template <int FAM, bool ACC>
+static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncArgs& a) {
+    const DevArgs& d = c->d;
+    const size_t lds = guide_wave2_lds(d.B, d.tile_targets);
+    if (c->async_blocks == 0) {
+        // resident single-wave workgroups: the grid (nothing depends on residency but speed: a block that is
+        // dispatched late finds what is left of its group's queue)
+        int per_cu = 0, dev = 0, n_cu = 0;
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_svi_async<FAM, ACC>, 64, lds));
+        HIP_OK(hipGetDevice(&dev));
+        HIP_OK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (per_cu < 1) return fail("k_svi_async does not fit on a compute unit (LDS " + std::to_string(lds) + " bytes)");
+        // the same number of waves on every SIMD (four per CU): async_waves_per_simd, within what fits
+        int k = async_waves_per_simd((long)d.n_tiles * d.R);
+        if (k > per_cu / 4) k = per_cu / 4;
+        c->async_blocks = k >= 1 ? k * 4 * n_cu : per_cu * n_cu / 8 * 8;
+        if (const char* e = getenv("BEAN_HIP_ASYNC_BLOCKS")) {  // experiments
+            const int v = atoi(e) / 8 * 8;
+            if (v >= 8) c->async_blocks = v;
+        }
+        if (getenv("BEAN_HIP_VERBOSE"))
+            fprintf(stderr, "k_svi_async: %d tiles x %d replicates per step, LDS %zu B, %d workgroups per CU x %d CUs -> grid %d\n",
+                    d.n_tiles, d.R, lds, per_cu, n_cu, c->async_blocks);
+    }
+    // no more waves than one step has items (a small screen would only add pollers)
+    const long items = (long)((d.n_tiles + 7) / 8 * 8) * d.R;
+    int blocks = c->async_blocks;
+    if ((long)blocks > items) blocks = (int)((items + 7) / 8 * 8);
+    const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
+    if (prof) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        hipExtLaunchKernelGGL((k_svi_async<FAM, ACC>), dim3(blocks), dim3(64), lds, stream, e0, e1, 0,
+                              (const DevArgs*)c->dargs_dev, d.R, d.n_tiles, a);
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+        c->ev_steps.push_back((uint64_t)a.n_steps);
+    } else {
+        hipLaunchKernelGGL((k_svi_async<FAM, ACC>), dim3(blocks), dim3(64), lds, stream, (const DevArgs*)c->dargs_dev, d.R,
+                           d.n_tiles, a);
+    }
+    return 0;
+}
+
+// n steps from step0 (loss slots from slot0) on the draw and tables already on the device; leaves the draw and tables
+// of step0 + n, the step counters as n {guide, k_param} pairs would, and the loss accumulators filled (not finalized)
+static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0, uint64_t slot0, uint64_t n_steps) {
+    const DevArgs& d = c->d;
+    if (n_steps > c->step_sizes_cap) {
+        if (c->step_sizes) (void)hipFree(c->step_sizes);
+        c->step_sizes = nullptr;
+        c->step_sizes_cap = 0;
+        const uint64_t cap = n_steps < 256 ? 256 : n_steps;
+        HIP_OK(hipMalloc((void**)&c->step_sizes, cap * sizeof(float)));
+        c->step_sizes_cap = cap;
+    }
+    const size_t ws_ints = (size_t)9 * kAsyncQueueStride + (size_t)d.n_tiles;
+    if (!c->async_ws) HIP_OK(hipMalloc((void**)&c->async_ws, ws_ints * sizeof(int)));
+    // queue counters, abort word and completed-step words start every call at zero; so do the arrival counters
+    // (they return to zero by themselves unless an earlier launch gave up)
+    HIP_OK(hipMemsetAsync(c->async_ws, 0, ws_ints * sizeof(int), stream));
+    HIP_OK(hipMemsetAsync(d.tile_ctr, 0, (size_t)d.n_arrival_ctr * sizeof(int), stream));
+    hipLaunchKernelGGL(k_step_sizes, dim3((unsigned)((n_steps + 255) / 256)), dim3(256), 0, stream, d,
+                       (unsigned long long)step0, (int)n_steps, c->step_sizes);
+    // the out-of-line pieces of the kernel read DevArgs from a copy in global memory (the same bytes: c->d as it is now)
+    if (!c->dargs_dev) HIP_OK(hipMalloc((void**)&c->dargs_dev, sizeof(DevArgs)));
+    hipLaunchKernelGGL(k_put_args, dim3(1), dim3(64), 0, stream, d, c->dargs_dev);
+    AsyncArgs a;
+    a.step0 = step0;
+    a.slot0 = slot0;
+    a.n_steps = (int)n_steps;
+    a.queue = c->async_ws;
+    a.abort_flag = c->async_ws + 8 * kAsyncQueueStride;
+    a.done = c->async_ws + 9 * kAsyncQueueStride;
+    a.step_sizes = c->step_sizes;
+    a.stamps = nullptr;
+#ifdef BEAN_ASYNC_STAMP
+    {
+        static unsigned long long* g_stamps = nullptr;
+        const size_t words = (size_t)kAsyncStampSteps * ((d.n_tiles + 7) / 8 * 8) * d.R * 8;
+        if (!g_stamps) HIP_OK(hipMalloc((void**)&g_stamps, words * 8));
+        HIP_OK(hipMemsetAsync(g_stamps, 0, words * 8, stream));
+        a.stamps = g_stamps;
+        c->async_stamps = g_stamps;
+        c->async_stamp_words = words;
+    }
+#endif
+    int rc;
+    if (d.family == kMixture) {
+        if (d.flags & kAcc) rc = launch_svi_async_t<kMixture, true>(c, stream, a);
+        else rc = launch_svi_async_t<kMixture, false>(c, stream, a);
+    } else {
+        rc = launch_svi_async_t<kNormal, false>(c, stream, a);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_async_tail, dim3(1), dim3(64), 0, stream, d, a);
+    return 0;
+}
+
 extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
                                 int32_t graph_chunk, void* stream_) {
     if (!c) return fail("bean_hip_svi_run: null handle");
@@ -1509,6 +1639,15 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
 #else
     (void)tile;
 #endif
+    if (async_candidate(c) && stream != nullptr && n_steps < (1ull << 30)) {
+        // one launch for the call: it also draws step first_step + n_steps, which nobody reads
+        launch_set_step(c, stream, first_step, first_step, n_steps);
+        launch_param<false, false, true>(c, stream);  // draws and tables of the first step
+        if (launch_svi_async(c, stream, first_step, first_step, n_steps)) return -1;
+        launch_finalize(c, stream, first_step, n_steps, false);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
     launch_set_step(c, stream, first_step, first_step, n_steps);
     launch_param<false, false, true>(c, stream);
     if (fused) {
@@ -1608,6 +1747,21 @@ extern "C" int bean_hip_svi_resume(bean_hip_ctx* c, uint64_t seed, uint64_t firs
                          c->resume_stream == stream_;
     c->resume_ok = false;
     c->d.seed = seed;
+    if (async_candidate(c) && n_steps < (1ull << 30)) {
+        // the whole window in one launch (bean_async_v2.hpp); windows chain exactly as the pairs do
+        if (!resumed) {
+            launch_set_step(c, stream, first_step, first_step, n_steps);
+            launch_param<false, false, true>(c, stream);  // draw and tables of the first step
+        }
+        if (launch_svi_async(c, stream, first_step, first_step, n_steps)) return -1;
+        launch_finalize(c, stream, first_step, n_steps, false);
+        HIP_OK(hipGetLastError());
+        c->resume_ok = true;
+        c->resume_next = first_step + n_steps;
+        c->resume_seed = seed;
+        c->resume_stream = stream_;
+        return 0;
+    }
     int kmax = 0;
     if (graph_chunk > 1) {
         // graphs of 4, 8, ... <= graph_chunk pairs, all instantiated at the first call
@@ -1927,6 +2081,7 @@ extern "C" const char* bean_hip_dominant_kernel(const bean_hip_ctx* c) {
                               : (c->tiling_rep ? "k_guide_tiling_rep" : (c->tiling_wave ? "k_guide_tiling_wave" : "k_guide_tiling"));
     if (c && c->d.survival) return c->surv_wave ? "k_guide_survival_wave" : "k_guide_survival";
     if (c && c->wave_guide && c->tile_svi && c->tile_ready) return "k_svi_tile";
+    if (c && c->wave_guide && c->wave2 && c->async_step) return "k_svi_async";
     if (c && c->wave_guide) return c->wave2 ? (c->fused_step ? "k_step_wave2" : "k_guide_wave2") : "k_guide_wave";
     return "k_lik";
 }
@@ -1940,7 +2095,7 @@ extern "C" const char* bean_hip_dominant_kernel_variant(const bean_hip_ctx* c) {
     const std::string base = bean_hip_dominant_kernel(c);
     if (d.family == kMultiMixture) name = base + "<" + acc + ", " + surv + ">";
     else if (base == "k_guide_wave2" || base == "k_guide_survival_wave" || base == "k_step_wave2" || base == "k_svi_tile" ||
-             base == "k_guide_wave")
+             base == "k_guide_wave" || base == "k_svi_async")
         name = base + "<" + (d.family == kMixture ? "2" : "0") + ", " + (d.family == kMixture ? acc : "false") + ">";
     else name = base;
     return name.c_str();
@@ -1987,6 +2142,17 @@ extern "C" int bean_hip_get_profile(bean_hip_ctx* c, double* avg_ms, uint64_t* l
     *launches = n;
     return 0;
 }
+
+#ifdef BEAN_ASYNC_STAMP
+// diagnostic builds only: the item timeline of the last k_svi_async call (bean_async_v2.hpp)
+extern "C" int64_t bean_hip_async_stamps(bean_hip_ctx* c, unsigned long long* host, uint64_t n_words) {
+    HIP_OK(hipDeviceSynchronize());
+    if (!c->async_stamps) return 0;
+    const uint64_t n = n_words < c->async_stamp_words ? n_words : c->async_stamp_words;
+    HIP_OK(hipMemcpy(host, c->async_stamps, n * 8, hipMemcpyDeviceToHost));
+    return (int64_t)c->async_stamp_words;
+}
+#endif
 
 #ifdef BEAN_STAMP
 // diagnostic builds only: copy the per-wave cycle stamps of the last k_lik launch to the host

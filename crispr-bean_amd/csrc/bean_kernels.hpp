@@ -476,15 +476,30 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float 
     p = fmaf(-k.step_size, q, p);      // p.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
-template <bool ADAM>
+// Accesses to state that ANOTHER wave of the same launch wrote at an earlier step or will read at a later one
+// (k_svi_async, bean_async_v2.hpp: one launch runs many steps, and the wave that finishes a tile differs from step
+// to step): COH == 2 makes them agent-scope (global_load / global_store ... sc1: the store is written through,
+// the load bypasses this CU's L1, which no other CU's store ever refreshes).  Any other mode: plain.
+template <int COH, typename T>
+__device__ __forceinline__ T coh_ld(const T* p) {
+    if (COH == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <int COH, typename T>
+__device__ __forceinline__ void coh_st(T* p, T v) {
+    if (COH == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <bool ADAM, int COH = 0>
 __device__ __forceinline__ void emit_grad(const DevArgs& c, int which, long idx, double grad, AdamCoef k) {
     const float gf = (float)grad;
     if (ADAM) {
-        float p = c.p[which][idx], m = c.m[which][idx], v = c.v[which][idx];
+        float p = coh_ld<COH>(c.p[which] + idx), m = coh_ld<COH>(c.m[which] + idx), v = coh_ld<COH>(c.v[which] + idx);
         adam_update(p, m, v, gf, k);
-        c.p[which][idx] = p;
-        c.m[which][idx] = m;
-        c.v[which][idx] = v;
+        coh_st<COH>(c.p[which] + idx, p);
+        coh_st<COH>(c.m[which] + idx, m);
+        coh_st<COH>(c.v[which] + idx, v);
     } else {
         c.g[which][idx] = gf;
     }
@@ -492,15 +507,15 @@ __device__ __forceinline__ void emit_grad(const DevArgs& c, int which, long idx,
 
 // Same with the parameter and its moments already in registers (loaded before the gradient sums,
 // so that no load sits behind them); the updated parameter stays in `p` for the next draw.
-template <bool ADAM>
+template <bool ADAM, int COH = 0>
 __device__ __forceinline__ void emit_grad_pre(const DevArgs& c, int which, long idx, double grad, AdamCoef k,
                                               float& p, float m, float v) {
     const float gf = (float)grad;
     if (ADAM) {
         adam_update(p, m, v, gf, k);
-        c.p[which][idx] = p;
-        c.m[which][idx] = m;
-        c.v[which][idx] = v;
+        coh_st<COH>(c.p[which] + idx, p);
+        coh_st<COH>(c.m[which] + idx, m);
+        coh_st<COH>(c.v[which] + idx, v);
     } else {
         c.g[which][idx] = gf;
     }
@@ -986,7 +1001,10 @@ __device__ __forceinline__ double noise_row_coherent(const DevArgs& c, int g) {
 // Guide part of k_param for the variant MixtureNormal families, one guide per lane: Dirichlet
 // normalisers, chain to alpha_pi, ClippedAdam, (+Acc: the noise site), and the lgamma / digamma table of
 // the updated concentrations.  Shared with the fused step kernel (COH: see row_ld); roundings pinned.
-template <bool FINISH, bool ADAM, bool PREP, bool COH>
+// COH: 0 = rows of the previous launch (plain loads); 1 = rows another wave of this launch has written (fused step
+// kernel: agent-scope loads); 2 = k_svi_async: as 1, and the guide's own state - alpha_pi, the noise site, their
+// moments, the tabulated digammas, the draw - is read and written at agent scope too (coh_ld / coh_st).
+template <bool FINISH, bool ADAM, bool PREP, int COH>
 __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoef ak, unsigned long long s_prep,
                                                 double& loss_fin) {
 #pragma clang fp contract(off)
@@ -994,17 +1012,17 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
     const bool fit_noise = acc_on && (c.flags & kFitNoise);
     float nl = 0.f, ns_u = 0.f;
     if (fit_noise) {
-        nl = c.p[5][g];
-        ns_u = c.p[6][g];
+        nl = coh_ld<COH>(c.p[5] + g);
+        ns_u = coh_ld<COH>(c.p[6] + g);
     }
     // alpha_pi: parameters and moments loaded once, with everything else the guide needs (k_param is a
     // chain of memory round trips); PREP takes the updated values from registers
-    float up[2] = {c.p[4][2 * g], c.p[4][2 * g + 1]}, um[2] = {0.f, 0.f}, uv[2] = {0.f, 0.f};
+    float up[2] = {coh_ld<COH>(c.p[4] + 2 * g), coh_ld<COH>(c.p[4] + 2 * g + 1)}, um[2] = {0.f, 0.f}, uv[2] = {0.f, 0.f};
     if (FINISH && ADAM) {
-        um[0] = c.m[4][2 * g];
-        um[1] = c.m[4][2 * g + 1];
-        uv[0] = c.v[4][2 * g];
-        uv[1] = c.v[4][2 * g + 1];
+        um[0] = coh_ld<COH>(c.m[4] + 2 * g);
+        um[1] = coh_ld<COH>(c.m[4] + 2 * g + 1);
+        uv[0] = coh_ld<COH>(c.v[4] + 2 * g);
+        uv[1] = coh_ld<COH>(c.v[4] + 2 * g + 1);
     }
     if (FINISH) {
         const float u0 = up[0], u1 = up[1];
@@ -1018,12 +1036,12 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
         if (c.dgq) {
             // the guide side (c_q) was tabulated by the previous PREP for this alpha_pi
             const long Gl = c.G;
-            lgS_q = c.dgq[g];
-            lg_q[0] = c.dgq[Gl + g];
-            lg_q[1] = c.dgq[2 * Gl + g];
-            dgS_q = c.dgq[3 * Gl + g];
-            dg_q[0] = c.dgq[4 * Gl + g];
-            dg_q[1] = c.dgq[5 * Gl + g];
+            lgS_q = coh_ld<COH>(c.dgq + g);
+            lg_q[0] = coh_ld<COH>(c.dgq + Gl + g);
+            lg_q[1] = coh_ld<COH>(c.dgq + 2 * Gl + g);
+            dgS_q = coh_ld<COH>(c.dgq + 3 * Gl + g);
+            dg_q[0] = coh_ld<COH>(c.dgq + 4 * Gl + g);
+            dg_q[1] = coh_ld<COH>(c.dgq + 5 * Gl + g);
             lgS_p = lgS_q, dgS_p = dgS_q, lg_p[0] = lg_q[0], lg_p[1] = lg_q[1], dg_p[0] = dg_q[0], dg_p[1] = dg_q[1];
             if (cl[0] || cl[1]) {  // model side (c_p, unclamped) differs
                 lgamma_digamma(cp[0] + cp[1], lgS_p, dgS_p);
@@ -1050,7 +1068,7 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
             const long RG = (long)c.R * c.G;
             const double* w = c.wrow + g;
             nrg = c.part[(long)kPNrg * c.G + g];  // data only (k_prepare)
-            if (COH) {
+            if (COH != 0) {
                 // atomic loads stay in program order and are waited for where they are used: load
                 // eight replicates' rows first, add afterwards (same order of additions)
                 for (int r0 = 0; r0 < c.R; r0 += 8) {
@@ -1124,11 +1142,11 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
         }
         loss_fin += -lp + lq;
         const double dot = (gc[0] * al0 + gc[1] * al1) / s;
-        emit_grad_pre<ADAM>(c, 4, 2 * g, pa0 / s * (gc[0] - dot) * al0, ak, up[0], um[0], uv[0]);
-        emit_grad_pre<ADAM>(c, 4, 2 * g + 1, pa0 / s * (gc[1] - dot) * al1, ak, up[1], um[1], uv[1]);
+        emit_grad_pre<ADAM, COH>(c, 4, 2 * g, pa0 / s * (gc[0] - dot) * al0, ak, up[0], um[0], uv[0]);
+        emit_grad_pre<ADAM, COH>(c, 4, 2 * g + 1, pa0 / s * (gc[1] - dot) * al1, ak, up[1], um[1], uv[1]);
         if (acc_on) {
-            const double lpn = c.lpn[g], eps = c.eps_noise[g];
-            const double gl = COH ? noise_row_coherent(c, g) : lik_row(c, kPGnoise, g);
+            const double lpn = coh_ld<COH>(c.lpn + g), eps = coh_ld<COH>(c.eps_noise + g);
+            const double gl = COH != 0 ? noise_row_coherent(c, g) : lik_row(c, kPGnoise, g);
             const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
             // Normal(0, 0.655) prior held in float32 by the reference (utils.py:158-161)
             const float nsf = 0.655f;
@@ -1138,11 +1156,11 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
             loss_fin += -logp + logq;
             if (fit_noise) {
                 const double Gl = gl + lpn / nvar;
-                emit_grad<ADAM>(c, 5, g, Gl, ak);
-                emit_grad<ADAM>(c, 6, g, Gl * eps * ns - 1.0, ak);
+                emit_grad<ADAM, COH>(c, 5, g, Gl, ak);
+                emit_grad<ADAM, COH>(c, 6, g, Gl * eps * ns - 1.0, ak);
                 if (ADAM) {
-                    nl = c.p[5][g];
-                    ns_u = c.p[6][g];
+                    nl = coh_ld<COH>(c.p[5] + g);
+                    ns_u = coh_ld<COH>(c.p[6] + g);
                 }
             }
         }
@@ -1156,8 +1174,8 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
                                          s_prep * 4ull).x;
         }
         const double ns = fit_noise ? exp((double)ns_u) : kPiNoiseSd;
-        c.eps_noise[g] = eps;
-        c.lpn[g] = (fit_noise ? (double)nl : 0.0) + eps * ns;
+        coh_st<COH>(c.eps_noise + g, eps);
+        coh_st<COH>(c.lpn + g, (fit_noise ? (double)nl : 0.0) + eps * ns);
         if (c.eps_noise_out) c.eps_noise_out[g] = eps;
     }
     if (PREP && c.dgq) {
@@ -1172,12 +1190,12 @@ __device__ __forceinline__ void param_guide_mix(const DevArgs& c, int g, AdamCoe
         lgamma_digamma(q0, lg0, dg0);
         lgamma_digamma(q1, lg1, dg1);
         const long Gl = c.G;
-        c.dgq[g] = lgS;
-        c.dgq[Gl + g] = lg0;
-        c.dgq[2 * Gl + g] = lg1;
-        c.dgq[3 * Gl + g] = dgS;
-        c.dgq[4 * Gl + g] = dg0;
-        c.dgq[5 * Gl + g] = dg1;
+        coh_st<COH>(c.dgq + g, lgS);
+        coh_st<COH>(c.dgq + Gl + g, lg0);
+        coh_st<COH>(c.dgq + 2 * Gl + g, lg1);
+        coh_st<COH>(c.dgq + 3 * Gl + g, dgS);
+        coh_st<COH>(c.dgq + 4 * Gl + g, dg0);
+        coh_st<COH>(c.dgq + 5 * Gl + g, dg1);
     }
 }
 
@@ -3795,6 +3813,7 @@ __global__ __launch_bounds__(256) void k_test_special(int op, long n, const doub
 }  // namespace bean
 
 #include "bean_guide_v2.hpp"
+#include "bean_async_v2.hpp"  // all the steps of a call in one launch, tile-asynchronous
 #ifdef BEAN_AB_KERNELS  // opt-in steppers, both bit-identical to the default path and measured slower
 #include "bean_step_v2.hpp"
 #endif

@@ -445,18 +445,6 @@ void k_svi_tile(DevArgs c, const DevArgs* cp, const int* __restrict__ tile_g0, c
     }
 }
 
-// DevArgs as the kernel received them -> their copy in global memory (stream-ordered, no host staging)
-__global__ __launch_bounds__(64) void k_put_args(DevArgs c, DevArgs* out) {
-    const unsigned int* src = (const unsigned int*)&c;
-    unsigned int* dst = (unsigned int*)out;
-    for (unsigned i = threadIdx.x; i < sizeof(DevArgs) / 4; i += 64) dst[i] = src[i];
-}
-
-// ClippedAdam step sizes of the n updates that follow update `step0` (update t = step + 1), one thread
-// each, with the device's exp / pow (adam_coef) so that every path holds the same float32 value
-__global__ __launch_bounds__(256) void k_step_sizes(DevArgs c, unsigned long long step0, int n, float* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = adam_coef(c, step0 + (unsigned long long)i + 1).step_size;
-}
+// (k_put_args, k_step_sizes: bean_async_v2.hpp)
 
 }  // namespace bean

@@ -1,0 +1,136 @@
+"""All the steps of a call in one launch, tile-asynchronous (k_svi_async, csrc/bean_async_v2.hpp; BEAN_HIP_STEP=async /
+=pair) against the two launches per step (k_guide_wave2 + k_param): same draws, same per-pair arithmetic, same summation
+orders - the fitted parameters must be bit-identical, for every window length, across resumed windows, for shards
+with offsets, and whatever the number of resident waves; the loss history agrees to the 2^-40 granule of its fixed-point
+parts (the prior / entropy terms of a tile's targets are rounded to that granule per finishing wave, per block of
+k_param on the pair path) and is itself reproducible run to run.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import bean_amd  # noqa: F401
+from bean_amd.preprocessing.synthetic import make_sorting_variant_screen
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _fit(monkeypatch, mode, family, data, steps, eng_kw, chunks=None, resume=False, blocks=None):
+    from bean_amd import engine
+
+    monkeypatch.setenv("BEAN_HIP_STEP", mode)
+    if blocks is not None:
+        monkeypatch.setenv("BEAN_HIP_ASYNC_BLOCKS", str(blocks))
+    else:
+        monkeypatch.delenv("BEAN_HIP_ASYNC_BLOCKS", raising=False)
+    eng = engine.HipSVI(family, data.to(DEV), num_steps=steps, **eng_kw)
+    assert eng.dominant_kernel == ("k_guide_wave2" if mode == "pair" else "k_svi_async")
+    for n in (chunks or [steps]):
+        eng.run(n, seed=5, resume=resume)
+    torch.cuda.synchronize()
+    out = {k: v.detach().cpu().clone() for k, v in eng.unconstrained.items()}
+    loss = np.array(eng.losses())
+    eng.close()
+    return out, loss
+
+
+def _same(monkeypatch, family, data, steps, eng_kw=None, chunks=None, resume=False, blocks=None):
+    a, la = _fit(monkeypatch, "pair", family, data, steps, eng_kw or {}, chunks, resume)
+    b, lb = _fit(monkeypatch, "async", family, data, steps, eng_kw or {}, chunks, resume, blocks)
+    assert np.all(np.isfinite(la)) and len(la) == steps == len(lb)
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, (a[k] - b[k]).abs().max().item())
+    assert np.max(np.abs(la - lb) / np.abs(la)) < 1e-12
+
+
+@pytest.mark.parametrize("n_guides,n_reps,gpt", [(64, 1, 1), (200, 2, 3), (333, 1, 5), (461, 3, 7), (130, 5, 1),
+                                                 (1300, 9, 5), (6400, 3, 64), (3000, 4, 33), (4097, 2, 5)])
+def test_async_is_bitwise_the_pair_path(monkeypatch, n_guides, n_reps, gpt):
+    data = make_sorting_variant_screen(n_guides, n_reps, seed=300 + n_guides, guides_per_target=gpt,
+                                       mask_fraction=0.05 if (n_guides > 100 and n_reps > 1) else 0.0)
+    _same(monkeypatch, "MixtureNormal", data, 37)
+
+
+@pytest.mark.parametrize("steps,chunks,resume", [(1, None, False), (2, None, False), (3, None, True), (150, None, False),
+                                                 (131, [1, 2, 64, 64], True), (131, [1, 2, 64, 64], False),
+                                                 (300, [100, 100, 100], True)])
+def test_async_step_counts_and_windows(monkeypatch, steps, chunks, resume):
+    data = make_sorting_variant_screen(2500, 3, seed=77, guides_per_target=5)
+    _same(monkeypatch, "MixtureNormal", data, steps, chunks=chunks, resume=resume)
+
+
+def test_async_families(monkeypatch):
+    data = make_sorting_variant_screen(1800, 3, seed=78, with_accessibility=True, mask_fraction=0.05)
+    _same(monkeypatch, "MixtureNormal", data, 40, dict(scale_by_accessibility=True))
+    _same(monkeypatch, "MixtureNormal", data, 40, dict(scale_by_accessibility=True, fit_noise=False))
+    _same(monkeypatch, "Normal", data, 40)
+    _same(monkeypatch, "Normal", data, 40, dict(use_bcmatch=False))
+    T = data.n_targets
+    g = torch.Generator().manual_seed(0)
+    prior = {
+        "mu_loc": torch.randn((T, 1), generator=g, dtype=torch.float64) * 0.2,
+        "mu_scale": torch.rand((T, 1), generator=g, dtype=torch.float64) + 0.5,
+        "sd_loc": torch.randn((T, 1), generator=g, dtype=torch.float64) * 0.1,
+        "sd_scale": torch.rand((T, 1), generator=g, dtype=torch.float64) * 0.05 + 0.01,
+    }
+    _same(monkeypatch, "MixtureNormal", data, 40, dict(prior_params=prior))
+
+
+@pytest.mark.parametrize("blocks", [8, 64, 1000])
+def test_async_does_not_depend_on_the_number_of_resident_waves(monkeypatch, blocks):
+    """Fewer workgroups than one step has items: every wave works through several items per step and the polls
+    really wait.  Same bits."""
+    data = make_sorting_variant_screen(9000, 4, seed=81, guides_per_target=5, mask_fraction=0.03)
+    _same(monkeypatch, "MixtureNormal", data, 60, blocks=blocks)
+
+
+def test_async_metric_shape_long(monkeypatch):
+    """The metric shape over a few hundred steps: the hand-overs under full load (every wave slot of the chip in use,
+    finishing waves of one step beside the guide waves of the next, rewritten tables read across XCDs)."""
+    data = make_sorting_variant_screen(50000, 5, seed=79)
+    _same(monkeypatch, "MixtureNormal", data, 400, chunks=[100, 100, 100, 100], resume=True)
+
+
+def test_async_shard_with_an_offset(monkeypatch):
+    """A shard that does not start at a multiple of 64 guides (tiles follow the global guide index)."""
+    from bean_amd import engine, parallel
+
+    data = make_sorting_variant_screen(20000, 3, seed=82, guides_per_target=5)
+    shards = parallel.plan_shards(data.target_lengths.numpy(), 3)
+    assert any(sh[0] % 64 for sh in shards)
+    outs = {}
+    for mode in ("pair", "async"):
+        monkeypatch.setenv("BEAN_HIP_STEP", mode)
+        res = []
+        for sh in shards:
+            eng = engine.HipSVI("MixtureNormal", parallel.shard_screen(data, sh).to(DEV), guide_offset=sh[0],
+                                target_offset=sh[2], n_guides_total=data.n_guides, num_steps=50)
+            assert eng.dominant_kernel == ("k_guide_wave2" if mode == "pair" else "k_svi_async")
+            eng.run(50, seed=9)
+            torch.cuda.synchronize()
+            res.append(({k2: v.detach().cpu().clone() for k2, v in eng.unconstrained.items()}, np.array(eng.losses())))
+            eng.close()
+        outs[mode] = res
+    for (pa, la), (pb, lb) in zip(outs["pair"], outs["async"]):
+        for k in pa:
+            assert torch.equal(pa[k], pb[k]), k
+        assert np.max(np.abs(la - lb) / np.abs(la)) < 1e-12
+
+
+def test_async_loss_history_is_reproducible(monkeypatch):
+    data = make_sorting_variant_screen(12000, 3, seed=83, guides_per_target=5)
+    _, l1 = _fit(monkeypatch, "async", "MixtureNormal", data, 80, {})
+    _, l2 = _fit(monkeypatch, "async", "MixtureNormal", data, 80, {}, blocks=512)
+    assert np.array_equal(l1, l2)
+
+
+def test_targets_longer_than_a_tile_take_the_pair_path(monkeypatch):
+    from bean_amd import engine
+
+    monkeypatch.setenv("BEAN_HIP_STEP", "async")
+    data = make_sorting_variant_screen(6500, 2, seed=80, guides_per_target=65)
+    eng = engine.HipSVI("MixtureNormal", data.to(DEV), num_steps=10)
+    assert eng.dominant_kernel == "k_guide_wave2"
+    eng.run(5)
+    assert np.all(np.isfinite(eng.losses()))
+    eng.close()

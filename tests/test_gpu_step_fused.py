@@ -17,7 +17,7 @@ def _fit(monkeypatch, mode, family, data, steps, eng_kw, chunks=None):
     from bean_amd import engine
 
     if mode == "pair":  # the product library
-        monkeypatch.delenv("BEAN_HIP_STEP", raising=False)
+        monkeypatch.setenv("BEAN_HIP_STEP", "pair")  # (large screens default to k_svi_async)
         eng = engine.HipSVI(family, data.to(DEV), num_steps=steps, **eng_kw)
     else:  # the opt-in kernel lives in the A/B library (libbean_hip_ab.so)
         monkeypatch.setenv("BEAN_HIP_STEP", "fused")

@@ -23,7 +23,7 @@ def _engine(family, data, pair, **kw):
 
     old = os.environ.get("BEAN_HIP_STEP")
     if pair:
-        os.environ.pop("BEAN_HIP_STEP", None)
+        os.environ["BEAN_HIP_STEP"] = "pair"
     else:
         os.environ["BEAN_HIP_STEP"] = "tile"
     try:  # the tile kernel lives in the A/B library; the reference path is the product library
