@@ -16,14 +16,19 @@
 // and of the two neighbours it may share a target with, and for nothing else: one tile's finish chain runs while other
 // tiles' waves keep the SIMDs busy, and a step never drains.
 //
+// (Measured and not adopted: pulling a wave's NEXT item at the head of the current one, to hide the queue atomic's
+// round trip - an item that is claimed but not started delays its tile, and every tile's delay is the next step's wait:
+// 49.8 -> 61.0 us per step at 50k guides, 83.6 -> 92.6 at 100k.  Inlining the two pieces at two waves per SIMD
+// (237 VGPRs, no calls, no scratch): 51.5 -> 53.0.)
+//
 // Order and progress.  The queue is one counter per XCD group (blockIdx & 7, a label: the blocks that share a label
 // share an L2; nothing depends on it but speed), items in (step, tile, replicate) order; tile k belongs to group
 // k & 7, so whatever a tile reads and writes over the steps stays in one L2 except the targets it shares with its
 // neighbours.  An item depends only on items of the PREVIOUS step, and a group hands out all items of step s before any
 // of step s + 1: a wave that polls waits for waves that hold earlier items and do not wait for it - no cycle, whatever
 // the residency.  Every poll is bounded (kAsyncSpinMax) and watches an abort word; a wave that gives up sets it, every
-// wave then leaves at its next poll or pull, the grid drains, and k_async_tail turns the call's loss slots into NaN
-// (the host halts a fit on a non-finite loss window).
+// wave then leaves at its next poll or pull, the grid drains, and the call's loss slots report NaN (the host halts a
+// fit on a non-finite loss window).
 //
 // Visibility (MI355X_MICROARCH.md, "inter-workgroup visibility"; the forms measured valid there).  Per-XCD L2s are not
 // coherent with each other and a CU's L1 is never refreshed by another CU's stores.  Everything one wave writes and
@@ -62,6 +67,9 @@ namespace bean {
 // (tile, replicate) per step upwards.  Below that a step is one tile's dependency chain either way and k_param's
 // chip-wide launch is the shorter chain.
 constexpr long kAsyncMinItems = 3300;
+// ... and up to 24 000 items (~300k guides at R = 5): beyond, both forms sit on the same issue bound in long windows and a
+// short call pays the pipeline's ramp (500k guides, one 20-step call: 456 against 407 us per step).
+constexpr long kAsyncMaxItems = 24000;
 // Resident waves per SIMD.  Fewer waves than the chip holds is FASTER while a step has few items per wave: a wave's
 // guide work is a latency chain (20 us alone, 34 us with three neighbours on its SIMD), a tile's next step waits for the
 // slowest of its R waves plus the finish, and with ~2 items per wave and step every wave always finds an item whose
@@ -109,14 +117,22 @@ __global__ __launch_bounds__(256) void k_step_sizes(DevArgs c, unsigned long lon
     if (i < n) out[i] = adam_coef(c, step0 + (unsigned long long)i + 1).step_size;
 }
 
-// After the call: the step counters as n {guide, k_param} pairs would have left them (so that the pair path, the
-// loss finalize and a later resume continue from here), and NaN in the call's loss slots if the launch gave up.
-__global__ __launch_bounds__(64) void k_async_tail(DevArgs c, AsyncArgs a) {
-    const bool aborted = *a.abort_flag != 0;
-    if (aborted)
-        for (int i = threadIdx.x; i < a.n_steps; i += 64)
-            atomicAdd((unsigned long long*)(c.loss_acc + ((long)(a.slot0 + i) * kLossSub) * kLossWords) + 2, 1ull);
-    if (threadIdx.x != 0) return;
+// Everything the launch needs, in ONE small launch in front of it: the queue counters, the abort word, the
+// completed-step words and the arrival counters at zero (the latter return to zero by themselves unless an earlier
+// launch gave up), the ClippedAdam step sizes of the call's updates (the device's exp / pow, adam_coef: every path holds
+// the same float32 values), DevArgs as this kernel received them copied to global memory for the out-of-line pieces, and
+// the step counters as n {guide, k_param} pairs would LEAVE them - k_svi_async does not read them; the pair path, the loss
+// finalize and a later resume continue from there.
+__global__ __launch_bounds__(256) void k_async_head(DevArgs c, AsyncArgs a, DevArgs* args_out, int* ws, int ws_ints,
+                                                    float* step_sizes) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ws_ints; i += 256) ws[i] = 0;
+    for (int i = tid; i < c.n_arrival_ctr; i += 256) c.tile_ctr[i] = 0;
+    for (int i = tid; i < a.n_steps; i += 256) step_sizes[i] = adam_coef(c, a.step0 + (unsigned long long)i + 1).step_size;
+    const unsigned int* src = (const unsigned int*)&c;
+    unsigned int* dst = (unsigned int*)args_out;
+    for (unsigned i = tid; i < sizeof(DevArgs) / 4; i += 256) dst[i] = src[i];
+    if (tid != 0) return;
     StepCtr last, next;
     last.step = a.step0 + a.n_steps - 1;
     last.slot = a.slot0 + a.n_steps - 1;
@@ -128,6 +144,15 @@ __global__ __launch_bounds__(64) void k_async_tail(DevArgs c, AsyncArgs a) {
     next.pad_ = 0.f;
     *c.ctrA = last;
     *c.ctrB = next;
+}
+
+// A wave whose poll ran out: every wave leaves at its next poll or pull, and the call's loss slots report NaN
+// (the host halts a fit on a non-finite loss window).
+__device__ __forceinline__ void async_give_up(const DevArgs* cp, const AsyncArgs& a) {
+    __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long long* acc = cp->loss_acc;
+    for (int i = 0; i < a.n_steps; ++i)
+        atomicAdd((unsigned long long*)(acc + ((long)(a.slot0 + i) * kLossSub) * kLossWords) + 2, 1ull);
 }
 
 // Finish tile `tile` of the step `ctr` describes: k_param's work for the tile's targets and guides (FINISH of this
@@ -473,7 +498,7 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
                 if (__any(ab != 0)) return;
                 if (__all(v >= s)) break;
                 if (++spins > kAsyncSpinMax) {
-                    if (lane == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) async_give_up(cp, a);
                     return;
                 }
                 __builtin_amdgcn_s_sleep(BEAN_ASYNC_SLEEP);

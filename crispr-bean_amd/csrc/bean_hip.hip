@@ -474,7 +474,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         // sorting families of k_guide_wave2 whose parameters are all per target or per guide, no target longer than a
         // tile.  BEAN_HIP_STEP=async switches it on, =pair off.
         const char* sm = getenv("BEAN_HIP_STEP");
-        const bool on = sm ? !strcmp(sm, "async") : (long)d.n_tiles * s->n_reps >= kAsyncMinItems;
+        const long items = (long)d.n_tiles * s->n_reps;
+        const bool on = sm ? !strcmp(sm, "async") : (items >= kAsyncMinItems && items <= kAsyncMaxItems);
         c->async_step = on && c->wave2 && !d.wide_targets && s->max_target_len <= 64 && s->n_sample_covariates == 0 &&
                         !c->fused_step && !c->tile_svi &&
                         (s->family == BEAN_FAMILY_MIXTURE_NORMAL || s->family == BEAN_FAMILY_NORMAL) && !is_survival(*s);
@@ -1527,15 +1528,8 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
     }
     const size_t ws_ints = (size_t)9 * kAsyncQueueStride + (size_t)d.n_tiles;
     if (!c->async_ws) HIP_OK(hipMalloc((void**)&c->async_ws, ws_ints * sizeof(int)));
-    // queue counters, abort word and completed-step words start every call at zero; so do the arrival counters
-    // (they return to zero by themselves unless an earlier launch gave up)
-    HIP_OK(hipMemsetAsync(c->async_ws, 0, ws_ints * sizeof(int), stream));
-    HIP_OK(hipMemsetAsync(d.tile_ctr, 0, (size_t)d.n_arrival_ctr * sizeof(int), stream));
-    hipLaunchKernelGGL(k_step_sizes, dim3((unsigned)((n_steps + 255) / 256)), dim3(256), 0, stream, d,
-                       (unsigned long long)step0, (int)n_steps, c->step_sizes);
     // the out-of-line pieces of the kernel read DevArgs from a copy in global memory (the same bytes: c->d as it is now)
     if (!c->dargs_dev) HIP_OK(hipMalloc((void**)&c->dargs_dev, sizeof(DevArgs)));
-    hipLaunchKernelGGL(k_put_args, dim3(1), dim3(64), 0, stream, d, c->dargs_dev);
     AsyncArgs a;
     a.step0 = step0;
     a.slot0 = slot0;
@@ -1545,6 +1539,8 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
     a.done = c->async_ws + 9 * kAsyncQueueStride;
     a.step_sizes = c->step_sizes;
     a.stamps = nullptr;
+    // queue, abort and completed-step words to zero, step sizes, the DevArgs copy, the step counters the call leaves
+    hipLaunchKernelGGL(k_async_head, dim3(1), dim3(256), 0, stream, d, a, c->dargs_dev, c->async_ws, (int)ws_ints, c->step_sizes);
 #ifdef BEAN_ASYNC_STAMP
     {
         static unsigned long long* g_stamps = nullptr;
@@ -1563,9 +1559,7 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
     } else {
         rc = launch_svi_async_t<kNormal, false>(c, stream, a);
     }
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_async_tail, dim3(1), dim3(64), 0, stream, d, a);
-    return 0;
+    return rc;
 }
 
 extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_step, uint64_t n_steps,
