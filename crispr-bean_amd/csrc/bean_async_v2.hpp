@@ -19,7 +19,11 @@
 // (Measured and not adopted: pulling a wave's NEXT item at the head of the current one, to hide the queue atomic's
 // round trip - an item that is claimed but not started delays its tile, and every tile's delay is the next step's wait:
 // 49.8 -> 61.0 us per step at 50k guides, 83.6 -> 92.6 at 100k.  Inlining the two pieces at two waves per SIMD
-// (237 VGPRs, no calls, no scratch): 51.5 -> 53.0.)
+// (237 VGPRs, no calls, no scratch): 51.5 -> 53.0.  A work-conserving queue - one ring per group that holds READY items
+// in the order they became ready, filled by the finish that completes a tile's three dependencies, so that no wave holds
+// an item that cannot start: same bits, and 51.0 us at two waves per SIMD where this form takes 50.6, 65 / 64 at three /
+// four against 59.6 / 67.7.  Head-of-line blocking is not what more resident waves lose to; a wave's own chain growing
+// with its SIMD's load is, and a tile waits for the slowest of its R waves.)
 //
 // Order and progress.  The queue is one counter per XCD group (blockIdx & 7, a label: the blocks that share a label
 // share an L2; nothing depends on it but speed), items in (step, tile, replicate) order; tile k belongs to group
