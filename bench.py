@@ -192,8 +192,11 @@ def valu_issue_roofline(config, kernel_name, kernel_ms):
     lines = open(cfile).read().splitlines()
     for i, ln in enumerate(lines):
         if ln.startswith("bean::" + kernel_name + "<") or ln.startswith("bean::" + kernel_name + " "):
-            for l2 in lines[i + 1:i + 12]:
-                m = re.match(r"\s+SQ_INSTS_VALU\s+n=\s*\d+\s+mean=([0-9.e+]+)", l2)
+            # (k_svi_async: one launch = a whole report window; the summary also gives the counter per SVI step)
+            pat = (r"\s+SQ_INSTS_VALU / step\s+n=\s*\d+\s+mean=([0-9.e+]+)" if kernel_name == "k_svi_async"
+                   else r"\s+SQ_INSTS_VALU\s+n=\s*\d+\s+mean=([0-9.e+]+)")
+            for l2 in lines[i + 1:i + 24]:
+                m = re.match(pat, l2)
                 if m:
                     insts = float(m.group(1))
                     break

@@ -23,7 +23,16 @@
 // in the order they became ready, filled by the finish that completes a tile's three dependencies, so that no wave holds
 // an item that cannot start: same bits, and 51.0 us at two waves per SIMD where this form takes 50.6, 65 / 64 at three /
 // four against 59.6 / 67.7.  Head-of-line blocking is not what more resident waves lose to; a wave's own chain growing
-// with its SIMD's load is, and a tile waits for the slowest of its R waves.)
+// with its SIMD's load is, and a tile waits for the slowest of its R waves.  In the finish: the boundary counters, the R
+// waves' loss parts (one word per lane) and the guides' state requested in one batch at the top and the guides' part
+// moved in front of the targets' - 18.8 -> 21.2 us per finish (more values live across the chain, 36 B more scratch).)
+//
+// Where a wave's time goes at the metric shape, two waves per SIMD (scripts/async_timeline.py, a -DBEAN_ASYNC_STAMP
+// build; medians): an item waits 1.2 us for its dependencies (the poll's own round trip), computes for 19.1 us (a lone
+// wave's chain: the SIMD's second wave fills 65 % of its issue slots), drains its stores and arrives in 1.4 us; one
+// item in five then finishes its tile in 18.8 us - the call and the boundary counters 3.6, sums / ClippedAdam / draw
+// 4.7, Phi tables 2.8, the guides' alpha_pi and digamma tables 5.0, loss parts + store drain + publish 2.8.  A wave is
+// busy for 90 - 93 % of a step.
 //
 // Order and progress.  The queue is one counter per XCD group (blockIdx & 7, a label: the blocks that share a label
 // share an L2; nothing depends on it but speed), items in (step, tile, replicate) order; tile k belongs to group
@@ -96,6 +105,7 @@ struct AsyncArgs {
 // diagnostic builds: the items of local steps [kAsyncStampStep0, + kAsyncStampSteps) of a call leave their timeline
 // (real-time clock, 100 MHz): pulled, dependencies seen, guide work done, arrived, finished / published
 constexpr int kAsyncStampStep0 = 40, kAsyncStampSteps = 4;
+constexpr long kAsyncStampFinOff = 1l << 22;  // words between an item's row and its finish-phase row (host: 2 x 2^22 words)
 #ifdef BEAN_ASYNC_STAMP
 #define BEAN_ASYNC_T(k)                                                                              \
     if (st_row) {                                                                                    \
@@ -103,8 +113,20 @@ constexpr int kAsyncStampStep0 = 40, kAsyncStampSteps = 4;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u_)::"memory");               \
         if (lane == 0) st_row[k] = u_;                                                               \
     }
+// (finish phases: a second table behind the items', one row per item too)
+#define BEAN_ASYNC_TF(k)                                                                             \
+    if (st_row) {                                                                                    \
+        unsigned long long u_;                                                                       \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u_)::"memory");               \
+        if (lane == 0) st_row[kAsyncStampFinOff + (k)] = u_;                                         \
+    }
+#define BEAN_ASYNC_ST_ARG , unsigned long long* st_row
+#define BEAN_ASYNC_ST_PASS , st_row
 #else
 #define BEAN_ASYNC_T(k)
+#define BEAN_ASYNC_TF(k)
+#define BEAN_ASYNC_ST_ARG
+#define BEAN_ASYNC_ST_PASS
 #endif
 
 // DevArgs as the kernel received them -> their copy in global memory (stream-ordered, no host staging)
@@ -168,7 +190,7 @@ __device__ __forceinline__ void async_give_up(const DevArgs* cp, const AsyncArgs
 // polynomials first - above the loop and spills them (measured: 249 spilled VGPRs, 576 B of scratch per lane).
 template <int FAM, bool ACC>
 __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned long long step, unsigned long long slot,
-                                               float step_size, int tile, int t0, int nt) {
+                                               float step_size, int tile, int t0, int nt BEAN_ASYNC_ST_ARG) {
     const DevArgs c = dev_args_in_sgprs(cp);
     step = rfl_u64(step);
     slot = rfl_u64(slot);
@@ -214,6 +236,7 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
     }
     own_left = __builtin_amdgcn_readfirstlane(own_left);
     own_right = __builtin_amdgcn_readfirstlane(own_right);
+    BEAN_ASYNC_TF(0);
     const int ta = own_left ? t0 : t0 + 1, tb = own_right ? t1 : t1 - 1;  // this wave's targets, ta > tb: none
     // Which wave finishes a straddling target depends on timing, so the prior / entropy terms are not added up as
     // doubles per wave: every TERM goes into the loss's fixed-point form by itself (fixed_add's split) and the wave
@@ -315,6 +338,7 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
         }
     }
     __syncthreads();
+    BEAN_ASYNC_TF(1);
     // ---- phase C: the Phi tables of the new draws (one lane per distinct finite bin edge, then one per (target, bin))
     {
 #pragma clang fp contract(off)
@@ -360,6 +384,7 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
             __syncthreads();
         }
     }
+    BEAN_ASYNC_TF(2);
     // ---- the tile's guides: alpha_pi (and the accessibility noise site), tables for the next step
     if (MIX) {
         const int g = tile * 64 + lane - c.g_sh;
@@ -369,6 +394,7 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
             loss_term(lg);
         }
     }
+    BEAN_ASYNC_TF(3);
     // ---- loss: the R waves' parts of this tile + this wave's prior / entropy terms, integer atomics
     loss_hi = wave_sum_i64(loss_hi);
     loss_lo = wave_sum_i64(loss_lo);
@@ -408,7 +434,7 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
 // {t0, number of the tile's targets} when this wave completed the tile (it then finishes it), {-1, 0} otherwise.
 template <int FAM, bool ACC>
 __device__ BEAN_ASYNC_INLINE int2 async_guide_item(const DevArgs* cp, unsigned long long step, unsigned long long slot,
-                                              float step_size, int tile, int r) {
+                                              float step_size, int tile, int r BEAN_ASYNC_ST_ARG) {
     const DevArgs c = dev_args_in_sgprs(cp);
     tile = rfl_i(tile);
     r = rfl_i(r);
@@ -422,6 +448,7 @@ __device__ BEAN_ASYNC_INLINE int2 async_guide_item(const DevArgs* cp, unsigned l
     int t0, nt;
     double tot;
     guide_wave2_tile<FAM, ACC, 2>(c, ctr, tile, r, wg, t0, nt, tot);
+    BEAN_ASYNC_T(4);
     if (lane == 0) {
         long long w0 = 0, w1 = 0, w2 = 1;
         if (fabs(tot) < kLossPartMax) {
@@ -512,12 +539,12 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
         BEAN_ASYNC_T(1);
         const unsigned long long step = a.step0 + (unsigned long long)s, slot = a.slot0 + (unsigned long long)s;
         const float step_size = a.step_sizes[s];
-        const int2 fin = async_guide_item<FAM, ACC>(cp, step, slot, step_size, tile, r);
+        const int2 fin = async_guide_item<FAM, ACC>(cp, step, slot, step_size, tile, r BEAN_ASYNC_ST_PASS);
         BEAN_ASYNC_T(2);
         if (fin.x >= 0) {
             // (the tile's next step waits for this chain: it goes first on its SIMD)
             if (BEAN_ASYNC_PRIO) __builtin_amdgcn_s_setprio(3);
-            async_finish_tile<FAM, ACC>(cp, step, slot, step_size, tile, fin.x, fin.y);
+            async_finish_tile<FAM, ACC>(cp, step, slot, step_size, tile, fin.x, fin.y BEAN_ASYNC_ST_PASS);
             if (BEAN_ASYNC_PRIO) __builtin_amdgcn_s_setprio(0);
             // ---- publish: every store of the finish has completed before the tile's step count moves
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

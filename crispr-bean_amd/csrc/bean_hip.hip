@@ -1544,7 +1544,9 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
 #ifdef BEAN_ASYNC_STAMP
     {
         static unsigned long long* g_stamps = nullptr;
-        const size_t words = (size_t)kAsyncStampSteps * ((d.n_tiles + 7) / 8 * 8) * d.R * 8;
+        const size_t words = (size_t)2 * kAsyncStampFinOff;  // item rows, then finish-phase rows
+        if ((size_t)kAsyncStampSteps * ((d.n_tiles + 7) / 8 * 8) * d.R * 8 > (size_t)kAsyncStampFinOff)
+            return fail("BEAN_ASYNC_STAMP: screen too large for the stamp buffer");
         if (!g_stamps) HIP_OK(hipMalloc((void**)&g_stamps, words * 8));
         HIP_OK(hipMemsetAsync(g_stamps, 0, words * 8, stream));
         a.stamps = g_stamps;

@@ -32,10 +32,12 @@ fn.restype = ctypes.c_int64
 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
 n_tiles = (G + 63) // 64
 all_items = (n_tiles + 7) // 8 * 8 * R
-buf = np.zeros(4 * all_items * 8, dtype=np.uint64)
+FIN_OFF = 1 << 22
+buf = np.zeros(2 * FIN_OFF, dtype=np.uint64)
 n = fn(eng._h, buf.ctypes.data, buf.size)
 assert n == buf.size, (n, buf.size)
-st = buf.reshape(4, all_items, 8).astype(np.int64)
+st = buf[:4 * all_items * 8].reshape(4, all_items, 8).astype(np.int64)
+stf = buf[FIN_OFF:FIN_OFF + 4 * all_items * 8].reshape(4, all_items, 8).astype(np.int64)
 ok = st[:, :, 0] > 0
 t0 = st[:, :, 0][ok].min()
 us = lambda x: (x - t0) / 100.0  # noqa: E731
@@ -51,6 +53,12 @@ for s in range(4):
         "wait_for_deps_us": q((ready - pull) / 100.0),
         "guide_plus_arrival_us": q((done - ready) / 100.0),
         "finish_us": q((fin[isfin] - done[isfin]) / 100.0),
+        "guide_math_us": q((st[s, :, 4][m] - ready) / 100.0),
+        "arrival_us (stores drained + counter)": q((done - st[s, :, 4][m]) / 100.0),
+        "finish_phases_us (call+boundary counters | sums, Adam, draw | Phi tables | guides | loss + drain + publish)": [
+            q((stf[s, :, 0][m][isfin] - done[isfin]) / 100.0), q((stf[s, :, 1][m][isfin] - stf[s, :, 0][m][isfin]) / 100.0),
+            q((stf[s, :, 2][m][isfin] - stf[s, :, 1][m][isfin]) / 100.0), q((stf[s, :, 3][m][isfin] - stf[s, :, 2][m][isfin]) / 100.0),
+            q((fin[isfin] - stf[s, :, 3][m][isfin]) / 100.0)],
         "published_at_us": q(us(fin[isfin])),
     }
 # per wave (block id): busy fraction between its first pull of step 0 and its last event of step 3

@@ -65,6 +65,9 @@ def resources(k):
 
 lines, traffic, calib = [], {}, {}
 dominant = None
+# k_svi_async runs ALL the steps of a call in one launch: scripts/profile_async.sh makes every launch of a pass the
+# same length and names it here, so that counters are also given per SVI step (what bench.py's roofline prices)
+ASYNC_STEPS = int(os.environ.get("ASYNC_STEPS_PER_LAUNCH", "0"))
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     for f in newest(os.path.join(root, sub, "**", "*counter_collection.csv")):
         agg = defaultdict(lambda: defaultdict(list))
@@ -81,7 +84,13 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
             lines.append(f"{k}  [{resources(k) or 'code object: n/a'}; wg {meta[k][5]} grid {meta[k][6]}]")
             for c, v in sorted(cs.items()):
                 lines.append(f"    {c:24s} n={len(v):5d} mean={sum(v) / len(v):.6g}")
-                if "k_guide" in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
+                if "k_svi_async" in k and ASYNC_STEPS:
+                    lines.append(f"    {c + ' / step':24s} n={len(v):5d} mean={sum(v) / len(v) / ASYNC_STEPS:.6g}"
+                                 f"   (launches of {ASYNC_STEPS} steps)")
+                    if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                        traffic[c] = sum(v) / len(v) / ASYNC_STEPS
+                        dominant = k + f" (per SVI step: launches of {ASYNC_STEPS} steps)"
+                elif "k_guide" in k and c in ("FETCH_SIZE", "WRITE_SIZE") and not (dominant and "k_svi_async" in dominant):
                     traffic[c] = sum(v) / len(v)
                     dominant = k
                 if "k_prepare" in k and c == "FETCH_SIZE":
