@@ -274,7 +274,7 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         return fail("bean_hip_create: R, G, T must be >= 1");
     if (s->n_condits < 1 || s->n_condits > kBCap)
         return fail("bean_hip_create: n_condits must be in [1, " + std::to_string(kBCap) +
-                    "] (libbean_hip.so holds 8 conditions, libbean_hip_a16.so 32)");
+                    "] (libbean_hip.so holds 8 conditions, libbean_hip_a16.so 64)");
     if (s->family == BEAN_FAMILY_MIXTURE_NORMAL && s->n_max_alleles != 2)
         return fail("bean_hip_create: MixtureNormal requires n_max_alleles == 2");
     if (is_tiling(*s)) {
@@ -810,6 +810,10 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
                 fn = d.survival ? (acc ? (const void*)k_guide_tiling_wave<true, true> : (const void*)k_guide_tiling_wave<false, true>)
                                 : (acc ? (const void*)k_guide_tiling_wave<true, false> : (const void*)k_guide_tiling_wave<false, false>);
         }
+        if (lds > kLdsPerWorkgroupMax)
+            return fail("bean_hip_prepare: " + std::to_string(d.B) + " conditions x " + std::to_string(d.tile_targets) +
+                        " targets per 64-guide tile need " + std::to_string(lds) + " bytes of LDS per workgroup; a compute unit has " +
+                        std::to_string(kLdsPerWorkgroupMax));
         if (fn && lds > 65536) HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
 #ifdef BEAN_AB_KERNELS

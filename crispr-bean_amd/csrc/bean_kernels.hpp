@@ -247,8 +247,10 @@ constexpr int kWaveMisc = 6;  // k_guide_wave: per-guide values staged in LDS (c
 constexpr int kBMax = BEAN_BMAX;  // conditions whose counts a wave loads in one register batch: 8 in libbean_hip.so, 16 in libbean_hip_a16.so
 // n_condits <= kBCap (bean_hip_create).  The default build stays at its batch (the fast path); the 16-condition
 // build stages further conditions one by one (every per-condition value is a thread-private LDS column and the
-// loops over conditions are rolled), up to what 64 KB of LDS per wave hold.
-constexpr int kBCap = BEAN_BMAX <= 8 ? 8 : 32;
+// loops over conditions are rolled), up to 64 conditions - or what a workgroup's 160 KB of LDS hold (the launch asks
+// for the attribute beyond 64 KB; bean_hip_prepare refuses a shape that needs more than the CU has).
+constexpr int kBCap = BEAN_BMAX <= 8 ? 8 : 64;
+constexpr size_t kLdsPerWorkgroupMax = 160 * 1024;
 enum TPart { kTGnoise = 0, kTNrg = 1, kTPath = 2, kTL = 2 + kAMax, kTGmu = 2 + 2 * kAMax,
              kTGsig = 2 + 2 * kAMax + (kAMax - 1), kTNumPart = 2 + 2 * kAMax + 2 * (kAMax - 1) };
 

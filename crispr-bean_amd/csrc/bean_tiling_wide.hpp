@@ -22,8 +22,19 @@
 
 namespace bean {
 
-constexpr int kWideSlots = 4;                 // alleles per lane
-constexpr int kWideMaxA = 64 * kWideSlots;    // 256 alleles per guide
+// alleles per lane: 4 in libbean_hip.so (256 alleles per guide), 8 in the builds that also hold more conditions
+// (libbean_hip_a16.so / _a32.so: 512 alleles per guide - the engine loads them for tables beyond 256; the per-lane arrays
+// double, and with them the spills: a table of that width is far outside what `bean filter` leaves, it has to run, not to
+// run fast)
+#if BEAN_AMAX > 8
+constexpr int kWideSlots = 8;
+#else
+constexpr int kWideSlots = 4;
+#endif
+constexpr int kWideMaxA = 64 * kWideSlots;
+// the draws of allele a of (replicate, guide) i are stream i * stride + a: 256 for every table this path ran before the
+// wider build existed (the streams of those screens do not change, whichever build serves them), 1024 beyond
+__host__ __device__ inline unsigned long long wide_stream_stride(int A) { return A <= 256 ? 256ull : 1024ull; }
 __host__ __device__ inline int tq_path(int A) { (void)A; return 2; }
 __host__ __device__ inline int tq_L(int A) { return 2 + A; }
 __host__ __device__ inline int tq_gmu(int A) { return 2 + 2 * A; }
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(64) void k_guide_tiling_wide(DevArgs c) {
                 if (a < A) pi[j] = c.pi_in[((long)r * G + g) * A + a];
                 if (a2 < A) pi[j + 1] = c.pi_in[((long)r * G + g) * A + a2];
             } else if (a < A) {
-                Rng rng(c.seed, kSitePi, ((unsigned long long)r * c.G_tot + guide_stream_id(c, g)) * kWideMaxA + a,
+                Rng rng(c.seed, kSitePi, ((unsigned long long)r * c.G_tot + guide_stream_id(c, g)) * wide_stream_stride(A) + a,
                         ctr.step * 256ull);
                 // (a draw whose boost factor has already put it below DBL_MIN skips the rejection loop: with both
                 // slots of the pair masked - concentrations of ~1e-6 - that is most waves; same values after the floor)

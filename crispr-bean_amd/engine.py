@@ -80,7 +80,7 @@ class HipSVI:
         # decides then
         amax = 8
         n_al = int(getattr(data, "n_max_alleles", 2)) if family == "MultiMixtureNormal" else 2
-        if (8 < n_al <= 16) or data.n_condits > 8:
+        if (8 < n_al <= 16) or data.n_condits > 8 or n_al > 256:  # (> 256: the wider allele-parallel kernels)
             amax = 16
         if 16 < n_al <= 32:
             amax = 32

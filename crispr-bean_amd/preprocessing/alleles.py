@@ -15,9 +15,10 @@ Two deliberate differences, both stated to the user when they apply:
   reproducible run to run; any numbering is equivalent up to a permutation of the rows of the
   result table);
 * alleles per guide: up to 32 (the unedited one included) run in the register-resident kernels
-  (``libbean_hip.so`` holds 8, ``libbean_hip_a16.so`` 16, ``libbean_hip_a32.so`` 32), up to ``MAX_ALLELES`` = 256 in the
-  allele-parallel kernels (``csrc/bean_tiling_wide.hpp``), so unfiltered tables fit as they are (the
-  reference's own ``tests/data/tiling_mini_screen.h5ad`` has 230).  Beyond 256 the build stops with an
+  (``libbean_hip.so`` holds 8, ``libbean_hip_a16.so`` 16, ``libbean_hip_a32.so`` 32), up to ``MAX_ALLELES`` = 512 in the
+  allele-parallel kernels (``csrc/bean_tiling_wide.hpp``: 256 in the default build, 512 in the 16-allele build, which the
+  engine loads for the wider tables), so unfiltered tables fit as they are (the
+  reference's own ``tests/data/tiling_mini_screen.h5ad`` has 230).  Beyond 512 the build stops with an
   error that names ``bean filter``; ``BEAN_MAX_ALLELES_PER_GUIDE=N`` opts in to keeping each guide's
   ``N - 1`` most abundant alleles instead (the reads of the dropped ones fall into the unedited allele
   exactly as they do for alleles ``bean filter`` removes, ``data_class.py:773-777``) - a different model
@@ -34,7 +35,7 @@ import numpy as np
 import pandas as pd
 import torch
 
-MAX_ALLELES = 256  # csrc/bean_tiling_wide.hpp: kWideMaxA
+MAX_ALLELES = 512  # csrc/bean_tiling_wide.hpp: kWideMaxA of the wider builds (libbean_hip.so itself holds 256)
 _REV = {"A": "T", "C": "G", "T": "A", "G": "C", "-": "-"}
 _NT_EDIT = re.compile(r"(((chr)?\w+|nan):)?-?\d+:-?\d+:[+-]:[A-Z*-]>[A-Z*-]")
 _NT_EDIT_UID = re.compile(r"[\w*]!-?\d+:-?\d+:[+-]:[A-Z*-]>[A-Z*-]")

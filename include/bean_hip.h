@@ -73,7 +73,7 @@ typedef struct bean_hip_shape {
     int32_t flags;         /* OR of enum bean_hip_flags */
     int32_t n_reps;        /* R */
     int32_t n_condits;     /* B: sort bins incl. the control pseudo-bin, or timepoints (<= 8 in libbean_hip.so,
-                              <= 32 in libbean_hip_a16.so) */
+                              <= 64 in libbean_hip_a16.so / _a32.so) */
     int32_t n_guides;      /* G */
     int32_t n_targets;     /* T (variant); = n_edits for tiling: the per-target parameters are per edit */
     int32_t n_max_alleles; /* A (2 in variant mode) */

@@ -217,7 +217,7 @@ def test_ragged_shapes(engine, n_guides, n_reps):
     _compare(engine, "MixtureNormal", data, {})
 
 
-@pytest.mark.parametrize("n_bins", [1, 2, 3, 5, 7, 8, 11, 15, 19, 31])  # > 7 bins (+ bulk): the 16-condition build, which stages conditions 17 ... 32 one by one
+@pytest.mark.parametrize("n_bins", [1, 2, 3, 5, 7, 8, 11, 15, 19, 31, 39, 63])  # > 7 bins (+ bulk): the 16-condition build, which stages conditions 17 ... 64 one by one
 def test_bin_counts(engine, n_bins):
     edges = np.linspace(0, 1, n_bins + 1)
     bins = tuple((float(edges[i]), float(edges[i + 1])) for i in range(n_bins))
@@ -489,6 +489,8 @@ def _compare_tiling(engine, data, kw, seed=7, step=2):
           bins=tuple((i / 20, (i + 1) / 20) for i in range(20))), {}),  # 20 bins + bulk (> 16 conditions)
     (dict(n_guides=70, n_reps=2, n_max_alleles=6, with_accessibility=True,
           bins=tuple((i / 31, (i + 1) / 31) for i in range(31))), dict(scale_by_accessibility=True)),  # 32 conditions, > 64 KB LDS
+    (dict(n_guides=70, n_reps=2, n_max_alleles=5,
+          bins=tuple((i / 39, (i + 1) / 39) for i in range(39))), {}),  # 40 conditions (the reference has no bound)
 ])
 def test_tiling_elbo_and_gradients_match_oracle(engine, gen_kw, kw):
     data = make_sorting_tiling_screen(seed=4, **gen_kw)
@@ -541,6 +543,10 @@ def test_tiling_screen_built_from_h5ad_matches_oracle(engine):
      "k_guide_tiling_wide"),
     (dict(n_guides=40, n_reps=2, n_max_alleles=100), {}, "k_guide_tiling_wide"),  # two alleles per lane
     (dict(n_guides=60, n_reps=3, n_max_alleles=33, mask_fraction=0.05), {}, "k_guide_tiling_wide"),
+    # more than 256 alleles per guide: eight alleles per lane, the 16-allele build's copy of the kernels
+    (dict(n_guides=24, n_reps=2, n_max_alleles=300), {}, "k_guide_tiling_wide"),
+    (dict(n_guides=20, n_reps=2, n_max_alleles=512, with_accessibility=True), dict(scale_by_accessibility=True),
+     "k_guide_tiling_wide"),
 ])
 def test_wide_tiling_matches_oracle(engine, gen_kw, kw, kernel):
     """More alleles per guide than the default builds hold (8, 16), against the same oracle."""
@@ -678,6 +684,7 @@ def _compare_survival(engine, family, data, kw, seed=7, step=2):
     (dict(n_guides=65, n_reps=1, times=(0.0, 2.0, 4.0, 6.0, 8.0, 10.0, 12.0, 14.0)), {}),
     (dict(n_guides=120, n_reps=2, times=tuple(float(t) for t in range(0, 22, 2))), {}),  # 11 timepoints
     (dict(n_guides=90, n_reps=2, times=tuple(float(t) for t in range(0, 23))), {}),  # 23 timepoints (> 16)
+    (dict(n_guides=90, n_reps=2, times=tuple(0.5 * t for t in range(0, 40))), {}),  # 40 timepoints (> 32)
     # 37 guides x 4 replicates = 148 rows per target: k_param's 4 lanes per target loop over them ten times
     (dict(n_guides=2600, n_reps=4, guides_per_target=37), {}),
 ])
