@@ -449,10 +449,11 @@ class Leg:
         if self.exchanged:
             x = self.eng.exchange_buffers()
             self.exchange = "per step: " + ", ".join(f"all-reduce {k} ({v.numel()} f64)" for k, v in x.items())
-            # default: the Python stepping loop + torch.distributed.all_reduce; BEAN_HIP_NATIVE_COMM=1: the library
-            # steps with its own RCCL communicator (kernels + ncclAllReduce enqueued natively)
+            # default: the library steps with its own RCCL communicator (kernels + ncclAllReduce enqueued natively) once
+            # the communicator has passed its check; otherwise, or with BEAN_HIP_NATIVE_COMM=0: the Python stepping loop +
+            # torch.distributed.all_reduce
             native = False
-            if parallel.native_comm_enabled():  # opt-in, BEAN_HIP_NATIVE_COMM=1 (parallel.py)
+            if parallel.native_comm_enabled():
                 try:
                     native = self.eng.init_native_comm()
                 except Exception as exc:  # noqa: BLE001  (never lose the run over the faster path)

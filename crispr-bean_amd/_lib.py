@@ -96,6 +96,7 @@ SYMBOLS = [
     ("bean_hip_sharded_update", c_int32, [c_void_p, c_int32, c_void_p]),
     ("bean_hip_comm_unique_id", c_int32, [c_char_p, c_void_p]),
     ("bean_hip_comm_init", c_int32, [c_void_p, c_char_p, c_void_p, c_int32, c_int32]),
+    ("bean_hip_comm_all_reduce", c_int32, [c_void_p, c_void_p, c_uint64, c_void_p]),
     ("bean_hip_comm_destroy", c_int32, [c_void_p]),
     ("bean_hip_svi_run_exchanged", c_int32, [c_void_p, c_uint64, c_uint64, c_uint64, c_int32, c_void_p]),
     ("bean_hip_step_bytes", c_uint64, [c_void_p]),

@@ -1948,6 +1948,13 @@ extern "C" int bean_hip_comm_init(bean_hip_ctx* c, const char* rccl_path, const 
     return 0;
 }
 
+extern "C" int bean_hip_comm_all_reduce(bean_hip_ctx* c, double* buf, uint64_t n, void* stream_) {
+    if (!c || !buf) return fail("bean_hip_comm_all_reduce: null argument");
+    if (!c->comm) return fail("bean_hip_comm_all_reduce: no communicator (bean_hip_comm_init)");
+    RCCL_OK(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, c->comm, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" int bean_hip_comm_destroy(bean_hip_ctx* c) {
     if (!c || !c->comm) return 0;
     drop_graph(c);

@@ -488,6 +488,23 @@ class HipSVI:
             if st == 0:
                 self.lib.bean_hip_comm_destroy(self._h)
             return False
+        # ... and a fit depends on the communicator only after it has summed a known vector right: rank k contributes
+        # (k + 1) * (1, 2, ..., n) - every entry of the sum is an exact integer in float64 - through the very call the
+        # stepping loop issues (ncclAllReduce, sum, float64, in place, the engine's stream), over a length that takes
+        # RCCL through its multi-channel path as the per-edit gradients of a tiling fit do; the ranks agree on the
+        # outcome, and on any doubt all of them keep the Python stepping loop
+        n = 4099
+        probe = torch.arange(1, n + 1, dtype=torch.float64, device=self.device) * (rank + 1)
+        with self._on_stream():
+            rc = self.lib.bean_hip_comm_all_reduce(self._h, ctypes.c_void_p(probe.data_ptr()), n, self._sptr())
+        self.stream.synchronize()
+        want = torch.arange(1, n + 1, dtype=torch.float64, device=self.device) * (world * (world + 1) // 2)
+        good = rc == 0 and bool(torch.equal(probe, want))
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            self.lib.bean_hip_comm_destroy(self._h)
+            return False
         self._native_comm = True
         return True
 

@@ -157,11 +157,17 @@ REPLICATED = ("mu_cov_loc", "mu_cov_scale")  # shared by every guide: identical 
 
 
 def native_comm_enabled() -> bool:
-    """``BEAN_HIP_NATIVE_COMM=1``: exchange families of a guide-sharded fit step through the library-owned
-    RCCL communicator (``HipSVI.init_native_comm``).  Off by default until a multi-GPU run has exercised it."""
+    """Exchange families of a guide-sharded fit step through the library-owned RCCL communicator
+    (``HipSVI.init_native_comm``) - no host in the per-step loop, the collectives on the engine's own stream
+    (``torch.distributed`` runs its collectives on a stream of its own: the two cross-stream hand-overs per step
+    idle the device ~10 us each, ``profiles/r05_exchange_kernel_timeline.txt``).  Default since round 5: the
+    communicator is CHECKED when it is made - every rank loads RCCL before anyone enters ``ncclCommInitRank``, the
+    ranks agree on the outcome, and a known vector must come back summed exactly through the very call the stepping
+    loop issues - and any doubt leaves every rank on the Python stepping loop.  ``BEAN_HIP_NATIVE_COMM=0`` forces
+    that loop."""
     import os
 
-    return os.environ.get("BEAN_HIP_NATIVE_COMM", "0") == "1"
+    return os.environ.get("BEAN_HIP_NATIVE_COMM", "1") != "0"
 
 
 def run_sharded(
@@ -208,10 +214,9 @@ def run_sharded(
     eng = engine_factory(shard_screen(data, mine), mine, data.n_guides, **extra)
     exchanged = bool(eng.exchange_buffers()) if hasattr(eng, "exchange_buffers") else False
     if exchanged and grp.on and hasattr(eng, "init_native_comm") and native_comm_enabled():
-        # opt-in (BEAN_HIP_NATIVE_COMM=1): the library steps with its own RCCL communicator, no host in
-        # the per-step loop.  Default: the Python stepping loop + torch.distributed.all_reduce, which two
-        # and more ranks have exercised (gloo here, nccl on the driver's nodes); the native path has run
-        # with ONE rank on hardware so far (tests/test_gpu_nccl.py)
+        # the library steps with its own RCCL communicator, no host in the per-step loop - once the communicator has
+        # passed its check (init_native_comm: False, and the Python stepping loop + torch.distributed.all_reduce
+        # stays, on a non-nccl backend, if RCCL refuses, or if the probe sum comes back wrong on any rank)
         eng.init_native_comm(group)
     done = 0
     while done < num_steps:

@@ -299,12 +299,16 @@ int bean_hip_sharded_update(bean_hip_ctx* ctx, int32_t last, void* stream);
  *
  *   bean_hip_comm_unique_id   rank 0 only: fills id[128] (ncclGetUniqueId); the caller broadcasts it
  *   bean_hip_comm_init        every rank, collectively (ncclCommInitRank on the current device)
+ *   bean_hip_comm_all_reduce  one ncclAllReduce(sum, float64, in place) of `n` doubles on that communicator and `stream`:
+ *                             what bean_hip_svi_run_exchanged issues between its kernels, callable by itself so that a
+ *                             caller can CHECK a fresh communicator against a known sum before a fit depends on it
  *   bean_hip_comm_destroy     ncclCommDestroy
  * Returns 0, or -1 with bean_hip_last_error() (RCCL missing, refused, ...): callers then keep stepping
  * with bean_hip_sharded_* and their own all-reduce. */
 #define BEAN_HIP_COMM_ID_BYTES 128
 int bean_hip_comm_unique_id(const char* rccl_path, uint8_t* id);
 int bean_hip_comm_init(bean_hip_ctx* ctx, const char* rccl_path, const uint8_t* id, int32_t rank, int32_t world);
+int bean_hip_comm_all_reduce(bean_hip_ctx* ctx, double* buf, uint64_t n, void* stream);
 int bean_hip_comm_destroy(bean_hip_ctx* ctx);
 int bean_hip_svi_run_exchanged(bean_hip_ctx* ctx, uint64_t seed, uint64_t first_step, uint64_t n_steps,
                                int32_t graph_chunk, void* stream);
