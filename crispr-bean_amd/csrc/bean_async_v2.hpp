@@ -25,7 +25,10 @@
 // four against 59.6 / 67.7.  Head-of-line blocking is not what more resident waves lose to; a wave's own chain growing
 // with its SIMD's load is, and a tile waits for the slowest of its R waves.  In the finish: the boundary counters, the R
 // waves' loss parts (one word per lane) and the guides' state requested in one batch at the top and the guides' part
-// moved in front of the targets' - 18.8 -> 21.2 us per finish (more values live across the chain, 36 B more scratch).)
+// moved in front of the targets' - 18.8 -> 21.2 us per finish (more values live across the chain, 36 B more scratch).
+// A 256-register build for the two-waves-per-SIMD grids whose bin loop takes two bins per pass (four lgamma / digamma
+// chains side by side instead of two; same bits): 50.4 - 51.5 us against 50.7 - two chains already issue a float64
+// instruction every ~5.5 cycles, the pipe's rate for one wave.)
 //
 // Where a wave's time goes at the metric shape, two waves per SIMD (scripts/async_timeline.py, a -DBEAN_ASYNC_STAMP
 // build; medians): an item waits 1.2 us for its dependencies (the poll's own round trip), computes for 19.1 us (a lone
