@@ -25,6 +25,14 @@ HIPCC_FLAGS = [
     "-shared",
     "-fPIC",
     "-munsafe-fp-atomics",
+    # MachineLICM hoists the materialisation of 64-bit constants (two v_mov_b32 per float64 literal: a third of every
+    # polynomial here) and other loop-invariant values out of the kernels' loops and keeps them in VGPRs across the whole
+    # loop body: k_svi_async's item loop with its pieces inlined went to 448 B of scratch per lane (16 B without the
+    # pass), and every guide kernel carries 6 - 22 more VGPRs with it.  Same arithmetic, same bits; measured on one box,
+    # with / without the pass: metric 55.8 / 55.1 us per step on the two launches, 50.6 / 48.3 asynchronous, tiling
+    # 153.5 / 151.9, tiling +Acc 171.5 / 168.4, survival 83.6 / 83.7.
+    "-mllvm",
+    "-disable-machine-licm",
 ]
 
 

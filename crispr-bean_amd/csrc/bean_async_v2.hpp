@@ -61,8 +61,12 @@
 
 #include "bean_devargs_sgpr.hpp"
 
+// The two pieces of an item are inlined into the item loop.  That needs the build's -mllvm -disable-machine-licm
+// (_lib.HIPCC_FLAGS): with the pass, the loop keeps every hoisted constant live across both pieces (448 B of scratch per
+// lane at 128 VGPRs), and out-of-line pieces (-DBEAN_ASYNC_INLINE=__noinline__, how this kernel was first built) save and
+// restore ~60 callee-saved registers per call - 82 of the 122 MB the launch then moved per step were that.
 #ifndef BEAN_ASYNC_INLINE
-#define BEAN_ASYNC_INLINE __noinline__
+#define BEAN_ASYNC_INLINE __forceinline__
 #endif
 #ifndef BEAN_ASYNC_PRIO
 #define BEAN_ASYNC_PRIO 1
@@ -77,12 +81,12 @@
 namespace bean {
 
 // When it is the default (BEAN_HIP_STEP=async forces it for any eligible screen, =pair switches it off), measured on
-// MI355X against the two launches per step (scripts/time_async.py, R = 5; us per step, async at its best grid / pair):
-// 25k guides 41.0 / 37.1, 37.5k 49.0 / 46.7, 50k 49.8 / 55.6, 62.5k 62.7 / 66.1, 75k 71.7 / 75.2, 87.5k 77.0 / 86.3,
-// 100k 83.6 / 96.5, 125k 101.8 / 113.7, 150k 120.6 / 132.2, 250k 190.9 / 204.5, 500k 387 / 384: from ~3 300 items
-// (tile, replicate) per step upwards.  Below that a step is one tile's dependency chain either way and k_param's
-// chip-wide launch is the shorter chain.
-constexpr long kAsyncMinItems = 3300;
+// MI355X against the two launches per step (scripts/time_async.py, R = 5; us per step, async at its best grid / pair;
+// the build without MachineLICM): 25k guides 39.9 / 37.2, 37.5k 44.3 / 46.4, 50k 48.3 / 55.1, 62.5k 60.7 / 66.1,
+// 75k 64.1 / 75.2, 100k 78.7 / 95.8, 150k 110 / 132, 250k 191 / 204 (first build), 500k 387 / 384 (first build): from
+// ~2 800 items (tile, replicate) per step upwards.  Below that a step is one tile's dependency chain either way and
+// k_param's chip-wide launch is the shorter chain.
+constexpr long kAsyncMinItems = 2800;
 // ... and up to 24 000 items (~300k guides at R = 5): beyond, both forms sit on the same issue bound in long windows and a
 // short call pays the pipeline's ramp (500k guides, one 20-step call: 456 against 407 us per step).
 constexpr long kAsyncMaxItems = 24000;
@@ -90,7 +94,8 @@ constexpr long kAsyncMaxItems = 24000;
 // guide work is a latency chain (20 us alone, 34 us with three neighbours on its SIMD), a tile's next step waits for the
 // slowest of its R waves plus the finish, and with ~2 items per wave and step every wave always finds an item whose
 // dependencies are met (measured wait: 0.8 us median at two waves per SIMD, 25 us at four - scripts/async_timeline.py).
-// 50k guides: 2 / 3 / 4 waves per SIMD 49.8 / 59.6 / 67.7 us per step; 100k: 99.8 / 83.6 / 93.9; 150k: - / 123.2 / 120.6.
+// 50k guides: 2 / 3 / 4 waves per SIMD 48.3 / 54.9 / 60.2 us per step; 75k: 72.9 / 64.1 / 70.3; 100k: 97.2 / 78.7 / 86.3;
+// 150k: 144 / 118 / 110.
 // Grids that do not give every SIMD the same number of waves lose 10 - 20 % (2304 blocks: 60.4 us at 50k guides).
 __host__ __device__ inline int async_waves_per_simd(long items) { return items <= 5400 ? 2 : (items <= 11000 ? 3 : 4); }
 constexpr int kAsyncQueueStride = 32;      // ints between two groups' queue counters (separate 128-byte lines)
@@ -188,9 +193,9 @@ __device__ __forceinline__ void async_give_up(const DevArgs* cp, const AsyncArgs
 // step, PREP of the next), by the wave that arrived last.  The structure and the arithmetic are k_step_wave2's
 // (bean_step_v2.hpp; its comments explain the lane maps); what differs is that every access to state that lives
 // across steps is agent-scope, because the wave that finishes this tile's NEXT step runs on another CU.
-// Out of line, DevArgs from their copy in global memory into SGPRs (bean_devargs_sgpr.hpp): inlined into the item loop
-// the compiler hoists every loop-invariant value of the pair math and of this chain - the 64-bit constants of the
-// polynomials first - above the loop and spills them (measured: 249 spilled VGPRs, 576 B of scratch per lane).
+// DevArgs come from their copy in global memory into SGPRs (bean_devargs_sgpr.hpp), read again for every item: nothing
+// derived from them is loop-invariant to the compiler (with MachineLICM on and DevArgs as a kernel argument, the
+// inlined loop spilled 249 VGPRs: 576 B of scratch per lane).
 template <int FAM, bool ACC>
 __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned long long step, unsigned long long slot,
                                                float step_size, int tile, int t0, int nt BEAN_ASYNC_ST_ARG) {
