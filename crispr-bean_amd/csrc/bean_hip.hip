@@ -906,12 +906,7 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
         c->ev.push_back(e0);
         c->ev.push_back(e1);
     }
-    // Tiling: PREP ends with the allele-level tables of the draw it has just made (k_allele; until round 5 the head of
-    // the guide launch).  In the steady-state step of the register-resident form the guides' roles of k_param move into
-    // that launch (k_allele_guides): k_param runs its edit blocks alone.  BEAN_HIP_TILING_SPLIT=0: one k_param, then k_allele.
-    static const bool split_off = getenv("BEAN_HIP_TILING_SPLIT") && !strcmp(getenv("BEAN_HIP_TILING_SPLIT"), "0");
-    const bool split = FINISH && ADAM && PREP && kind == 3 && !split_off && !(c->profile && c->profile_param) && d.n_live_slots > 0;
-    const dim3 grid(split ? ntb : nb), block(kParamBlock);
+    const dim3 grid(nb), block(kParamBlock);
 #define BEAN_LAUNCH_PARAM(K)                                                                                    \
     do {                                                                                                         \
         if (prof) hipExtLaunchKernelGGL((k_param<FINISH, ADAM, PREP, K>), grid, block, 0, stream, e0, e1, 0, d, ntb); \
@@ -924,12 +919,6 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
         default: BEAN_LAUNCH_PARAM(0); break;
     }
 #undef BEAN_LAUNCH_PARAM
-    if (PREP && d.family == kMultiMixture) {
-        const long n = d.n_live_slots;
-        const unsigned nab = (unsigned)((n + 255) / 256);
-        if (split) hipLaunchKernelGGL(k_allele_guides, dim3((unsigned)(nb - ntb) + nab), dim3(kParamBlock), 0, stream, d, ntb, nb - ntb);
-        else if (n > 0) hipLaunchKernelGGL(k_allele, dim3(nab), dim3(256), 0, stream, d);
-    }
 }
 
 #ifdef BEAN_AB_KERNELS  // block forms and the split form: A/B references
@@ -1235,7 +1224,10 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         launch_guide_survival_wave(c, stream);
         return;
     }
-    // (tiling: the allele-level tables of this step's draw were filled behind the k_param that drew it: launch_param)
+    if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
+        const long n = d.n_live_slots;
+        if (n > 0) hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
+    }
     if (c->tiling_rep) {
         launch_guide_tiling_rep(c, stream);
         return;

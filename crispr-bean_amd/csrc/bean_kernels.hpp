@@ -1297,10 +1297,8 @@ __device__ __forceinline__ void q0_draws_and_totals(const DevArgs& c, int gb, in
 // drops the other families' code: 121 -> <= 96 VGPRs without scratch (five instead of four resident
 // waves per SIMD, so the 1 026 blocks of a 62.5k-guide shard are one round, not one round and two blocks)
 // and less than half the instructions to fetch.  KIND 0: everything.
-// (the body of k_param as a function of the block's index `blk`: k_allele_guides below runs the guide roles of the
-// tiling families from a launch of its own)
 template <bool FINISH, bool ADAM, bool PREP, int KIND = 0>
-__device__ __forceinline__ void param_block(const DevArgs& c, const int n_target_blocks, const unsigned blk) {
+__global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_blocks) {
     if (KIND == 1) {
         __builtin_assume(c.lpt == kLanesPerTarget);
         __builtin_assume(!c.survival);
@@ -1350,12 +1348,12 @@ __device__ __forceinline__ void param_block(const DevArgs& c, const int n_target
     // (As a tail of the guide blocks - this round's first form - the draws began when the alpha_pi update
     // ended: k_param 33 us.  As blocks of their own that waited for a guide block's flag: 35 us.  Without a
     // q0 site the order of guide and target blocks makes no difference: measured on configs 1 and 3.)
-    unsigned bid = blk;
+    unsigned bid = blockIdx.x;
     if (c.q0_blocks) {
         const unsigned ntb = (unsigned)n_target_blocks, nq0 = (unsigned)c.n_gamma_blocks, ngd = (unsigned)c.q0_blk0;
-        if (blk < nq0) bid = ntb + ngd + blk;
-        else if (blk < nq0 + ngd) bid = ntb + (blk - nq0);
-        else bid = blk - nq0 - ngd;
+        if (blockIdx.x < nq0) bid = ntb + ngd + blockIdx.x;
+        else if (blockIdx.x < nq0 + ngd) bid = ntb + (blockIdx.x - nq0);
+        else bid = blockIdx.x - nq0 - ngd;
     }
     __shared__ double scratch[16];
     __shared__ double hand[4][kTargetsPerBlockMax];  // phase hand-over: gmu, gy (A -> B), mu, y (B -> C)
@@ -1783,11 +1781,6 @@ __device__ __forceinline__ void param_block(const DevArgs& c, const int n_target
         nxt.pad_ = 0.f;
         *c.ctrB = nxt;
     }
-}
-
-template <bool FINISH, bool ADAM, bool PREP, int KIND = 0>
-__global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_blocks) {
-    param_block<FINISH, ADAM, PREP, KIND>(c, n_target_blocks, blockIdx.x);
 }
 
 #ifndef BEAN_WAVE_EU
@@ -2835,24 +2828,6 @@ __device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int
 // the launch ran every wave for half the lanes.
 __global__ __launch_bounds__(256) void k_allele(DevArgs c) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= c.n_live_slots) return;
-    const int s = c.live_slots[idx];  // a1 * G + g
-    allele_slot_tables(c, s / c.G, s % c.G);
-}
-
-// Tiling, the steady-state step (round 5): the guides' part of k_param<FINISH, ADAM, PREP> - alpha_pi, the digamma tables,
-// the noise site; eight lanes per guide - does not depend on the per-edit update, and the allele tables of the next
-// step's draw do not depend on the guides.  With the guide roles in k_param its 2 032 blocks (469 edit blocks + 1 563
-// guide blocks at config 3) ran as two rounds of latency chains in front of a k_allele launch of 753 light blocks; here
-// k_param runs its edit blocks alone and THIS launch holds the guide roles (first: the longer chain) and the allele
-// tables.  The same code on the same operands (param_block, allele_slot_tables): the same bits.
-__global__ __launch_bounds__(kParamBlock) void k_allele_guides(DevArgs c, int n_target_blocks, int n_guide_blocks) {
-    static_assert(kParamBlock == 256, "k_allele's block size");
-    if ((int)blockIdx.x < n_guide_blocks) {
-        param_block<true, true, true, 3>(c, n_target_blocks, (unsigned)n_target_blocks + blockIdx.x);
-        return;
-    }
-    const long idx = (long)(blockIdx.x - n_guide_blocks) * blockDim.x + threadIdx.x;
     if (idx >= c.n_live_slots) return;
     const int s = c.live_slots[idx];  // a1 * G + g
     allele_slot_tables(c, s / c.G, s % c.G);
