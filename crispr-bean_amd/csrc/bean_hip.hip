@@ -1466,8 +1466,11 @@ static int launch_svi_tile(bean_hip_ctx* c, hipStream_t stream, uint64_t step0, 
 #endif  // BEAN_AB_KERNELS
 
 // ---- all the steps of a call in one launch: bean_async_v2.hpp
-static bool async_candidate(const bean_hip_ctx* c) {
+// (n_steps: the call's; a group's queue counter is an int)
+static bool async_candidate(const bean_hip_ctx* c, uint64_t n_steps) {
     const DevArgs& d = c->d;
+    const uint64_t per_group = (uint64_t)((d.n_tiles + 7) / 8) * (uint64_t)d.R;
+    if (n_steps == 0 || per_group * n_steps > 2000000000ull) return false;
     return c->async_step && !c->profile_param && !d.eps_mu_in && !d.eps_sd_in && !d.pi_in && !d.eps_noise_in &&
            !d.eps_mu_out && !d.eps_sd_out && !d.eps_noise_out && !(d.flags & kDumpPi) && d.lpart && d.tile_ctr &&
            (d.family != kMixture || d.dgq);
@@ -1639,7 +1642,7 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
 #else
     (void)tile;
 #endif
-    if (async_candidate(c) && stream != nullptr && n_steps < (1ull << 30)) {
+    if (async_candidate(c, n_steps) && stream != nullptr) {
         // one launch for the call: it also draws step first_step + n_steps, which nobody reads
         launch_set_step(c, stream, first_step, first_step, n_steps);
         launch_param<false, false, true>(c, stream);  // draws and tables of the first step
@@ -1747,7 +1750,7 @@ extern "C" int bean_hip_svi_resume(bean_hip_ctx* c, uint64_t seed, uint64_t firs
                          c->resume_stream == stream_;
     c->resume_ok = false;
     c->d.seed = seed;
-    if (async_candidate(c) && n_steps < (1ull << 30)) {
+    if (async_candidate(c, n_steps)) {
         // the whole window in one launch (bean_async_v2.hpp); windows chain exactly as the pairs do
         if (!resumed) {
             launch_set_step(c, stream, first_step, first_step, n_steps);
