@@ -11,8 +11,8 @@
 //
 // Here nothing waits for the chip.  Single-wave workgroups stay resident and PULL work items (step, tile, replicate)
 // from a queue; an item is k_guide_wave2's wave work (guide_wave2_tile, the same code, the same bits); the wave that
-// completes a tile last finishes it - k_step_wave2's hand-over and k_param's per-target / per-guide code - and then
-// publishes "tile k has completed step s".  An item of step s + 1 waits (a bounded poll) for that word of its own tile
+// completes a tile last finishes it (or, with finisher roles, hands the finish to a wave that does nothing else: below)
+// - k_step_wave2's hand-over and k_param's per-target / per-guide code - and then publishes "tile k has completed step s".  An item of step s + 1 waits (a bounded poll) for that word of its own tile
 // and of the two neighbours it may share a target with, and for nothing else: one tile's finish chain runs while other
 // tiles' waves keep the SIMDs busy, and a step never drains.
 //
@@ -98,7 +98,21 @@ constexpr long kAsyncMaxItems = 24000;
 // 150k: 144 / 118 / 110.
 // Grids that do not give every SIMD the same number of waves lose 10 - 20 % (2304 blocks: 60.4 us at 50k guides).
 __host__ __device__ inline int async_waves_per_simd(long items) { return items <= 5400 ? 2 : (items <= 11000 ? 3 : 4); }
+// Finisher roles (round 5, second form).  One more wave per SIMD that does nothing but finish tiles: the wave that
+// completes a tile appends (step, tile) to its group's finish ring and pulls its next item at once; a finisher takes the
+// ring's next position and polls it.  The item waves lose the fifth of their time they spent finishing; the finisher is
+// a latency chain that takes few issue slots from its SIMD's item waves.  It pays where an item wave has more than ~2
+// items per step (us per step, roles / no roles, scripts/time_async.py): 43.75k guides 49.4 / 45.8 and 50k 50.3 / 48.8
+// (1.7 and 1.9 items per wave: no), 56.25k 52.3 / 54.6, 62.5k 57.4 / 61.0, 68.75k 63.0 / 67.0 (2.15 ... 2.6: yes); at three
+// item waves per SIMD 87.5k 74.3 / 69.3 (2.2: no), 100k 77.5 / 79.7, 125k 94.5 / 101.8 (2.55, 3.2: yes).  Progress does not
+// depend on the finishers being resident: a wave whose item has waited kAsyncStealEvery polls takes the oldest finish
+// nobody has taken, and a wave that finds no items left joins the finishers (tests/test_gpu_async.py runs both).
+__host__ __device__ inline bool async_finisher_roles(int waves_per_simd, long items, long simds) {
+    const double per_wave = (double)items / (double)(waves_per_simd * simds);
+    return (waves_per_simd == 2 && per_wave >= 2.05) || (waves_per_simd == 3 && per_wave >= 2.4);
+}
 constexpr int kAsyncQueueStride = 32;      // ints between two groups' queue counters (separate 128-byte lines)
+constexpr int kAsyncStealEvery = 64;       // polls between two looks of a waiting item's wave into the finish ring
 constexpr int kAsyncSpinMax = 1 << 21;     // polls before a wave gives up (~0.3 us each: over half a second)
 
 struct AsyncArgs {
@@ -107,6 +121,13 @@ struct AsyncArgs {
     int* queue;                // [8 * kAsyncQueueStride] next item of each group; zero when the call starts
     int* done;                 // [n_tiles] steps of THIS call the tile has completed; zero when the call starts
     int* abort_flag;           // [1] set by a wave whose poll ran out
+    // finisher roles (n_guide_blocks > 0): blocks from n_guide_blocks upwards only finish tiles; the wave that completes a
+    // tile appends (step, tile) to its group's finish ring instead of finishing it itself
+    int n_guide_blocks;        // 0: every wave pulls items and the last arriver finishes (no roles)
+    int* fhead;                // [8 * kAsyncQueueStride] next ring position a finisher takes
+    int* ftail;                // [8 * kAsyncQueueStride] next ring position to be filled
+    int* fring;                // [8 * fring_stride] ((step + 1) << 16) | (tile >> 3), 0 = not filled yet
+    long fring_stride;
     const float* step_sizes;   // [n_steps] ClippedAdam step size of the update of step0 + i (k_step_sizes)
     unsigned long long* stamps;  // diagnostic builds (-DBEAN_ASYNC_STAMP): kAsyncStampSteps x items x 8 words, or null
 };
@@ -159,14 +180,18 @@ __global__ __launch_bounds__(256) void k_step_sizes(DevArgs c, unsigned long lon
 // finalize and a later resume continue from there.
 __global__ __launch_bounds__(256) void k_async_head(DevArgs c, AsyncArgs a, DevArgs* args_out, int* ws, int ws_ints,
                                                     float* step_sizes) {
-    const int tid = threadIdx.x;
-    for (int i = tid; i < ws_ints; i += 256) ws[i] = 0;
-    for (int i = tid; i < c.n_arrival_ctr; i += 256) c.tile_ctr[i] = 0;
-    for (int i = tid; i < a.n_steps; i += 256) step_sizes[i] = adam_coef(c, a.step0 + (unsigned long long)i + 1).step_size;
+    // (a few blocks: the finish rings are n_steps x tiles ints)
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
+    if (a.n_guide_blocks > 0)
+        for (long i = tid; i < 8 * a.fring_stride; i += nth) a.fring[i] = 0;
+    if (blockIdx.x != 0) return;
+    for (int i = threadIdx.x; i < ws_ints; i += 256) ws[i] = 0;
+    for (int i = threadIdx.x; i < c.n_arrival_ctr; i += 256) c.tile_ctr[i] = 0;
+    for (int i = threadIdx.x; i < a.n_steps; i += 256) step_sizes[i] = adam_coef(c, a.step0 + (unsigned long long)i + 1).step_size;
     const unsigned int* src = (const unsigned int*)&c;
     unsigned int* dst = (unsigned int*)args_out;
-    for (unsigned i = tid; i < sizeof(DevArgs) / 4; i += 256) dst[i] = src[i];
-    if (tid != 0) return;
+    for (unsigned i = threadIdx.x; i < sizeof(DevArgs) / 4; i += 256) dst[i] = src[i];
+    if (threadIdx.x != 0) return;
     StepCtr last, next;
     last.step = a.step0 + a.n_steps - 1;
     last.slot = a.slot0 + a.n_steps - 1;
@@ -198,14 +223,19 @@ __device__ __forceinline__ void async_give_up(const DevArgs* cp, const AsyncArgs
 // inlined loop spilled 249 VGPRs: 576 B of scratch per lane).
 template <int FAM, bool ACC>
 __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned long long step, unsigned long long slot,
-                                               float step_size, int tile, int t0, int nt BEAN_ASYNC_ST_ARG) {
+                                               float step_size, int tile BEAN_ASYNC_ST_ARG) {
     const DevArgs c = dev_args_in_sgprs(cp);
     step = rfl_u64(step);
     slot = rfl_u64(slot);
     step_size = __builtin_bit_cast(float, rfl_i(__builtin_bit_cast(int, step_size)));
     tile = rfl_i(tile);
-    t0 = rfl_i(t0);
-    nt = rfl_i(nt);
+    int t0, nt;  // the tile's first target and their number (as guide_wave2_tile finds them)
+    {
+        const int gf = tile * 64 - c.g_sh > 0 ? tile * 64 - c.g_sh : 0;
+        const int gl = tile * 64 + 63 - c.g_sh < c.G ? tile * 64 + 63 - c.g_sh : c.G - 1;
+        t0 = __builtin_amdgcn_readfirstlane(c.g2t[gf]);
+        nt = __builtin_amdgcn_readfirstlane(c.g2t[gl]) - t0 + 1;
+    }
     StepCtr ctr;
     ctr.step = step;
     ctr.slot = slot;
@@ -481,9 +511,11 @@ __device__ BEAN_ASYNC_INLINE int2 async_guide_item(const DevArgs* cp, unsigned l
         }
     }
     last = __builtin_amdgcn_readfirstlane(last);
+    (void)t0;
+    (void)nt;
     int2 res;
-    res.x = last ? rfl_i(t0) : -1;
-    res.y = last ? rfl_i(nt) : 0;
+    res.x = last ? 1 : -1;
+    res.y = 0;
     return res;
 }
 
@@ -495,68 +527,151 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
     const int nx = (n_tiles - x + 7) >> 3;      // tiles k with k & 7 == x
     const int per_step = nx * R;
     const long total = (long)per_step * a.n_steps;
+    const long total_fin = (long)nx * a.n_steps;
     int* const queue = a.queue + x * kAsyncQueueStride;
+    const bool roles = a.n_guide_blocks > 0;
+    bool finisher = roles && (int)blockIdx.x >= a.n_guide_blocks;
+    int* const fhead = a.fhead + x * kAsyncQueueStride;
+    int* const ftail = a.ftail + x * kAsyncQueueStride;
+    int* const fring = a.fring + x * a.fring_stride;
+    int item = -1;  // a guide item this wave has pulled and not run yet
     for (;;) {
-        // ---- pull the group's next item: (step, tile, replicate) in that order
-        int item = 0;
-        if (lane == 0) item = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= total) return;
-        const int s = item / per_step;
+        int fin_s = -1, fin_tile = 0;  // the finish this iteration ends with, if any
 #ifdef BEAN_ASYNC_STAMP
         unsigned long long* st_row = nullptr;
-        if (a.stamps && s >= kAsyncStampStep0 && s < kAsyncStampStep0 + kAsyncStampSteps) {
-            const long all = (long)((n_tiles + 7) / 8 * 8) * R;
-            const int rem_ = item - s * per_step;
-            const int tile_ = (rem_ / R) * 8 + x;
-            st_row = a.stamps + ((long)(s - kAsyncStampStep0) * all + (long)tile_ * R + (rem_ % R)) * 8;
-            if (lane == 0) {
-                st_row[5] = (unsigned long long)blockIdx.x;
-                st_row[6] = (unsigned long long)tile_;
-                st_row[7] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
-            }
-        }
 #endif
-        BEAN_ASYNC_T(0);
-        const int rem = item - s * per_step;
-        const int jt = rem / R;
-        const int r = rem - jt * R;
-        const int tile = jt * 8 + x;
-        // ---- wait until the previous step of this tile and of its two neighbours (a target may straddle a tile
-        // boundary, and is finished by whichever of the two tiles completes second) has been finished: lanes 0 - 2
-        // poll one word each, lane 3 the abort word
-        {
-            const int tq = lane == 0 ? tile : (lane == 1 ? tile - 1 : tile + 1);
-            const bool need = s > 0 && lane < 3 && tq >= 0 && tq < n_tiles;
-            int spins = 0;
+        if (finisher) {
+            // ---- a finisher takes the group's next finish and waits until it is there
+            int pos = 0;
+            if (lane == 0) pos = __hip_atomic_fetch_add(fhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pos = __builtin_amdgcn_readfirstlane(pos);
+            if (pos >= total_fin) return;
+            int entry = 0, spins = 0;
             for (;;) {
-                int v = s;
-                if (need) v = __hip_atomic_load(a.done + tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int ab = 0;
-                if (lane == 3) ab = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int v = 0, ab = 0;
+                if (lane == 0) v = __hip_atomic_load(fring + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 1) ab = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__any(ab != 0)) return;
-                if (__all(v >= s)) break;
+                entry = __builtin_amdgcn_readfirstlane(v);
+                if (entry != 0) break;
                 if (++spins > kAsyncSpinMax) {
                     if (lane == 0) async_give_up(cp, a);
                     return;
                 }
                 __builtin_amdgcn_s_sleep(BEAN_ASYNC_SLEEP);
             }
-            asm volatile("" ::: "memory");  // (nothing below is loaded before the poll has matched)
+            asm volatile("" ::: "memory");
+            fin_s = (int)((unsigned)entry >> 16) - 1;
+            fin_tile = (entry & 0xffff) * 8 + x;
+        } else {
+            // ---- pull the group's next item: (step, tile, replicate) in that order
+            if (item < 0) {
+                int it = 0;
+                if (lane == 0) it = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                item = __builtin_amdgcn_readfirstlane(it);
+            }
+            if (item >= total) {
+                // no items left: without roles the wave is done; with roles it joins the finishers for what is left in the
+                // ring (the last steps' finishes - and all of them, should no finisher be resident)
+                if (!roles) return;
+                finisher = true;
+                continue;
+            }
+            const int s = item / per_step;
+            const int rem = item - s * per_step;
+            const int jt = rem / R;
+            const int r = rem - jt * R;
+            const int tile = jt * 8 + x;
+#ifdef BEAN_ASYNC_STAMP
+            if (a.stamps && s >= kAsyncStampStep0 && s < kAsyncStampStep0 + kAsyncStampSteps) {
+                const long all = (long)((n_tiles + 7) / 8 * 8) * R;
+                st_row = a.stamps + ((long)(s - kAsyncStampStep0) * all + (long)tile * R + r) * 8;
+                if (lane == 0) {
+                    st_row[5] = (unsigned long long)blockIdx.x;
+                    st_row[6] = (unsigned long long)tile;
+                    st_row[7] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
+                }
+            }
+#endif
+            BEAN_ASYNC_T(0);
+            // ---- wait until the previous step of this tile and of its two neighbours (a target may straddle a tile
+            // boundary, and is finished by whichever of the two tiles completes second) has been finished: lanes 0 - 2
+            // poll one word each, lane 3 the abort word.  With finisher roles a wave that has waited for a while looks
+            // into the finish ring and takes the oldest finish that nobody has taken (the finishers need not be
+            // resident for the launch to make progress).
+            bool ready = false;
+            {
+                const int tq = lane == 0 ? tile : (lane == 1 ? tile - 1 : tile + 1);
+                const bool need = s > 0 && lane < 3 && tq >= 0 && tq < n_tiles;
+                int spins = 0;
+                for (;;) {
+                    int v = s;
+                    if (need) v = __hip_atomic_load(a.done + tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int ab = 0;
+                    if (lane == 3) ab = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__any(ab != 0)) return;
+                    if (__all(v >= s)) {
+                        ready = true;
+                        break;
+                    }
+                    if (++spins > kAsyncSpinMax) {
+                        if (lane == 0) async_give_up(cp, a);
+                        return;
+                    }
+                    if (roles && (spins & (kAsyncStealEvery - 1)) == 0) {
+                        int e = 0;
+                        if (lane == 0) {
+                            const int h = __hip_atomic_load(fhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (h < total_fin) {
+                                const int cand = __hip_atomic_load(fring + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                int expect = h;
+                                if (cand != 0 && __hip_atomic_compare_exchange_strong(fhead, &expect, h + 1, __ATOMIC_RELAXED,
+                                                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                    e = cand;
+                            }
+                        }
+                        e = __builtin_amdgcn_readfirstlane(e);
+                        if (e != 0) {
+                            fin_s = (int)((unsigned)e >> 16) - 1;
+                            fin_tile = (e & 0xffff) * 8 + x;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(BEAN_ASYNC_SLEEP);
+                }
+                asm volatile("" ::: "memory");  // (nothing below is loaded before the poll has matched)
+            }
+            BEAN_ASYNC_T(1);
+            if (ready) {
+                const unsigned long long step = a.step0 + (unsigned long long)s, slot = a.slot0 + (unsigned long long)s;
+                const int2 fin = async_guide_item<FAM, ACC>(cp, step, slot, a.step_sizes[s], tile, r BEAN_ASYNC_ST_PASS);
+                item = -1;
+                BEAN_ASYNC_T(2);
+                if (fin.x >= 0) {
+                    if (roles) {
+                        // the tile is complete: hand its finish to the group's finishers (the rows, sums and loss parts of
+                        // all R waves had completed before the arrival that made this wave the last)
+                        if (lane == 0) {
+                            const int p = __hip_atomic_fetch_add(ftail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(fring + p, (int)(((unsigned)(s + 1) << 16) | (unsigned)(tile >> 3)), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    } else {
+                        fin_s = s;
+                        fin_tile = tile;
+                    }
+                }
+            }
         }
-        BEAN_ASYNC_T(1);
-        const unsigned long long step = a.step0 + (unsigned long long)s, slot = a.slot0 + (unsigned long long)s;
-        const float step_size = a.step_sizes[s];
-        const int2 fin = async_guide_item<FAM, ACC>(cp, step, slot, step_size, tile, r BEAN_ASYNC_ST_PASS);
-        BEAN_ASYNC_T(2);
-        if (fin.x >= 0) {
+        if (fin_s >= 0) {
+            const unsigned long long step = a.step0 + (unsigned long long)fin_s, slot = a.slot0 + (unsigned long long)fin_s;
             // (the tile's next step waits for this chain: it goes first on its SIMD)
             if (BEAN_ASYNC_PRIO) __builtin_amdgcn_s_setprio(3);
-            async_finish_tile<FAM, ACC>(cp, step, slot, step_size, tile, fin.x, fin.y BEAN_ASYNC_ST_PASS);
+            async_finish_tile<FAM, ACC>(cp, step, slot, a.step_sizes[fin_s], fin_tile BEAN_ASYNC_ST_PASS);
             if (BEAN_ASYNC_PRIO) __builtin_amdgcn_s_setprio(0);
             // ---- publish: every store of the finish has completed before the tile's step count moves
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(a.done + tile, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(a.done + fin_tile, fin_s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             BEAN_ASYNC_T(3);
         }
         __syncthreads();  // (the next item restages the wave's LDS)

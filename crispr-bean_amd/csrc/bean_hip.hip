@@ -84,7 +84,9 @@ struct bean_hip_ctx {
     // all the steps of a call in ONE launch, tile-asynchronous (bean_async_v2.hpp): eligible shape and switched on
     bool async_step;
     int* async_ws;      // device: 8 queue counters (kAsyncQueueStride apart), the abort word, done[n_tiles]
-    int async_blocks;   // grid: resident single-wave workgroups, a multiple of 8 (0: not yet measured)
+    int async_blocks;   // grid: resident single-wave workgroups that pull items, a multiple of 8 (0: not yet measured)
+    int async_fin_blocks;  // ... and that only finish tiles (0: no roles, the last arriver finishes)
+    size_t async_ws_ints;
     unsigned long long* async_stamps;  // diagnostic builds (-DBEAN_ASYNC_STAMP): the last call's item timeline
     size_t async_stamp_words;
 };
@@ -348,6 +350,8 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->async_step = false;
     c->async_ws = nullptr;
     c->async_blocks = 0;
+    c->async_fin_blocks = 0;
+    c->async_ws_ints = 0;
     c->async_stamps = nullptr;
     c->async_stamp_words = 0;
     c->loss_acc = nullptr;
@@ -1477,7 +1481,7 @@ static bool async_candidate(const bean_hip_ctx* c, uint64_t n_steps) {
 }
 
 template <int FAM, bool ACC>
-static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncArgs& a) {
+static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncArgs& a_in, int* roles_out) {
     const DevArgs& d = c->d;
     const size_t lds = guide_wave2_lds(d.B, d.tile_targets);
     if (c->async_blocks == 0) {
@@ -1492,9 +1496,16 @@ static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncAr
         int k = async_waves_per_simd((long)d.n_tiles * d.R);
         if (k > per_cu / 4) k = per_cu / 4;
         c->async_blocks = k >= 1 ? k * 4 * n_cu : per_cu * n_cu / 8 * 8;
+        // finisher roles: one more wave per SIMD that only finishes tiles, where there is room for it and the item waves
+        // have more than ~2 items per step each (async_finisher_roles)
+        c->async_fin_blocks = (k >= 1 && k + 1 <= per_cu / 4 && async_finisher_roles(k, (long)d.n_tiles * d.R, 4l * n_cu)) ? 4 * n_cu : 0;
         if (const char* e = getenv("BEAN_HIP_ASYNC_BLOCKS")) {  // experiments
             const int v = atoi(e) / 8 * 8;
             if (v >= 8) c->async_blocks = v;
+        }
+        if (const char* e = getenv("BEAN_HIP_ASYNC_FIN")) {  // experiments: finisher blocks (0: no roles; -1: roles without finishers)
+            const int v = atoi(e);
+            c->async_fin_blocks = v < 0 ? -1 : v / 8 * 8;
         }
         if (getenv("BEAN_HIP_VERBOSE"))
             fprintf(stderr, "k_svi_async: %d tiles x %d replicates per step, LDS %zu B, %d workgroups per CU x %d CUs -> grid %d\n",
@@ -1504,6 +1515,17 @@ static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncAr
     const long items = (long)((d.n_tiles + 7) / 8 * 8) * d.R;
     int blocks = c->async_blocks;
     if ((long)blocks > items) blocks = (int)((items + 7) / 8 * 8);
+    AsyncArgs a = a_in;
+    int fin_blocks = 0;
+    if (c->async_fin_blocks != 0 && a.n_steps < 32000 && d.n_tiles <= 8 * 65535) {
+        fin_blocks = c->async_fin_blocks < 0 ? 0 : c->async_fin_blocks;
+        const int tiles8 = (d.n_tiles + 7) / 8 * 8;
+        if (fin_blocks > tiles8) fin_blocks = tiles8;  // (no more finishers than tiles)
+        a.n_guide_blocks = blocks;
+        blocks += fin_blocks;
+    } else {
+        a.n_guide_blocks = 0;
+    }
     const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     if (prof) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1518,6 +1540,7 @@ static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncAr
         hipLaunchKernelGGL((k_svi_async<FAM, ACC>), dim3(blocks), dim3(64), lds, stream, (const DevArgs*)c->dargs_dev, d.R,
                            d.n_tiles, a);
     }
+    if (roles_out) *roles_out = a.n_guide_blocks;
     return 0;
 }
 
@@ -1533,8 +1556,18 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
         HIP_OK(hipMalloc((void**)&c->step_sizes, cap * sizeof(float)));
         c->step_sizes_cap = cap;
     }
-    const size_t ws_ints = (size_t)9 * kAsyncQueueStride + (size_t)d.n_tiles;
-    if (!c->async_ws) HIP_OK(hipMalloc((void**)&c->async_ws, ws_ints * sizeof(int)));
+    // [8 x stride] queue | abort word (a line of its own) | [8 x stride] finish-ring heads | [8 x stride] tails | done[n_tiles]:
+    // zeroed by every call; behind them the finish rings (n_steps x the group's tiles, zeroed when roles are on)
+    const size_t ws_ints = (size_t)25 * kAsyncQueueStride + (size_t)d.n_tiles;
+    const size_t fring_stride = (size_t)((d.n_tiles + 7) / 8) * n_steps;
+    const size_t need_ints = ws_ints + 8 * fring_stride;
+    if (need_ints > c->async_ws_ints) {
+        if (c->async_ws) (void)hipFree(c->async_ws);
+        c->async_ws = nullptr;
+        c->async_ws_ints = 0;
+        HIP_OK(hipMalloc((void**)&c->async_ws, need_ints * sizeof(int)));
+        c->async_ws_ints = need_ints;
+    }
     // the out-of-line pieces of the kernel read DevArgs from a copy in global memory (the same bytes: c->d as it is now)
     if (!c->dargs_dev) HIP_OK(hipMalloc((void**)&c->dargs_dev, sizeof(DevArgs)));
     AsyncArgs a;
@@ -1543,11 +1576,21 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
     a.n_steps = (int)n_steps;
     a.queue = c->async_ws;
     a.abort_flag = c->async_ws + 8 * kAsyncQueueStride;
-    a.done = c->async_ws + 9 * kAsyncQueueStride;
+    a.fhead = c->async_ws + 9 * kAsyncQueueStride;
+    a.ftail = c->async_ws + 17 * kAsyncQueueStride;
+    a.done = c->async_ws + 25 * kAsyncQueueStride;
+    a.fring = c->async_ws + ws_ints;
+    a.fring_stride = (long)fring_stride;
+    a.n_guide_blocks = c->async_fin_blocks != 0 || c->async_blocks == 0 ? 1 : 0;  // (head: zero the rings unless roles are known to be off)
     a.step_sizes = c->step_sizes;
     a.stamps = nullptr;
     // queue, abort and completed-step words to zero, step sizes, the DevArgs copy, the step counters the call leaves
-    hipLaunchKernelGGL(k_async_head, dim3(1), dim3(256), 0, stream, d, a, c->dargs_dev, c->async_ws, (int)ws_ints, c->step_sizes);
+    {
+        unsigned hb = (unsigned)((8 * fring_stride + 256 * 64 - 1) / (256 * 64));  // ~64 ring words per thread
+        if (hb < 1) hb = 1;
+        if (hb > 128) hb = 128;
+        hipLaunchKernelGGL(k_async_head, dim3(hb), dim3(256), 0, stream, d, a, c->dargs_dev, c->async_ws, (int)ws_ints, c->step_sizes);
+    }
 #ifdef BEAN_ASYNC_STAMP
     {
         static unsigned long long* g_stamps = nullptr;
@@ -1563,10 +1606,10 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
 #endif
     int rc;
     if (d.family == kMixture) {
-        if (d.flags & kAcc) rc = launch_svi_async_t<kMixture, true>(c, stream, a);
-        else rc = launch_svi_async_t<kMixture, false>(c, stream, a);
+        if (d.flags & kAcc) rc = launch_svi_async_t<kMixture, true>(c, stream, a, nullptr);
+        else rc = launch_svi_async_t<kMixture, false>(c, stream, a, nullptr);
     } else {
-        rc = launch_svi_async_t<kNormal, false>(c, stream, a);
+        rc = launch_svi_async_t<kNormal, false>(c, stream, a, nullptr);
     }
     return rc;
 }

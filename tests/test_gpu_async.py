@@ -15,14 +15,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _fit(monkeypatch, mode, family, data, steps, eng_kw, chunks=None, resume=False, blocks=None):
+def _fit(monkeypatch, mode, family, data, steps, eng_kw, chunks=None, resume=False, blocks=None, fin=None):
     from bean_amd import engine
 
     monkeypatch.setenv("BEAN_HIP_STEP", mode)
-    if blocks is not None:
-        monkeypatch.setenv("BEAN_HIP_ASYNC_BLOCKS", str(blocks))
-    else:
-        monkeypatch.delenv("BEAN_HIP_ASYNC_BLOCKS", raising=False)
+    for key, val in (("BEAN_HIP_ASYNC_BLOCKS", blocks), ("BEAN_HIP_ASYNC_FIN", fin)):
+        if val is not None:
+            monkeypatch.setenv(key, str(val))
+        else:
+            monkeypatch.delenv(key, raising=False)
     eng = engine.HipSVI(family, data.to(DEV), num_steps=steps, **eng_kw)
     assert eng.dominant_kernel == ("k_guide_wave2" if mode == "pair" else "k_svi_async")
     for n in (chunks or [steps]):
@@ -34,9 +35,9 @@ def _fit(monkeypatch, mode, family, data, steps, eng_kw, chunks=None, resume=Fal
     return out, loss
 
 
-def _same(monkeypatch, family, data, steps, eng_kw=None, chunks=None, resume=False, blocks=None):
+def _same(monkeypatch, family, data, steps, eng_kw=None, chunks=None, resume=False, blocks=None, fin=None):
     a, la = _fit(monkeypatch, "pair", family, data, steps, eng_kw or {}, chunks, resume)
-    b, lb = _fit(monkeypatch, "async", family, data, steps, eng_kw or {}, chunks, resume, blocks)
+    b, lb = _fit(monkeypatch, "async", family, data, steps, eng_kw or {}, chunks, resume, blocks, fin)
     assert np.all(np.isfinite(la)) and len(la) == steps == len(lb)
     for k in a:
         assert torch.equal(a[k], b[k]), (k, (a[k] - b[k]).abs().max().item())
@@ -84,6 +85,15 @@ def test_async_does_not_depend_on_the_number_of_resident_waves(monkeypatch, bloc
     _same(monkeypatch, "MixtureNormal", data, 60, blocks=blocks)
 
 
+@pytest.mark.parametrize("blocks,fin", [(64, 0), (64, 8), (512, 64), (64, -1), (1000, -1)])
+def test_async_finisher_roles(monkeypatch, blocks, fin):
+    """Finishes by the last arriver (fin = 0), by dedicated finisher waves (the default where a SIMD has room for one
+    more wave), and - roles on, no finisher resident (fin = -1) - by the waves that wait for them, which take the oldest
+    finish nobody has taken: the launch makes progress whatever is resident.  Same bits."""
+    data = make_sorting_variant_screen(9000, 4, seed=84, guides_per_target=5, mask_fraction=0.03)
+    _same(monkeypatch, "MixtureNormal", data, 50, blocks=blocks, fin=fin)
+
+
 def test_async_metric_shape_long(monkeypatch):
     """The metric shape over a few hundred steps: the hand-overs under full load (every wave slot of the chip in use,
     finishing waves of one step beside the guide waves of the next, rewritten tables read across XCDs)."""
@@ -120,7 +130,7 @@ def test_async_shard_with_an_offset(monkeypatch):
 def test_async_loss_history_is_reproducible(monkeypatch):
     data = make_sorting_variant_screen(12000, 3, seed=83, guides_per_target=5)
     _, l1 = _fit(monkeypatch, "async", "MixtureNormal", data, 80, {})
-    _, l2 = _fit(monkeypatch, "async", "MixtureNormal", data, 80, {}, blocks=512)
+    _, l2 = _fit(monkeypatch, "async", "MixtureNormal", data, 80, {}, blocks=512, fin=0)
     assert np.array_equal(l1, l2)
 
 
