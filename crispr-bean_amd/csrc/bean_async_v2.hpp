@@ -99,17 +99,23 @@ constexpr long kAsyncMaxItems = 24000;
 // Grids that do not give every SIMD the same number of waves lose 10 - 20 % (2304 blocks: 60.4 us at 50k guides).
 __host__ __device__ inline int async_waves_per_simd(long items) { return items <= 5400 ? 2 : (items <= 11000 ? 3 : 4); }
 // Finisher roles (round 5, second form).  One more wave per SIMD that does nothing but finish tiles: the wave that
-// completes a tile appends (step, tile) to its group's finish ring and pulls its next item at once; a finisher takes the
-// ring's next position and polls it.  The item waves lose the fifth of their time they spent finishing; the finisher is
-// a latency chain that takes few issue slots from its SIMD's item waves.  It pays where an item wave has more than ~2
-// items per step (us per step, roles / no roles, scripts/time_async.py): 43.75k guides 49.4 / 45.8 and 50k 50.3 / 48.8
-// (1.7 and 1.9 items per wave: no), 56.25k 52.3 / 54.6, 62.5k 57.4 / 61.0, 68.75k 63.0 / 67.0 (2.15 ... 2.6: yes); at three
-// item waves per SIMD 87.5k 74.3 / 69.3 (2.2: no), 100k 77.5 / 79.7, 125k 94.5 / 101.8 (2.55, 3.2: yes).  Progress does not
-// depend on the finishers being resident: a wave whose item has waited kAsyncStealEvery polls takes the oldest finish
-// nobody has taken, and a wave that finds no items left joins the finishers (tests/test_gpu_async.py runs both).
+// completes a tile appends two entries to its group's finish ring - the tile's TARGETS (sums, priors, ClippedAdam, draw,
+// Phi tables, the R waves' loss parts) and its GUIDES (alpha_pi, noise site, digamma tables): two chains that do not
+// depend on each other - and pulls its next item at once; a finisher takes the ring's next position and polls it, so
+// the two parts of a tile run on two waves at the same time (11 and 5 us instead of 19 in a row), and an item waits for
+// its tile's two completed-step words and its neighbours' target words.  The item waves lose the fifth of their time they
+// spent finishing; a finisher is a latency chain that takes few issue slots from its SIMD's item waves.  It pays where an
+// item wave has about two items per step or more (us per step, roles / no roles, scripts/time_async.py, same box per
+// pair): 43.75k guides 46.9 / 46.4 (1.7 items per wave: no), 50k 47.8 / 49.6, 62.5k 58.4 / 62.2 (1.9, 2.4: yes); at three
+// item waves per SIMD 75k 69.0 / 64.8, 87.5k 71.7 / 70.1 (1.9, 2.2: no), 100k 77.8 / 79.9, 125k 96.6 / 99.5 (2.55, 3.2: yes);
+// 512 ... 2 048 finishers make no difference.  (With the finish in ONE piece the roles lost at 50k - 50.3 / 48.8: the hop
+// through the ring made the tile's chain longer than the item waves' step - and won as much at 62.5k, 57.4 / 61.0.)
+// Progress does not depend on the finishers being resident: a wave whose item has waited kAsyncStealEvery polls takes the
+// oldest finish nobody has taken, and a wave that finds no items left joins the finishers
+// (tests/test_gpu_async.py runs both).
 __host__ __device__ inline bool async_finisher_roles(int waves_per_simd, long items, long simds) {
     const double per_wave = (double)items / (double)(waves_per_simd * simds);
-    return (waves_per_simd == 2 && per_wave >= 2.05) || (waves_per_simd == 3 && per_wave >= 2.4);
+    return (waves_per_simd == 2 && per_wave >= 1.8) || (waves_per_simd == 3 && per_wave >= 2.4);
 }
 constexpr int kAsyncQueueStride = 32;      // ints between two groups' queue counters (separate 128-byte lines)
 constexpr int kAsyncStealEvery = 64;       // polls between two looks of a waiting item's wave into the finish ring
@@ -119,14 +125,14 @@ struct AsyncArgs {
     unsigned long long step0, slot0;  // first step of the call and its loss slot
     int n_steps;
     int* queue;                // [8 * kAsyncQueueStride] next item of each group; zero when the call starts
-    int* done;                 // [n_tiles] steps of THIS call the tile has completed; zero when the call starts
+    int* done;                 // [2 n_tiles] steps of THIS call whose finish is complete: [2 k] tile k's targets, [2 k + 1] its guides
     int* abort_flag;           // [1] set by a wave whose poll ran out
     // finisher roles (n_guide_blocks > 0): blocks from n_guide_blocks upwards only finish tiles; the wave that completes a
     // tile appends (step, tile) to its group's finish ring instead of finishing it itself
     int n_guide_blocks;        // 0: every wave pulls items and the last arriver finishes (no roles)
     int* fhead;                // [8 * kAsyncQueueStride] next ring position a finisher takes
     int* ftail;                // [8 * kAsyncQueueStride] next ring position to be filled
-    int* fring;                // [8 * fring_stride] ((step + 1) << 16) | (tile >> 3), 0 = not filled yet
+    int* fring;                // [8 * fring_stride] ((step + 1) << 17) | (part: 0 targets, 1 guides) << 16 | (tile >> 3); 0 = not filled yet
     long fring_stride;
     const float* step_sizes;   // [n_steps] ClippedAdam step size of the update of step0 + i (k_step_sizes)
     unsigned long long* stamps;  // diagnostic builds (-DBEAN_ASYNC_STAMP): kAsyncStampSteps x items x 8 words, or null
@@ -223,8 +229,12 @@ __device__ __forceinline__ void async_give_up(const DevArgs* cp, const AsyncArgs
 // inlined loop spilled 249 VGPRs: 576 B of scratch per lane).
 template <int FAM, bool ACC>
 __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned long long step, unsigned long long slot,
-                                               float step_size, int tile BEAN_ASYNC_ST_ARG) {
+                                               float step_size, int tile, int part BEAN_ASYNC_ST_ARG) {
+    // part: 1 = the tile's targets (sums, priors, ClippedAdam, draw, Phi tables; the R waves' loss parts), 2 = its guides
+    // (alpha_pi, the noise site, digamma tables), 3 = both.  The two do not depend on each other: with finisher roles they
+    // are two entries of the finish ring and run on two waves at the same time.
     const DevArgs c = dev_args_in_sgprs(cp);
+    part = rfl_i(part);
     step = rfl_u64(step);
     slot = rfl_u64(slot);
     step_size = __builtin_bit_cast(float, rfl_i(__builtin_bit_cast(int, step_size)));
@@ -255,6 +265,20 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
     const int g_last = tile * 64 + 63 - c.g_sh < G ? tile * 64 + 63 - c.g_sh : G - 1;
     const bool left_str = tof0 < g_first;
     const bool right_str = tof1 > g_last + 1;
+    // Which wave finishes a straddling target depends on timing, so the prior / entropy terms are not added up as
+    // doubles per wave: every TERM goes into the loss's fixed-point form by itself (fixed_add's split) and the wave
+    // adds integers - the loss history is bitwise reproducible run to run, whoever finished what.
+    long long loss_hi = 0, loss_lo = 0, loss_bad = 0;
+    auto loss_term = [&](double v) {
+        if (!(fabs(v) < kLossPartMax)) {
+            loss_bad = 1;
+            return;
+        }
+        const double hi = rint(v * 1024.0);
+        loss_hi += (long long)hi;
+        loss_lo += (long long)rint((v - hi * (1.0 / 1024.0)) * 1099511627776.0);
+    };
+    if (part & 1) {
     int own_left = left_str ? 0 : 1, own_right = right_str ? 0 : 1;
     if (lane == 0) {
         // a target that straddles two tiles goes to the tile that completes second (one counter per boundary)
@@ -276,19 +300,6 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
     own_right = __builtin_amdgcn_readfirstlane(own_right);
     BEAN_ASYNC_TF(0);
     const int ta = own_left ? t0 : t0 + 1, tb = own_right ? t1 : t1 - 1;  // this wave's targets, ta > tb: none
-    // Which wave finishes a straddling target depends on timing, so the prior / entropy terms are not added up as
-    // doubles per wave: every TERM goes into the loss's fixed-point form by itself (fixed_add's split) and the wave
-    // adds integers - the loss history is bitwise reproducible run to run, whoever finished what.
-    long long loss_hi = 0, loss_lo = 0, loss_bad = 0;
-    auto loss_term = [&](double v) {
-        if (!(fabs(v) < kLossPartMax)) {
-            loss_bad = 1;
-            return;
-        }
-        const double hi = rint(v * 1024.0);
-        loss_hi += (long long)hi;
-        loss_lo += (long long)rint((v - hi * (1.0 / 1024.0)) * 1099511627776.0);
-    };
     double* hmu = tabs;  // drawn mu / y of the targets, hmu[t - ta] (<= 64 targets per tile)
     double* hy = tabs + 64;
     __syncthreads();  // single-wave workgroup: the guide work's LDS is free from here
@@ -422,9 +433,10 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
             __syncthreads();
         }
     }
+    }
     BEAN_ASYNC_TF(2);
     // ---- the tile's guides: alpha_pi (and the accessibility noise site), tables for the next step
-    if (MIX) {
+    if (MIX && (part & 2)) {
         const int g = tile * 64 + lane - c.g_sh;
         double lg = 0.0;
         if (g >= 0 && g < G) {
@@ -439,7 +451,7 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
     loss_bad = wave_sum_i64(loss_bad);
     if (lane == 0) {
         long long a = 0, b = 0, d = 0;
-        for (int r0 = 0; r0 < R; r0 += 8) {
+        for (int r0 = 0; r0 < ((part & 1) ? R : 0); r0 += 8) {  // (the R waves' parts: with the targets)
             long long w[8][3];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -527,7 +539,7 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
     const int nx = (n_tiles - x + 7) >> 3;      // tiles k with k & 7 == x
     const int per_step = nx * R;
     const long total = (long)per_step * a.n_steps;
-    const long total_fin = (long)nx * a.n_steps;
+    const long total_fin = 2l * nx * a.n_steps;  // (two entries per tile and step)
     int* const queue = a.queue + x * kAsyncQueueStride;
     const bool roles = a.n_guide_blocks > 0;
     bool finisher = roles && (int)blockIdx.x >= a.n_guide_blocks;
@@ -536,7 +548,7 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
     int* const fring = a.fring + x * a.fring_stride;
     int item = -1;  // a guide item this wave has pulled and not run yet
     for (;;) {
-        int fin_s = -1, fin_tile = 0;  // the finish this iteration ends with, if any
+        int fin_s = -1, fin_tile = 0, fin_part = 3;  // the finish this iteration ends with, if any
 #ifdef BEAN_ASYNC_STAMP
         unsigned long long* st_row = nullptr;
 #endif
@@ -561,7 +573,8 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
                 __builtin_amdgcn_s_sleep(BEAN_ASYNC_SLEEP);
             }
             asm volatile("" ::: "memory");
-            fin_s = (int)((unsigned)entry >> 16) - 1;
+            fin_s = (int)((unsigned)entry >> 17) - 1;
+            fin_part = (entry & 0x10000) ? 2 : 1;
             fin_tile = (entry & 0xffff) * 8 + x;
         } else {
             // ---- pull the group's next item: (step, tile, replicate) in that order
@@ -601,14 +614,15 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
             // resident for the launch to make progress).
             bool ready = false;
             {
-                const int tq = lane == 0 ? tile : (lane == 1 ? tile - 1 : tile + 1);
-                const bool need = s > 0 && lane < 3 && tq >= 0 && tq < n_tiles;
+                // (done[2 k]: tile k's targets, done[2 k + 1]: its guides; a neighbour matters through the targets it shares)
+                const int tq = (lane == 0 || lane == 3) ? tile : (lane == 1 ? tile - 1 : tile + 1);
+                const bool need = s > 0 && lane < 4 && tq >= 0 && tq < n_tiles;
                 int spins = 0;
                 for (;;) {
                     int v = s;
-                    if (need) v = __hip_atomic_load(a.done + tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (need) v = __hip_atomic_load(a.done + 2 * tq + (lane == 3 ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     int ab = 0;
-                    if (lane == 3) ab = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 4) ab = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__any(ab != 0)) return;
                     if (__all(v >= s)) {
                         ready = true;
@@ -632,7 +646,8 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
                         }
                         e = __builtin_amdgcn_readfirstlane(e);
                         if (e != 0) {
-                            fin_s = (int)((unsigned)e >> 16) - 1;
+                            fin_s = (int)((unsigned)e >> 17) - 1;
+                            fin_part = (e & 0x10000) ? 2 : 1;
                             fin_tile = (e & 0xffff) * 8 + x;
                             break;
                         }
@@ -651,14 +666,17 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
                     if (roles) {
                         // the tile is complete: hand its finish to the group's finishers (the rows, sums and loss parts of
                         // all R waves had completed before the arrival that made this wave the last)
+                        // (two entries: the targets' part and the guides' part run on two finishers at the same time)
                         if (lane == 0) {
-                            const int p = __hip_atomic_fetch_add(ftail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(fring + p, (int)(((unsigned)(s + 1) << 16) | (unsigned)(tile >> 3)), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+                            const int p = __hip_atomic_fetch_add(ftail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const int e = (int)(((unsigned)(s + 1) << 17) | (unsigned)(tile >> 3));
+                            __hip_atomic_store(fring + p, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(fring + p + 1, e | 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     } else {
                         fin_s = s;
                         fin_tile = tile;
+                        fin_part = 3;
                     }
                 }
             }
@@ -667,11 +685,14 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
             const unsigned long long step = a.step0 + (unsigned long long)fin_s, slot = a.slot0 + (unsigned long long)fin_s;
             // (the tile's next step waits for this chain: it goes first on its SIMD)
             if (BEAN_ASYNC_PRIO) __builtin_amdgcn_s_setprio(3);
-            async_finish_tile<FAM, ACC>(cp, step, slot, a.step_sizes[fin_s], fin_tile BEAN_ASYNC_ST_PASS);
+            async_finish_tile<FAM, ACC>(cp, step, slot, a.step_sizes[fin_s], fin_tile, fin_part BEAN_ASYNC_ST_PASS);
             if (BEAN_ASYNC_PRIO) __builtin_amdgcn_s_setprio(0);
-            // ---- publish: every store of the finish has completed before the tile's step count moves
+            // ---- publish: every store of the finish has completed before the tile's step counts move
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(a.done + fin_tile, fin_s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                if (fin_part & 1) __hip_atomic_store(a.done + 2 * fin_tile, fin_s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fin_part & 2) __hip_atomic_store(a.done + 2 * fin_tile + 1, fin_s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             BEAN_ASYNC_T(3);
         }
         __syncthreads();  // (the next item restages the wave's LDS)

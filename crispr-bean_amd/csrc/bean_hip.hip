@@ -1517,7 +1517,7 @@ static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncAr
     if ((long)blocks > items) blocks = (int)((items + 7) / 8 * 8);
     AsyncArgs a = a_in;
     int fin_blocks = 0;
-    if (c->async_fin_blocks != 0 && a.n_steps < 32000 && d.n_tiles <= 8 * 65535) {
+    if (c->async_fin_blocks != 0 && a.n_steps < 16000 && d.n_tiles <= 8 * 65535) {
         fin_blocks = c->async_fin_blocks < 0 ? 0 : c->async_fin_blocks;
         const int tiles8 = (d.n_tiles + 7) / 8 * 8;
         if (fin_blocks > tiles8) fin_blocks = tiles8;  // (no more finishers than tiles)
@@ -1558,8 +1558,8 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
     }
     // [8 x stride] queue | abort word (a line of its own) | [8 x stride] finish-ring heads | [8 x stride] tails | done[n_tiles]:
     // zeroed by every call; behind them the finish rings (n_steps x the group's tiles, zeroed when roles are on)
-    const size_t ws_ints = (size_t)25 * kAsyncQueueStride + (size_t)d.n_tiles;
-    const size_t fring_stride = (size_t)((d.n_tiles + 7) / 8) * n_steps;
+    const size_t ws_ints = (size_t)25 * kAsyncQueueStride + (size_t)2 * d.n_tiles;
+    const size_t fring_stride = (size_t)2 * ((d.n_tiles + 7) / 8) * n_steps;
     const size_t need_ints = ws_ints + 8 * fring_stride;
     if (need_ints > c->async_ws_ints) {
         if (c->async_ws) (void)hipFree(c->async_ws);
