@@ -23,7 +23,9 @@
 // in the order they became ready, filled by the finish that completes a tile's three dependencies, so that no wave holds
 // an item that cannot start: same bits, and 51.0 us at two waves per SIMD where this form takes 50.6, 65 / 64 at three /
 // four against 59.6 / 67.7.  Head-of-line blocking is not what more resident waves lose to; a wave's own chain growing
-// with its SIMD's load is, and a tile waits for the slowest of its R waves.  In the finish: the boundary counters, the R
+// with its SIMD's load is, and a tile waits for the slowest of its R waves.  With finisher roles, the next item pulled
+// between an item's last stores and the wait for them (the queue atomic under the store drain): 48.8 against 48.4 us at
+// 50k guides, 57.6 against 57.9 at 62.5k - nothing.  In the finish: the boundary counters, the R
 // waves' loss parts (one word per lane) and the guides' state requested in one batch at the top and the guides' part
 // moved in front of the targets' - 18.8 -> 21.2 us per finish (more values live across the chain, 36 B more scratch).
 // A 256-register build for the two-waves-per-SIMD grids whose bin loop takes two bins per pass (four lgamma / digamma
