@@ -132,9 +132,10 @@ struct AsyncArgs {
     // finisher roles (n_guide_blocks > 0): blocks from n_guide_blocks upwards only finish tiles; the wave that completes a
     // tile appends (step, tile) to its group's finish ring instead of finishing it itself
     int n_guide_blocks;        // 0: every wave pulls items and the last arriver finishes (no roles)
+    int fin_split;             // 1: a tile's finish is two ring entries (targets, guides); 0: one
     int* fhead;                // [8 * kAsyncQueueStride] next ring position a finisher takes
     int* ftail;                // [8 * kAsyncQueueStride] next ring position to be filled
-    int* fring;                // [8 * fring_stride] ((step + 1) << 17) | (part: 0 targets, 1 guides) << 16 | (tile >> 3); 0 = not filled yet
+    int* fring;                // [8 * fring_stride] ((step + 1) << 18) | (part: 0 targets, 1 guides, 2 both) << 16 | (tile >> 3); 0 = not filled yet
     long fring_stride;
     const float* step_sizes;   // [n_steps] ClippedAdam step size of the update of step0 + i (k_step_sizes)
     unsigned long long* stamps;  // diagnostic builds (-DBEAN_ASYNC_STAMP): kAsyncStampSteps x items x 8 words, or null
@@ -541,7 +542,7 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
     const int nx = (n_tiles - x + 7) >> 3;      // tiles k with k & 7 == x
     const int per_step = nx * R;
     const long total = (long)per_step * a.n_steps;
-    const long total_fin = 2l * nx * a.n_steps;  // (two entries per tile and step)
+    const long total_fin = (a.fin_split ? 2l : 1l) * nx * a.n_steps;  // (ring entries per tile and step)
     int* const queue = a.queue + x * kAsyncQueueStride;
     const bool roles = a.n_guide_blocks > 0;
     bool finisher = roles && (int)blockIdx.x >= a.n_guide_blocks;
@@ -575,8 +576,8 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
                 __builtin_amdgcn_s_sleep(BEAN_ASYNC_SLEEP);
             }
             asm volatile("" ::: "memory");
-            fin_s = (int)((unsigned)entry >> 17) - 1;
-            fin_part = (entry & 0x10000) ? 2 : 1;
+            fin_s = (int)((unsigned)entry >> 18) - 1;
+            fin_part = ((entry >> 16) & 3) + 1;  // 1 targets, 2 guides, 3 both
             fin_tile = (entry & 0xffff) * 8 + x;
         } else {
             // ---- pull the group's next item: (step, tile, replicate) in that order
@@ -648,8 +649,8 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
                         }
                         e = __builtin_amdgcn_readfirstlane(e);
                         if (e != 0) {
-                            fin_s = (int)((unsigned)e >> 17) - 1;
-                            fin_part = (e & 0x10000) ? 2 : 1;
+                            fin_s = (int)((unsigned)e >> 18) - 1;
+                            fin_part = ((e >> 16) & 3) + 1;
                             fin_tile = (e & 0xffff) * 8 + x;
                             break;
                         }
@@ -670,10 +671,15 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
                         // all R waves had completed before the arrival that made this wave the last)
                         // (two entries: the targets' part and the guides' part run on two finishers at the same time)
                         if (lane == 0) {
-                            const int p = __hip_atomic_fetch_add(ftail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const int e = (int)(((unsigned)(s + 1) << 17) | (unsigned)(tile >> 3));
-                            __hip_atomic_store(fring + p, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(fring + p + 1, e | 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const int e = (int)(((unsigned)(s + 1) << 18) | (unsigned)(tile >> 3));
+                            if (a.fin_split) {
+                                const int p = __hip_atomic_fetch_add(ftail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(fring + p, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // targets
+                                __hip_atomic_store(fring + p + 1, e | 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // guides
+                            } else {
+                                const int p = __hip_atomic_fetch_add(ftail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(fring + p, e | 0x20000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // both
+                            }
                         }
                     } else {
                         fin_s = s;

@@ -1517,7 +1517,12 @@ static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncAr
     if ((long)blocks > items) blocks = (int)((items + 7) / 8 * 8);
     AsyncArgs a = a_in;
     int fin_blocks = 0;
-    if (c->async_fin_blocks != 0 && a.n_steps < 16000 && d.n_tiles <= 8 * 65535) {
+    // the finish as two ring entries (targets / guides on two finishers at once) while the item waves have few items per
+    // step - then a tile's chain is what a step waits for - and as one entry beyond (same box, split / one entry: 50k guides
+    // 48.5 / 51.3 us per step, 56k 53.2 / 53.3, 62.5k 59.4 / 58.8, 68.75k 65.5 / 64.4, 125k 97.0 / 95.7)
+    a.fin_split = (double)d.n_tiles * d.R / (double)(c->async_blocks > 0 ? c->async_blocks : 1) < 2.15 ? 1 : 0;
+    if (const char* e = getenv("BEAN_HIP_ASYNC_SPLIT")) a.fin_split = atoi(e) != 0;  // experiments
+    if (c->async_fin_blocks != 0 && a.n_steps < 8000 && d.n_tiles <= 8 * 65535) {
         fin_blocks = c->async_fin_blocks < 0 ? 0 : c->async_fin_blocks;
         const int tiles8 = (d.n_tiles + 7) / 8 * 8;
         if (fin_blocks > tiles8) fin_blocks = tiles8;  // (no more finishers than tiles)

@@ -85,11 +85,13 @@ def test_async_does_not_depend_on_the_number_of_resident_waves(monkeypatch, bloc
     _same(monkeypatch, "MixtureNormal", data, 60, blocks=blocks)
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
 @pytest.mark.parametrize("blocks,fin", [(64, 0), (64, 8), (512, 64), (64, -1), (1000, -1)])
-def test_async_finisher_roles(monkeypatch, blocks, fin):
+def test_async_finisher_roles(monkeypatch, blocks, fin, split):
     """Finishes by the last arriver (fin = 0), by dedicated finisher waves (the default where a SIMD has room for one
     more wave), and - roles on, no finisher resident (fin = -1) - by the waves that wait for them, which take the oldest
     finish nobody has taken: the launch makes progress whatever is resident.  Same bits."""
+    monkeypatch.setenv("BEAN_HIP_ASYNC_SPLIT", split)  # a tile's finish as two ring entries (targets, guides) or as one
     data = make_sorting_variant_screen(9000, 4, seed=84, guides_per_target=5, mask_fraction=0.03)
     _same(monkeypatch, "MixtureNormal", data, 50, blocks=blocks, fin=fin)
 
