@@ -270,6 +270,12 @@ def roofline_object(config, leg, guides, std_size):
         "kernel_resources": kernel_resources(kernel_variant, lds_dyn),
         "measured_on": f"the weak leg's screen ({guides} guides on this rank)",
     }
+    if getattr(leg, "last_ms_per_step", None):
+        # the same bytes over the whole STEP (every launch of it), for comparing configurations whose dominant kernel is
+        # a part of the step (k_guide_* + k_param) with k_svi_async, which is the whole step
+        ws = step_bytes / (leg.last_ms_per_step * 1e-3) / 1e9
+        obj["whole_step"] = {"achieved": ws, "frac": ws / HBM_PEAK_GBS, "ms_per_step": leg.last_ms_per_step,
+                             "note": "algorithmic_bytes_per_launch / ms_per_step of this leg's timed region"}
     if std_size:
         valu = valu_issue_roofline(config, kernel_name, k_ms)
         if valu is not None:
@@ -502,6 +508,7 @@ class Leg:
             tt = torch.tensor([dt], dtype=torch.float64, device=self.dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+        self.last_ms_per_step = dt / steps * 1e3
         return dt
 
     def sustained(self, n_steps=2000, window=LOSS_SYNC_EVERY):

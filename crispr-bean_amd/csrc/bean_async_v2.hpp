@@ -191,8 +191,7 @@ __global__ __launch_bounds__(256) void k_async_head(DevArgs c, AsyncArgs a, DevA
                                                     float* step_sizes) {
     // (a few blocks: the finish rings are n_steps x tiles ints)
     const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
-    if (a.n_guide_blocks > 0)
-        for (long i = tid; i < 8 * a.fring_stride; i += nth) a.fring[i] = 0;
+    for (long i = tid; i < 8 * a.fring_stride; i += nth) a.fring[i] = 0;
     if (blockIdx.x != 0) return;
     for (int i = threadIdx.x; i < ws_ints; i += 256) ws[i] = 0;
     for (int i = threadIdx.x; i < c.n_arrival_ctr; i += 256) c.tile_ctr[i] = 0;

@@ -1586,7 +1586,8 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
     a.done = c->async_ws + 25 * kAsyncQueueStride;
     a.fring = c->async_ws + ws_ints;
     a.fring_stride = (long)fring_stride;
-    a.n_guide_blocks = c->async_fin_blocks != 0 || c->async_blocks == 0 ? 1 : 0;  // (head: zero the rings unless roles are known to be off)
+    a.n_guide_blocks = 0;  // (set by launch_svi_async_t, where the grid is decided)
+    a.fin_split = 0;
     a.step_sizes = c->step_sizes;
     a.stamps = nullptr;
     // queue, abort and completed-step words to zero, step sizes, the DevArgs copy, the step counters the call leaves
