@@ -12,14 +12,15 @@
 // Here nothing waits for the chip.  Single-wave workgroups stay resident and PULL work items (step, tile, replicate)
 // from a queue; an item is k_guide_wave2's wave work (guide_wave2_tile, the same code, the same bits); the wave that
 // completes a tile last finishes it (or, with finisher roles, hands the finish to a wave that does nothing else: below)
-// - k_step_wave2's hand-over and k_param's per-target / per-guide code - and then publishes "tile k has completed step s".  An item of step s + 1 waits (a bounded poll) for that word of its own tile
-// and of the two neighbours it may share a target with, and for nothing else: one tile's finish chain runs while other
-// tiles' waves keep the SIMDs busy, and a step never drains.
+// - k_step_wave2's hand-over and k_param's per-target / per-guide code - and the finish publishes "tile k has completed
+// step s" (one word for the tile's targets, one for its guides).  An item of step s + 1 waits (a bounded poll) for those
+// words of its own tile and for the target words of the two neighbours it may share a target with, and for nothing else:
+// one tile's finish chain runs while other tiles' waves keep the SIMDs busy, and a step never drains.
 //
 // (Measured and not adopted: pulling a wave's NEXT item at the head of the current one, to hide the queue atomic's
 // round trip - an item that is claimed but not started delays its tile, and every tile's delay is the next step's wait:
-// 49.8 -> 61.0 us per step at 50k guides, 83.6 -> 92.6 at 100k.  Inlining the two pieces at two waves per SIMD
-// (237 VGPRs, no calls, no scratch): 51.5 -> 53.0.  A work-conserving queue - one ring per group that holds READY items
+// 49.8 -> 61.0 us per step at 50k guides, 83.6 -> 92.6 at 100k.  A 237-register build at two waves per SIMD (while the
+// build still ran MachineLICM, the only way to inline the pieces without scratch): 51.5 -> 53.0.  A work-conserving queue - one ring per group that holds READY items
 // in the order they became ready, filled by the finish that completes a tile's three dependencies, so that no wave holds
 // an item that cannot start: same bits, and 51.0 us at two waves per SIMD where this form takes 50.6, 65 / 64 at three /
 // four against 59.6 / 67.7.  Head-of-line blocking is not what more resident waves lose to; a wave's own chain growing
