@@ -103,6 +103,34 @@ def test_async_metric_shape_long(monkeypatch):
     _same(monkeypatch, "MixtureNormal", data, 400, chunks=[100, 100, 100, 100], resume=True)
 
 
+def test_async_config4_shard_under_full_load(monkeypatch):
+    """One rank's shard of BASELINE config 4 (62 500 of 500 000 guides, an offset that is no multiple of 64) over three
+    report windows: item waves with ~2.4 items per step, finisher roles with the finish as ONE ring entry - the grid this
+    shape gets by default - against the pair path."""
+    from bean_amd import engine, parallel
+
+    data = make_sorting_variant_screen(500000, 5, seed=85)
+    shards = parallel.plan_shards(data.target_lengths.numpy(), 8)
+    sh = shards[3]
+    assert sh[0] % 64 != 0
+    sub = parallel.shard_screen(data, sh).to(DEV)
+    out = {}
+    for mode in ("pair", "async"):
+        monkeypatch.setenv("BEAN_HIP_STEP", mode)
+        eng = engine.HipSVI("MixtureNormal", sub, guide_offset=sh[0], target_offset=sh[2], n_guides_total=data.n_guides,
+                            num_steps=300)
+        assert eng.dominant_kernel == ("k_guide_wave2" if mode == "pair" else "k_svi_async")
+        for _ in range(3):
+            eng.run(100, seed=11, resume=True)
+        torch.cuda.synchronize()
+        out[mode] = ({k: v.detach().cpu().clone() for k, v in eng.unconstrained.items()}, np.array(eng.losses()))
+        eng.close()
+    for k in out["pair"][0]:
+        assert torch.equal(out["pair"][0][k], out["async"][0][k]), k
+    la, lb = out["pair"][1], out["async"][1]
+    assert np.all(np.isfinite(la)) and np.max(np.abs(la - lb) / np.abs(la)) < 1e-12
+
+
 def test_async_shard_with_an_offset(monkeypatch):
     """A shard that does not start at a multiple of 64 guides (tiles follow the global guide index)."""
     from bean_amd import engine, parallel
