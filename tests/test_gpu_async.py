@@ -174,3 +174,57 @@ def test_targets_longer_than_a_tile_take_the_pair_path(monkeypatch):
     eng.run(5)
     assert np.all(np.isfinite(eng.losses()))
     eng.close()
+
+
+SCALE = int(__import__("os").environ.get("BEAN_FUZZ_SCALE", "1"))
+
+
+@pytest.mark.parametrize("seed", range(10 * SCALE))
+def test_async_random_geometries_shards_and_grids(monkeypatch, seed):
+    """Random screens (targets of 1 ... 64 guides, 1 ... 6 replicates, +Acc or not, NormalModel every third seed), cut into
+    random target-aligned shards; every shard steps through k_svi_async with a random number of item waves, finisher mode
+    and finish form - and the shards together must reproduce the WHOLE screen's pair-path fit bit for bit."""
+    from bean_amd import engine, parallel
+
+    rng = np.random.default_rng(7000 + seed)
+    G = int(rng.integers(200, 5000))
+    R = int(rng.integers(1, 7))
+    lmax = int(rng.choice([1, 2, 9, 40, 64]))
+    data = make_sorting_variant_screen(G, R, seed=2000 + seed, guides_per_target=1,
+                                       mask_fraction=0.05 if R > 1 else 0.0, with_accessibility=bool(seed % 2))
+    lengths, left = [], G
+    while left > 0:
+        n = int(min(left, rng.integers(1, lmax + 1)))
+        lengths.append(n)
+        left -= n
+    data.target_lengths = torch.tensor(lengths, dtype=torch.int64)
+    data.n_targets = len(lengths)
+    family = "Normal" if seed % 3 == 0 else "MixtureNormal"
+    kw = dict(scale_by_accessibility=True) if (family == "MixtureNormal" and data.guide_accessibility is not None) else {}
+    steps = 30
+    monkeypatch.setenv("BEAN_HIP_STEP", "pair")
+    whole = engine.HipSVI(family, data.to(DEV), num_steps=steps, **kw)
+    assert whole.dominant_kernel == "k_guide_wave2"
+    whole.run(steps, seed=9)
+    ref_p, ref_l = whole.constrained(), np.array(whole.losses())
+    whole.close()
+    monkeypatch.setenv("BEAN_HIP_STEP", "async")
+    shards = parallel.plan_shards(data.target_lengths.numpy(), int(min(data.n_targets, rng.integers(1, 5))))
+    parts, losses = [], np.zeros(steps)
+    for sh in shards:
+        monkeypatch.setenv("BEAN_HIP_ASYNC_BLOCKS", str(int(rng.choice([8, 16, 64, 256, 2048]))))
+        monkeypatch.setenv("BEAN_HIP_ASYNC_FIN", str(int(rng.choice([-1, 0, 8, 64, 1024]))))
+        monkeypatch.setenv("BEAN_HIP_ASYNC_SPLIT", str(int(rng.integers(0, 2))))
+        e = engine.HipSVI(family, parallel.shard_screen(data, sh).to(DEV), guide_offset=sh[0], target_offset=sh[2],
+                          n_guides_total=data.n_guides, num_steps=steps, **kw)
+        # (a shard with fewer than 64 targets runs k_param in its one-block-per-target mode: the pair path, also fine)
+        assert e.dominant_kernel in ("k_svi_async", "k_guide_wave2")
+        for n in (7, 23):
+            e.run(n, seed=9, resume=True)
+        parts.append(e.constrained())
+        losses += np.array(e.losses())
+        e.close()
+    for k in ref_p:
+        got = torch.cat([p[k] for p in parts], dim=0)
+        assert torch.equal(got, ref_p[k]), (seed, k)
+    assert np.max(np.abs(losses - ref_l) / np.abs(ref_l)) < 1e-12
