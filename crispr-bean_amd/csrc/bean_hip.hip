@@ -1488,6 +1488,9 @@ static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncAr
         // resident single-wave workgroups: the grid (nothing depends on residency but speed: a block that is
         // dispatched late finds what is left of its group's queue)
         int per_cu = 0, dev = 0, n_cu = 0;
+        // (more than 64 KB of dynamic LDS per workgroup - many conditions - has to be asked for)
+        if (lds > 65536)
+            HIP_OK(hipFuncSetAttribute((const void*)k_svi_async<FAM, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_svi_async<FAM, ACC>, 64, lds));
         HIP_OK(hipGetDevice(&dev));
         HIP_OK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));

@@ -157,6 +157,16 @@ def test_async_shard_with_an_offset(monkeypatch):
         assert np.max(np.abs(la - lb) / np.abs(la)) < 1e-12
 
 
+def test_async_many_conditions(monkeypatch):
+    """The 16-condition build's copy of the kernel: 12 and 40 sorting conditions (beyond 64 KB of LDS per wave)."""
+    for n_bins, guides in ((11, 1500), (39, 700)):
+        edges = np.linspace(0, 1, n_bins + 1)
+        bins = tuple((float(edges[i]), float(edges[i + 1])) for i in range(n_bins))
+        data = make_sorting_variant_screen(guides, 2, bins=bins, seed=86 + n_bins, guides_per_target=4)
+        assert data.n_condits == n_bins + 1
+        _same(monkeypatch, "MixtureNormal", data, 25)
+
+
 def test_async_loss_history_is_reproducible(monkeypatch):
     data = make_sorting_variant_screen(12000, 3, seed=83, guides_per_target=5)
     _, l1 = _fit(monkeypatch, "async", "MixtureNormal", data, 80, {})
