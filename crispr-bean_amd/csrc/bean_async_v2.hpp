@@ -100,7 +100,16 @@ constexpr long kAsyncMaxItems = 24000;
 // 50k guides: 2 / 3 / 4 waves per SIMD 48.3 / 54.9 / 60.2 us per step; 75k: 72.9 / 64.1 / 70.3; 100k: 97.2 / 78.7 / 86.3;
 // 150k: 144 / 118 / 110.
 // Grids that do not give every SIMD the same number of waves lose 10 - 20 % (2304 blocks: 60.4 us at 50k guides).
-__host__ __device__ inline int async_waves_per_simd(long items) { return items <= 5400 ? 2 : (items <= 11000 ? 3 : 4); }
+// (All of these were measured on 1 024 SIMDs - 256 CUs - and are applied per SIMD: a partition with fewer CUs gets the
+// same items per wave.)
+__host__ __device__ inline int async_waves_per_simd(long items, long simds = 1024) {
+    const double per_simd = (double)items / (double)(simds > 0 ? simds : 1);
+    return per_simd <= 5400.0 / 1024.0 ? 2 : (per_simd <= 11000.0 / 1024.0 ? 3 : 4);
+}
+__host__ __device__ inline bool async_size_in_range(long items, long simds = 1024) {
+    const double per_simd = (double)items / (double)(simds > 0 ? simds : 1);
+    return per_simd >= (double)kAsyncMinItems / 1024.0 && per_simd <= (double)kAsyncMaxItems / 1024.0;
+}
 // Finisher roles (round 5, second form).  One more wave per SIMD that does nothing but finish tiles: the wave that
 // completes a tile appends two entries to its group's finish ring - the tile's TARGETS (sums, priors, ClippedAdam, draw,
 // Phi tables, the R waves' loss parts) and its GUIDES (alpha_pi, noise site, digamma tables): two chains that do not

@@ -479,7 +479,11 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         // tile.  BEAN_HIP_STEP=async switches it on, =pair off.
         const char* sm = getenv("BEAN_HIP_STEP");
         const long items = (long)d.n_tiles * s->n_reps;
-        const bool on = sm ? !strcmp(sm, "async") : (items >= kAsyncMinItems && items <= kAsyncMaxItems);
+        int dev_ = 0, n_cu_ = 256;
+        if (hipGetDevice(&dev_) != hipSuccess || hipDeviceGetAttribute(&n_cu_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess)
+            n_cu_ = 256;
+        (void)hipGetLastError();
+        const bool on = sm ? !strcmp(sm, "async") : async_size_in_range(items, 4l * n_cu_);
         c->async_step = on && c->wave2 && !d.wide_targets && s->max_target_len <= 64 && s->n_sample_covariates == 0 &&
                         !c->fused_step && !c->tile_svi &&
                         (s->family == BEAN_FAMILY_MIXTURE_NORMAL || s->family == BEAN_FAMILY_NORMAL) && !is_survival(*s);
@@ -1496,7 +1500,7 @@ static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncAr
         HIP_OK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         if (per_cu < 1) return fail("k_svi_async does not fit on a compute unit (LDS " + std::to_string(lds) + " bytes)");
         // the same number of waves on every SIMD (four per CU): async_waves_per_simd, within what fits
-        int k = async_waves_per_simd((long)d.n_tiles * d.R);
+        int k = async_waves_per_simd((long)d.n_tiles * d.R, 4l * n_cu);
         if (k > per_cu / 4) k = per_cu / 4;
         c->async_blocks = k >= 1 ? k * 4 * n_cu : per_cu * n_cu / 8 * 8;
         // finisher roles: one more wave per SIMD that only finishes tiles, where there is room for it and the item waves
