@@ -65,6 +65,91 @@ def _scale_pi(pi, guide_acc, fitted_noise_logit=None):
     return scaled if fitted_noise_logit is None else _add_noise_to_pi(scaled, fitted_noise_logit)
 
 
+def _fitted_columns(P, sd_is_fitted: bool, covariates: Optional[List[str]]) -> pd.DataFrame:
+    """One row per target: posterior mean / spread of mu, its z-score, the fitted sd, and - with sample covariates - the
+    covariate-shifted copies of the three (variances add)."""
+    loc = P["mu_loc"]
+    if loc.dim() not in (1, 2):
+        raise ValueError(f'`mu_loc` has invalid shape of {loc.shape}')
+    first = (lambda arr: arr[:, 0]) if loc.dim() == 2 else (lambda arr: arr)
+    centre, spread = first(_np(loc)), first(_np(P["mu_scale"]))
+    table = {"mu": centre, "mu_sd": spread, "mu_z": centre / spread}
+    if sd_is_fitted:
+        table["sd"] = first(_np(P["sd_loc"].detach().exp()))
+    if covariates is not None:
+        assert "mu_cov_loc" in P and "mu_cov_scale" in P, P.keys()
+        shift, shift_sd = _np(P["mu_cov_loc"]), _np(P["mu_cov_scale"])
+        for i, name in enumerate(covariates):
+            m = centre + shift[i]
+            s_ = np.sqrt(spread**2 + shift_sd[i] ** 2)
+            table.update({f"mu_{name}": m, f"mu_sd_{name}": s_, f"mu_z_{name}": m / s_})
+    return pd.DataFrame(table)
+
+
+def _rescale_by_control_fit(table: pd.DataFrame, negctrl_params, sd_is_fitted: bool,
+                            covariates: Optional[List[str]]) -> None:
+    """`_scaled` columns: the targets' posteriors in units of the common negative-control distribution (a separate
+    ControlNormal fit: its mean and, when sd is fitted, its sd).  In place."""
+    print("Normalizing with common negative control distribution")
+    centre0 = _np(negctrl_params["mu_loc"]).mean()
+    unit = _np(negctrl_params["sd_loc"].detach().exp()) if sd_is_fitted else 1.0
+    print(f"Fitted mu0={centre0}" + (f", sd0={unit}." if sd_is_fitted else ""))
+    table["mu_scaled"] = (table["mu"].values - centre0) / unit
+    table["mu_sd_scaled"] = table["mu_sd"].values / unit
+    table["mu_z_scaled"] = table.mu_scaled / table.mu_sd_scaled
+    if sd_is_fitted:
+        table["sd_scaled"] = table["sd"].values / unit
+    table["novl_scaled"] = get_novl(table, "mu_scaled", "mu_sd_scaled")
+    for name in covariates or ():
+        table[f"mu_{name}_scaled"] = (table[f"mu_{name}"] - centre0) / unit
+        table[f"mu_sd_{name}_scaled"] = table[f"mu_sd_{name}"] / unit
+        table[f"mu_z_{name}_scaled"] = table[f"mu_{name}_scaled"] / table["mu_sd_scaled"]
+
+
+def _ranked(table: pd.DataFrame, z_col: str) -> pd.DataFrame:
+    """Rows by decreasing |z| (the reference's order: argsort of -|z|, missing values as pandas places them)."""
+    return table.iloc[(-table[z_col].abs()).argsort()]
+
+
+def _calibrated_by_negatives(table: pd.DataFrame, negatives, covariates: Optional[List[str]], from_scaled: bool) -> pd.DataFrame:
+    """`_adj` columns: posterior spreads stretched by the spread of the negative-control VARIANTS' z-scores (a zero-mean
+    normal fitted to them), then credible intervals and the |z| order.  Fewer than ten negatives: no calibration."""
+    if len(negatives) < 10:
+        print("Cannot adjust confidence by negative control due to too small number "
+              f"({len(negatives)}) of negatives.")
+        return _ranked(add_credible_interval(table, "mu", "mu_sd"), "mu_z")
+    controls = table.iloc[negatives]
+    if "mu_z_scaled" in controls.columns:
+        print("Using mu_z_scaled for normalization input..")
+        z_centre, z_spread = norm.fit(controls.mu_z_scaled, floc=0)
+    else:
+        z_centre, z_spread = norm.fit(controls.mu_z, floc=0)
+    pick = (lambda base: base + "_scaled") if from_scaled else (lambda base: base)
+    table = adjust_normal_params_by_control(table, z_spread, suffix="_adj", mu_adjusted_col=pick("mu"),
+                                            mu_sd_adjusted_col=pick("mu_sd"), mu0=z_centre)
+    table = _ranked(add_credible_interval(table, "mu_adj", "mu_sd_adj"), "mu_z_adj")
+    for name in covariates or ():
+        table = adjust_normal_params_by_control(table, z_spread, suffix=f"_{name}_adj",
+                                                mu_adjusted_col=pick(f"mu_{name}"), mu_sd_adjusted_col=pick(f"mu_sd_{name}"))
+        table = add_credible_interval(table, f"mu_{name}_adj", f"mu_sd_{name}_adj")
+    return table
+
+
+def _guide_editing_columns(guide_info_df: pd.DataFrame, P, guide_acc) -> None:
+    """The sgRNA table's accessibility columns (in place): the fitted editing rate of every guide - the edited share of
+    its `alpha_pi` - scaled by accessibility as the model scales it."""
+    if guide_acc is None:
+        return
+    if "alpha_pi" in P.keys():
+        conc = _np(P["alpha_pi"])
+        edited_share = conc[..., 1:].sum(axis=1) / conc.sum(axis=1)
+    else:
+        edited_share = 1.0
+    logit_noise = _np(P["noise_scale"]) if "noise_scale" in P.keys() else None
+    guide_info_df.insert(1, "accessibility", guide_acc)
+    guide_info_df.insert(2, "scaled_edit_eff", _scale_pi(edited_share, guide_acc, fitted_noise_logit=logit_noise))
+
+
 def write_result_table(
     target_info_df: pd.DataFrame,
     guide_info_df: pd.DataFrame,
@@ -82,90 +167,22 @@ def write_result_table(
     is_survival_screen: bool = False,
 ) -> Union[pd.DataFrame, None]:
     """Combine target information and fitted scores into the element table (written
-    or returned) and write the sgRNA table (``bean/model/readwrite.py:49-215``)."""
-    P = param_hist_dict
-    ndim = P["mu_loc"].dim()
-    if ndim not in (1, 2):
-        raise ValueError(f'`mu_loc` has invalid shape of {P["mu_loc"].shape}')
-    col = (lambda a: a[:, 0]) if ndim == 2 else (lambda a: a)
-    mu, mu_sd = col(_np(P["mu_loc"])), col(_np(P["mu_scale"]))
-    cols = {"mu": mu, "mu_sd": mu_sd, "mu_z": mu / mu_sd}
-    sd = None
-    if sd_is_fitted:
-        sd = col(_np(P["sd_loc"].detach().exp()))
-        cols["sd"] = sd
-    if sample_covariates is not None:
-        assert "mu_cov_loc" in P and "mu_cov_scale" in P, P.keys()
-        cov_loc, cov_scale = _np(P["mu_cov_loc"]), _np(P["mu_cov_scale"])
-        for i, name in enumerate(sample_covariates):
-            cols[f"mu_{name}"] = mu + cov_loc[i]
-            cols[f"mu_sd_{name}"] = np.sqrt(mu_sd**2 + cov_scale[i] ** 2)
-            cols[f"mu_z_{name}"] = cols[f"mu_{name}"] / cols[f"mu_sd_{name}"]
-    fit_df = pd.DataFrame(cols)
-
+    or returned) and write the sgRNA table (``bean/model/readwrite.py:49-215``: same arguments, columns, row order
+    and files; the steps are the helpers above)."""
+    fitted = _fitted_columns(param_hist_dict, sd_is_fitted, sample_covariates)
     if negctrl_params is not None:
-        print("Normalizing with common negative control distribution")
-        mu0 = _np(negctrl_params["mu_loc"]).mean()
-        sd0 = _np(negctrl_params["sd_loc"].detach().exp()) if sd_is_fitted else 1.0
-        print(f"Fitted mu0={mu0}" + (f", sd0={sd0}." if sd_is_fitted else ""))
-        fit_df["mu_scaled"] = (mu - mu0) / sd0
-        fit_df["mu_sd_scaled"] = mu_sd / sd0
-        fit_df["mu_z_scaled"] = fit_df.mu_scaled / fit_df.mu_sd_scaled
-        if sd_is_fitted:
-            fit_df["sd_scaled"] = sd / sd0
-        fit_df["novl_scaled"] = get_novl(fit_df, "mu_scaled", "mu_sd_scaled")
-        if sample_covariates is not None:
-            for name in sample_covariates:
-                fit_df[f"mu_{name}_scaled"] = (fit_df[f"mu_{name}"] - mu0) / sd0
-                fit_df[f"mu_sd_{name}_scaled"] = fit_df[f"mu_sd_{name}"] / sd0
-                fit_df[f"mu_z_{name}_scaled"] = fit_df[f"mu_{name}_scaled"] / fit_df["mu_sd_scaled"]
-
-    fit_df = pd.concat([target_info_df.reset_index(), fit_df.reset_index(drop=True)], axis=1)
-
-    by_abs_z = lambda df, c: df.iloc[(-df[c].abs()).argsort()]
-    scaled_inputs = "negctrl" in P.keys()  # never true for a param store (kept as in the reference)
+        _rescale_by_control_fit(fitted, negctrl_params, sd_is_fitted, sample_covariates)
+    element = pd.concat([target_info_df.reset_index(), fitted.reset_index(drop=True)], axis=1)
     if adjust_confidence_by_negative_control:
         assert adjust_confidence_negatives is not None
-        if len(adjust_confidence_negatives) < 10:
-            print("Cannot adjust confidence by negative control due to too small number "
-                  f"({len(adjust_confidence_negatives)}) of negatives.")
-            fit_df = by_abs_z(add_credible_interval(fit_df, "mu", "mu_sd"), "mu_z")
-        else:
-            ncvar = fit_df.iloc[adjust_confidence_negatives]
-            if "mu_z_scaled" in ncvar.columns:
-                print("Using mu_z_scaled for normalization input..")
-                z_mean, z_std = norm.fit(ncvar.mu_z_scaled, floc=0)
-            else:
-                z_mean, z_std = norm.fit(ncvar.mu_z, floc=0)
-            fit_df = adjust_normal_params_by_control(
-                fit_df, z_std, suffix="_adj",
-                mu_adjusted_col="mu_scaled" if scaled_inputs else "mu",
-                mu_sd_adjusted_col="mu_sd_scaled" if scaled_inputs else "mu_sd",
-                mu0=z_mean,
-            )
-            fit_df = by_abs_z(add_credible_interval(fit_df, "mu_adj", "mu_sd_adj"), "mu_z_adj")
-            if sample_covariates is not None:
-                for name in sample_covariates:
-                    fit_df = adjust_normal_params_by_control(
-                        fit_df, z_std, suffix=f"_{name}_adj",
-                        mu_adjusted_col=f"mu_{name}_scaled" if scaled_inputs else f"mu_{name}",
-                        mu_sd_adjusted_col=f"mu_sd_{name}_scaled" if scaled_inputs else f"mu_sd_{name}",
-                    )
-                    fit_df = add_credible_interval(fit_df, f"mu_{name}_adj", f"mu_sd_{name}_adj")
+        # (the reference asks the PARAMETER STORE for a "negctrl" key, which it never has: the `_adj` columns always
+        # derive from the unscaled mu / mu_sd - SURVEY.md Appendix C item 4; kept, and pinned by the reference's own run)
+        element = _calibrated_by_negatives(element, adjust_confidence_negatives, sample_covariates,
+                                           from_scaled="negctrl" in param_hist_dict.keys())
     else:
-        fit_df = by_abs_z(add_credible_interval(fit_df, "mu", "mu_sd"), "mu_z")
-
-    # sgRNA table
-    if "alpha_pi" in P.keys():
-        a_fitted = _np(P["alpha_pi"])
-        pi = a_fitted[..., 1:].sum(axis=1) / a_fitted.sum(axis=1)
-    else:
-        pi = 1.0
-    if guide_acc is not None:
-        guide_info_df.insert(1, "accessibility", guide_acc)
-        noise = _np(P["noise_scale"]) if "noise_scale" in P.keys() else None
-        guide_info_df.insert(2, "scaled_edit_eff", _scale_pi(pi, guide_acc, fitted_noise_logit=noise))
+        element = _ranked(add_credible_interval(element, "mu", "mu_sd"), "mu_z")
+    _guide_editing_columns(guide_info_df, param_hist_dict, guide_acc)
     guide_info_df.to_csv(f"{prefix}bean_sgRNA_result.{model_label}{suffix}.csv")
     if return_result:
-        return fit_df
-    fit_df.to_csv(f"{prefix}bean_element_result.{model_label}{suffix}.csv")
+        return element
+    element.to_csv(f"{prefix}bean_element_result.{model_label}{suffix}.csv")
