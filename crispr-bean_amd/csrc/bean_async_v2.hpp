@@ -699,6 +699,14 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
             }
         }
         if (fin_s >= 0) {
+#ifdef BEAN_ASYNC_STAMP
+            // (a finish stamps the row of its tile's replicate 0, whoever runs it: words 4 / 5 of the finish table = start /
+            // published of the targets' part - or of the whole finish - 6 / 7 of the guides' part; words 0 - 3 its phases)
+            st_row = nullptr;
+            if (a.stamps && fin_s >= kAsyncStampStep0 && fin_s < kAsyncStampStep0 + kAsyncStampSteps)
+                st_row = a.stamps + ((long)(fin_s - kAsyncStampStep0) * ((long)((n_tiles + 7) / 8 * 8) * R) + (long)fin_tile * R) * 8;
+            BEAN_ASYNC_TF(fin_part == 2 ? 6 : 4);
+#endif
             const unsigned long long step = a.step0 + (unsigned long long)fin_s, slot = a.slot0 + (unsigned long long)fin_s;
             // (the tile's next step waits for this chain: it goes first on its SIMD)
             if (BEAN_ASYNC_PRIO) __builtin_amdgcn_s_setprio(3);
@@ -710,7 +718,7 @@ void k_svi_async(const DevArgs* cp, int R, int n_tiles, AsyncArgs a) {
                 if (fin_part & 1) __hip_atomic_store(a.done + 2 * fin_tile, fin_s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (fin_part & 2) __hip_atomic_store(a.done + 2 * fin_tile + 1, fin_s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            BEAN_ASYNC_T(3);
+            BEAN_ASYNC_TF(fin_part == 2 ? 7 : 5);
         }
         __syncthreads();  // (the next item restages the wave's LDS)
     }
