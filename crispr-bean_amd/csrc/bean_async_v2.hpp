@@ -28,7 +28,9 @@
 // between an item's last stores and the wait for them (the queue atomic under the store drain): 48.8 against 48.4 us at
 // 50k guides, 57.6 against 57.9 at 62.5k - nothing.  A table of every tile's first target, target count and offsets
 // (one load at the head of a finish instead of two dependent lookups, the boundary counters asked before DevArgs have
-// arrived): 48.67 against 48.74, 58.06 against 58.2 - nothing.  In the finish: the boundary counters, the R
+// arrived): 48.67 against 48.74, 58.06 against 58.2 - nothing.  A 168-register build (three waves per SIMD: what the
+// grids with finisher roles run; 137 - 141 VGPRs, nothing spilled, where the 128-register build spills 3 - 11): 53.5
+// against 49.0 and 63.0 against 58.0 - slower, as the 237-register build was.  In the finish: the boundary counters, the R
 // waves' loss parts (one word per lane) and the guides' state requested in one batch at the top and the guides' part
 // moved in front of the targets' - 18.8 -> 21.2 us per finish (more values live across the chain, 36 B more scratch).
 // A 256-register build for the two-waves-per-SIMD grids whose bin loop takes two bins per pass (four lgamma / digamma
