@@ -97,10 +97,10 @@ def test_async_finisher_roles(monkeypatch, blocks, fin, split):
 
 
 def test_async_metric_shape_long(monkeypatch):
-    """The metric shape over a few hundred steps: the hand-overs under full load (every wave slot of the chip in use,
+    """The metric shape over a whole fit of the reference's default length: the hand-overs under full load (every wave slot of the chip in use,
     finishing waves of one step beside the guide waves of the next, rewritten tables read across XCDs)."""
     data = make_sorting_variant_screen(50000, 5, seed=79)
-    _same(monkeypatch, "MixtureNormal", data, 400, chunks=[100, 100, 100, 100], resume=True)
+    _same(monkeypatch, "MixtureNormal", data, 2000, chunks=[100] * 20, resume=True)  # a whole `bean run` fit: 2 000 steps
 
 
 def test_async_config4_shard_under_full_load(monkeypatch):
