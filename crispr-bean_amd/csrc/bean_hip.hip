@@ -1529,7 +1529,7 @@ static int launch_svi_async_t(bean_hip_ctx* c, hipStream_t stream, const AsyncAr
     // 48.5 / 51.3 us per step, 56k 53.2 / 53.3, 62.5k 59.4 / 58.8, 68.75k 65.5 / 64.4, 125k 97.0 / 95.7)
     a.fin_split = (double)d.n_tiles * d.R / (double)(c->async_blocks > 0 ? c->async_blocks : 1) < 2.15 ? 1 : 0;
     if (const char* e = getenv("BEAN_HIP_ASYNC_SPLIT")) a.fin_split = atoi(e) != 0;  // experiments
-    if (c->async_fin_blocks != 0 && a.n_steps < 8000 && d.n_tiles <= 8 * 65535) {
+    if (c->async_fin_blocks != 0 && a.fring_stride > 0 && d.n_tiles <= 8 * 65535) {
         fin_blocks = c->async_fin_blocks < 0 ? 0 : c->async_fin_blocks;
         const int tiles8 = (d.n_tiles + 7) / 8 * 8;
         if (fin_blocks > tiles8) fin_blocks = tiles8;  // (no more finishers than tiles)
@@ -1571,7 +1571,8 @@ static int launch_svi_async(bean_hip_ctx* c, hipStream_t stream, uint64_t step0,
     // [8 x stride] queue | abort word (a line of its own) | [8 x stride] finish-ring heads | [8 x stride] tails | done[n_tiles]:
     // zeroed by every call; behind them the finish rings (n_steps x the group's tiles, zeroed when roles are on)
     const size_t ws_ints = (size_t)25 * kAsyncQueueStride + (size_t)2 * d.n_tiles;
-    const size_t fring_stride = (size_t)2 * ((d.n_tiles + 7) / 8) * n_steps;
+    // (finish rings only for calls short enough to have finisher roles: a ring entry holds the step in 14 bits)
+    const size_t fring_stride = n_steps < 8000 ? (size_t)2 * ((d.n_tiles + 7) / 8) * n_steps : 0;
     const size_t need_ints = ws_ints + 8 * fring_stride;
     if (need_ints > c->async_ws_ints) {
         if (c->async_ws) (void)hipFree(c->async_ws);
