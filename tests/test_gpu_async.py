@@ -54,7 +54,8 @@ def test_async_is_bitwise_the_pair_path(monkeypatch, n_guides, n_reps, gpt):
 
 @pytest.mark.parametrize("steps,chunks,resume", [(1, None, False), (2, None, False), (3, None, True), (150, None, False),
                                                  (131, [1, 2, 64, 64], True), (131, [1, 2, 64, 64], False),
-                                                 (300, [100, 100, 100], True)])
+                                                 (300, [100, 100, 100], True),
+                                                 (8300, None, False)])  # (one call too long for finisher roles: no rings)
 def test_async_step_counts_and_windows(monkeypatch, steps, chunks, resume):
     data = make_sorting_variant_screen(2500, 3, seed=77, guides_per_target=5)
     _same(monkeypatch, "MixtureNormal", data, steps, chunks=chunks, resume=resume)
