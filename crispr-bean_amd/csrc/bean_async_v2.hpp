@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void k_step_sizes(DevArgs c, unsigned long lon
 }
 
 // Everything the launch needs, in ONE small launch in front of it: the queue counters, the abort word, the
-// completed-step words and the arrival counters at zero (the latter return to zero by themselves unless an earlier
-// launch gave up), the ClippedAdam step sizes of the call's updates (the device's exp / pow, adam_coef: every path holds
+// completed-step words and the arrival counters at zero (they run on through a call: a multiple of R arrivals closes a
+// tile's step), the ClippedAdam step sizes of the call's updates (the device's exp / pow, adam_coef: every path holds
 // the same float32 values), DevArgs as this kernel received them copied to global memory for the out-of-line pieces, and
 // the step counters as n {guide, k_param} pairs would LEAVE them - k_svi_async does not read them; the pair path, the loss
 // finalize and a later resume continue from there.
@@ -301,16 +301,11 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
         int* const bl = c.bnd_ctr + (left_str ? tile - 1 : tile);
         int* const br = c.bnd_ctr + tile;
         int ol = 0, orr = 0;
+        // (running counters, as the tiles': two arrivals per boundary and step, the odd one is the second)
         if (left_str) ol = __hip_atomic_fetch_add(bl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (right_str) orr = __hip_atomic_fetch_add(br, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left_str && ol == 1) {
-            own_left = 1;
-            __hip_atomic_store(bl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (right_str && orr == 1) {
-            own_right = 1;
-            __hip_atomic_store(br, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (left_str && (ol & 1)) own_left = 1;
+        if (right_str && (orr & 1)) own_right = 1;
     }
     own_left = __builtin_amdgcn_readfirstlane(own_left);
     own_right = __builtin_amdgcn_readfirstlane(own_right);
@@ -532,11 +527,11 @@ __device__ BEAN_ASYNC_INLINE int2 async_guide_item(const DevArgs* cp, unsigned l
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int last = 0;
     if (lane == 0) {
+        // (the counter runs on through the call - k_async_head zeroed it - and is never reset: the arrivals of a step
+        // cannot begin before all R of the step before have been counted, so a multiple of R closes a step, and there is
+        // no store whose order against a later step's atomics would matter)
         const int old = __hip_atomic_fetch_add(c.tile_ctr + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == R - 1) {
-            last = 1;
-            __hip_atomic_store(c.tile_ctr + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (old % R == R - 1) last = 1;
     }
     last = __builtin_amdgcn_readfirstlane(last);
     (void)t0;
