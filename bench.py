@@ -265,7 +265,10 @@ def roofline_object(config, leg, guides, std_size):
         "kernel_ms": k_ms,
         "kernel_launches_timed": k_n,
         **({"kernel_ms_is": "per SVI step: one launch of k_svi_async runs a whole report window (100 steps); "
-                            "kernel_launches_timed counts the steps the timed launches covered"}
+                            "kernel_launches_timed counts the steps the timed launches covered",
+            "compare_with_earlier_rounds": "this kernel is the WHOLE step (guide work + per-target / per-guide finish); rounds "
+                                           "1 - 4 priced k_guide_wave2 alone (round 4: 17.01 MB / 44.2 us = 0.048, 43 - 44 us of a "
+                                           "55.2 us step, whose whole-step figure is 17.01 MB / 55.2 us = 0.0385): compare `whole_step`"}
            if kernel_name == "k_svi_async" else {}),
         "kernel_resources": kernel_resources(kernel_variant, lds_dyn),
         "measured_on": f"the weak leg's screen ({guides} guides on this rank)",
