@@ -30,7 +30,7 @@ eng.close()
 sizes = [int(x) for x in sys.argv[1:]] or [50000, 62500]
 res = {}
 for G in sizes:
-    for acc in ("0",):
+    for acc in (os.environ.get("ACC", "0"),):
         for mode in ["pair", "async"] + [f"async@{b}" for b in os.environ.get("ASYNC_BLOCKS", "").split(",") if b]:
             env = dict(os.environ, BEAN_HIP_STEP=mode.split("@")[0])
             if "@" in mode:
