@@ -51,6 +51,12 @@ struct bean_hip_ctx {
     bool tiling_wide;  // more alleles per guide than this build's kAMax: bean_tiling_wide.hpp
     int tiling_rep_w;  // ... with this many waves per workgroup
     bool tiling_rep;   // tiling families, default: k_guide_tiling_rep, the replicates of a guide share a wave (bean_tiling_v2.hpp)
+    // tiling: the allele tables (tabP, tabPmu, tabPy, mu_a, sig_a) belong to the draw that is on the device.  A PREP launch
+    // of k_param<..., 3> with allele blocks leaves them so (round 5); any other PREP launch leaves a new draw and stale
+    // tables, and launch_guide runs k_allele first.  BEAN_HIP_ALLELE=split: k_param never has allele blocks (A/B).
+    bool alleles_fresh;
+    bool allele_blocks;
+    bool resume_head_fresh;  // the resume graphs were captured with fresh tables at their head (their first node is a guide launch)
     double* gsum_ws;  // library-owned normaliser buffer (replaced by BEAN_BUF_XCHG_GSUM when bound)
     double* sq_ws;    // library-owned projection sums (replaced by BEAN_BUF_XCHG_SQ when bound)
     double* cov_sum_ws;  // library-owned covariate gradient sums (replaced by BEAN_BUF_XCHG_COV when bound)
@@ -343,6 +349,12 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     c->tile_ready = false;
     c->tile_tab = nullptr;
     c->live_slots = nullptr;
+    c->alleles_fresh = false;
+    c->resume_head_fresh = false;
+    {
+        const char* am = getenv("BEAN_HIP_ALLELE");
+        c->allele_blocks = !(am && !strcmp(am, "split"));
+    }
     c->n_tiles = c->tile_ntm = c->tile_gbm = c->tile_blocks = 0;
     c->step_sizes = nullptr;
     c->step_sizes_cap = 0;
@@ -505,7 +517,9 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
     // arrival counters of the fused step kernel: per tile and per tile boundary (ints, zero between launches)
     const uint64_t n_ctr = c->wave2 ? ((uint64_t)d.n_tiles + 7) / 8 * 8 + 2 + 3 * B + 2 : 0;
     const uint64_t n_kacc = (s->flags & BEAN_FLAG_SCALE_BY_ACC) ? G : 0;
-    const uint64_t n_dbl = n_kacc + n_ctr + 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
+    // tiling, k_param's allele blocks: arrival counters and go flags, one 128-byte line each (kAlleleCtrLines)
+    const uint64_t n_actr = (!c->wave2 && is_tiling(*s)) ? (uint64_t)kAlleleCtrLines * 16 : 0;
+    const uint64_t n_dbl = n_actr + n_kacc + n_ctr + 3 * B * n_tab + B + 4 * T + n_part * G + 2 * G + 2 * A1 * G + 2 + 8 + kLossWords + n_surv +
                            n_split + n_dbg + n_trow + 3 * n_lpart + n_dgq + n_dgq_t + 2 * n_cov + 2 * Rr + 1;
     c->workspace_bytes = n_dbl * 8;
     hipError_t e = hipMalloc(&c->workspace, c->workspace_bytes);
@@ -547,6 +561,11 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         w += n_ctr - 3 * B - 2;
         d.ue_z = w; w += 2 * B;
         d.ue_idx = (int*)w; w += B + 2;  // 2 B + 1 ints
+    }
+    if (n_actr) {  // (k_set_step zeroes tile_ctr[0 .. n_arrival_ctr))
+        d.tile_ctr = (int*)w;
+        d.n_arrival_ctr = (int)(2 * n_actr);
+        w += n_actr;
     }
     if (n_dbg) {
         d.dbg = (unsigned long long*)w; w += n_dbg;
@@ -707,6 +726,7 @@ extern "C" int bean_hip_prepare(bean_hip_ctx* c, void* stream_) {
     if (!c) return fail("bean_hip_prepare: null handle");
     if (check_bound(c, false, false)) return -1;
     c->resume_ok = false;  // (bean_hip.h: a prepare between two windows forbids a resume, in every family)
+    c->alleles_fresh = false;  // (tiling: the allele tables belong to no draw yet)
     hipStream_t stream = (hipStream_t)stream_;
     HIP_OK(hipMemsetAsync(c->d.const_acc, 0, kLossWords * sizeof(long long), stream));
     const long n = (long)c->d.R * c->d.G;
@@ -884,6 +904,27 @@ static void grid_param(const bean_hip_ctx* c, int& n_target_blocks, int& n_block
     n_blocks = n_target_blocks + guide_blocks;
 }
 
+// Allele blocks of a PREP launch of k_param on DevArgs d (tgrad as launched): its specialised tiling build (KIND 3), a
+// sorting screen, not switched off (BEAN_HIP_ALLELE=split; BEAN_HIP_PARAM_KIND=0 forces the generic kernel, which has none).
+static bool param_generic_only() {
+    static const bool g = getenv("BEAN_HIP_PARAM_KIND") && !strcmp(getenv("BEAN_HIP_PARAM_KIND"), "0");
+    return g;
+}
+static bool param_kind3(const DevArgs& d) {
+    return d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov && !d.lpart &&
+           d.trow_summed && !d.surv_q0lik && d.lpt == kLanesPerTargetNarrow;
+}
+static int param_allele_blocks(const bean_hip_ctx* c, const DevArgs& d) {
+    if (param_generic_only() || !param_kind3(d) || d.survival || !c->allele_blocks || d.n_live_slots <= 0 || !d.tile_ctr) return 0;
+    return (int)(((long)d.n_live_slots + kParamBlock - 1) / kParamBlock);
+}
+// what a PREP launch without exchanged gradients (the launches of bean_hip_svi_run / _resume) leaves
+static bool param_prep_leaves_alleles_fresh(const bean_hip_ctx* c) {
+    DevArgs d = c->d;
+    d.tgrad = nullptr;
+    return param_allele_blocks(c, d) > 0;
+}
+
 template <bool FINISH, bool ADAM, bool PREP>
 static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgrad = nullptr, bool cov_exchanged = false) {
     int ntb, nb;
@@ -901,10 +942,9 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
                        (d.dgq || d.family != kMixture) && d.tsum;
     const bool kind2 = d.survival && d.family == kMixture && !d.surv_q0lik && d.dgq && !d.tsum && !d.wide_targets && !d.tgrad &&
                        !d.n_cov && d.wrow && d.rows_v2 && !d.rrow && d.lpart && d.lpt == kLanesPerTargetNarrow;
-    const bool kind3 = d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov &&
-                       !d.lpart && d.trow_summed && !d.surv_q0lik && d.lpt == kLanesPerTargetNarrow;
+    const bool kind3 = param_kind3(d);
     // BEAN_HIP_PARAM_KIND=0 forces the generic build (the test that the specialised builds change nothing)
-    static const bool generic_only = getenv("BEAN_HIP_PARAM_KIND") && !strcmp(getenv("BEAN_HIP_PARAM_KIND"), "0");
+    const bool generic_only = param_generic_only();
     const int kind = generic_only ? 0 : (kind1 ? 1 : (kind2 ? 2 : (kind3 ? 3 : 0)));
     const bool prof = c->profile && c->profile_param && FINISH && PREP && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -914,7 +954,20 @@ static void launch_param(bean_hip_ctx* c, hipStream_t stream, const double* tgra
         c->ev.push_back(e0);
         c->ev.push_back(e1);
     }
-    const dim3 grid(nb), block(kParamBlock);
+    // allele blocks (k_param<..., 3>, sorting): k_allele's work as the tail of this grid
+    const int nab = (PREP && kind == 3) ? param_allele_blocks(c, d) : 0;
+    if (PREP) c->alleles_fresh = nab > 0;
+    if (nab > 0) {
+        // Dispatch order: edit blocks, `ahead` guide blocks, the allele blocks, the other guide blocks (DevArgs::q0_blk0,
+        // which the sorting tiling family does not use otherwise).  Measured at BASELINE config 3 (1 792 places for 469 +
+        // 1 563 + 753 blocks; us per step): the allele blocks last 146.5; behind the guide blocks that fill the first
+        // resident round (1 323) 148.0 (they poll on places the other guide blocks wait for); behind 531 of them 152.2;
+        // k_allele as a launch of its own 148.9.  BEAN_HIP_ALLELE_AHEAD: experiments.
+        static const int ahead_env = getenv("BEAN_HIP_ALLELE_AHEAD") ? atoi(getenv("BEAN_HIP_ALLELE_AHEAD")) : -1;
+        const int ngb = nb - ntb;
+        d.q0_blk0 = ahead_env >= 0 && ahead_env < ngb ? ahead_env : ngb;
+    }
+    const dim3 grid(nb + nab), block(kParamBlock);
 #define BEAN_LAUNCH_PARAM(K)                                                                                    \
     do {                                                                                                         \
         if (prof) hipExtLaunchKernelGGL((k_param<FINISH, ADAM, PREP, K>), grid, block, 0, stream, e0, e1, 0, d, ntb); \
@@ -1232,9 +1285,10 @@ static void launch_guide(bean_hip_ctx* c, hipStream_t stream) {
         launch_guide_survival_wave(c, stream);
         return;
     }
-    if (d.family == kMultiMixture) {  // allele-level tables of this step's draw
+    if (d.family == kMultiMixture) {  // allele-level tables of this step's draw, unless k_param's allele blocks left them
         const long n = d.n_live_slots;
-        if (n > 0) hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
+        if (n > 0 && !c->alleles_fresh) hipLaunchKernelGGL(k_allele, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d);
+        c->alleles_fresh = true;
     }
     if (c->tiling_rep) {
         launch_guide_tiling_rep(c, stream);
@@ -1382,8 +1436,10 @@ static void enqueue_fused(bean_hip_ctx* c, hipStream_t stream, uint64_t n, int f
 static int capture_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n, hipGraphExec_t* out, bool fused = false) {
     hipGraph_t graph = nullptr;
     HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    const bool fresh_was = c->alleles_fresh;  // (a capture runs nothing; these graphs begin with a PREP launch)
     if (fused) enqueue_fused(c, stream, n);
     else enqueue_pairs(c, stream, n);
+    c->alleles_fresh = fresh_was;
     hipError_t e = hipStreamEndCapture(stream, &graph);
     if (e != hipSuccess) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -1737,9 +1793,15 @@ extern "C" int bean_hip_svi_run(bean_hip_ctx* c, uint64_t seed, uint64_t first_s
             for (int k = 0; k < kmax; ++k)
                 if (rest & (1ull << k)) {
                     if (k < 2) enqueue_pairs(c, stream, 1ull << k);
-                    else HIP_OK(hipGraphLaunch(c->graphs[k], stream));
+                    else {
+                        HIP_OK(hipGraphLaunch(c->graphs[k], stream));
+                        c->alleles_fresh = true;  // (a graph of pairs ends with a guide launch)
+                    }
                 }
-            for (uint64_t i = 0; i < big; ++i) HIP_OK(hipGraphLaunch(c->graphs[kmax], stream));
+            for (uint64_t i = 0; i < big; ++i) {
+                HIP_OK(hipGraphLaunch(c->graphs[kmax], stream));
+                c->alleles_fresh = true;
+            }
             pairs = 0;
         }
         enqueue_pairs(c, stream, pairs);
@@ -1762,10 +1824,27 @@ static void enqueue_resume_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n
     launch_finalize(c, stream, 0, n, true);
 }
 
+// Replay of a resume graph: if it was captured with fresh allele tables at its head and they are not (cannot happen in
+// a resume chain - its last launch was a PREP k_param with allele blocks - but nothing else promises it), k_allele runs
+// first.  The graph ends with a PREP launch, i.e. in the state it was entered with.
+static int launch_resume_graph(bean_hip_ctx* c, hipGraphExec_t ge, hipStream_t stream) {
+    const DevArgs& d = c->d;
+    if (d.family == kMultiMixture && c->resume_head_fresh && !c->alleles_fresh && d.n_live_slots > 0)
+        hipLaunchKernelGGL(k_allele, dim3((unsigned)(((long)d.n_live_slots + 255) / 256)), dim3(256), 0, stream, d);
+    HIP_OK(hipGraphLaunch(ge, stream));
+    c->alleles_fresh = c->resume_head_fresh;
+    return 0;
+}
+
 static int capture_resume_pairs(bean_hip_ctx* c, hipStream_t stream, uint64_t n, hipGraphExec_t* out) {
     hipGraph_t graph = nullptr;
     HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    // the graph's first node is a guide launch: it is captured in the state a resume chain enters it with - behind a
+    // PREP launch of k_param (resume_head_state) - and a replay checks that state (launch_resume_graph)
+    const bool fresh_was = c->alleles_fresh;
+    c->alleles_fresh = c->resume_head_fresh;
     enqueue_resume_pairs(c, stream, n);
+    c->alleles_fresh = fresh_was;
     hipError_t e = hipStreamEndCapture(stream, &graph);
     if (e != hipSuccess) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -1828,6 +1907,7 @@ extern "C" int bean_hip_svi_resume(bean_hip_ctx* c, uint64_t seed, uint64_t firs
         while ((8ull << kmax) <= (uint64_t)graph_chunk && kmax < 8) ++kmax;
         if ((int)c->graphs_resume.size() != kmax + 1) {
             drop_graph(c);
+            c->resume_head_fresh = param_prep_leaves_alleles_fresh(c);
             for (int k = 0; k <= kmax; ++k) {
                 hipGraphExec_t ge = nullptr;
                 if (capture_resume_pairs(c, stream, 4ull << k, &ge)) {
@@ -1853,8 +1933,10 @@ extern "C" int bean_hip_svi_resume(bean_hip_ctx* c, uint64_t seed, uint64_t firs
         const uint64_t big = left >> (kmax + 2);
         const uint64_t rest = left - (big << (kmax + 2));
         for (int k = 0; k < kmax; ++k)
-            if (rest & (4ull << k)) HIP_OK(hipGraphLaunch(c->graphs_resume[k], stream));
-        for (uint64_t i = 0; i < big; ++i) HIP_OK(hipGraphLaunch(c->graphs_resume[kmax], stream));
+            if (rest & (4ull << k))
+                if (launch_resume_graph(c, c->graphs_resume[k], stream)) return -1;
+        for (uint64_t i = 0; i < big; ++i)
+            if (launch_resume_graph(c, c->graphs_resume[kmax], stream)) return -1;
         left = 0;
     }
     enqueue_resume_pairs(c, stream, left);
@@ -2095,7 +2177,12 @@ extern "C" int bean_hip_svi_run_exchanged(bean_hip_ctx* c, uint64_t seed, uint64
                 hipGraphExec_t ge = nullptr;
                 bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (ok) {
+                    // (tiling: a graph's first guide launch runs k_allele whatever ran before the graph - the update of an
+                    // exchanged step never leaves allele tables)
+                    const bool fresh_was = c->alleles_fresh;
+                    c->alleles_fresh = false;
                     for (uint64_t i = 0; ok && i < (2ull << k); ++i) ok = enqueue_exchanged_step(c, stream, false) == 0;
+                    c->alleles_fresh = fresh_was;
                     // the capture is ended whether or not a step failed inside it (enqueue_exchanged_step closes
                     // its RCCL group on every path); a partial graph is destroyed below
                     hipError_t e = hipStreamEndCapture(stream, &graph);
@@ -2118,6 +2205,7 @@ extern "C" int bean_hip_svi_run_exchanged(bean_hip_ctx* c, uint64_t seed, uint64
         for (int k = (int)c->graphs_xchg.size() - 1; k >= 0; --k)
             while (left > (2ull << k)) {  // strictly more: the last step stays outside the graphs
                 HIP_OK(hipGraphLaunch(c->graphs_xchg[k], stream));
+                c->alleles_fresh = false;  // (ends with an exchanged update)
                 left -= 2ull << k;
             }
     }

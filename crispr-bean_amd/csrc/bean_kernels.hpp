@@ -1289,6 +1289,93 @@ __device__ __forceinline__ void q0_draws_and_totals(const DevArgs& c, int gb, in
     }
 }
 
+// ------------------------------------------------- allele_slot_tables (k_allele, k_param's allele blocks)
+// Tiling: per allele slot (g, a >= 1): mu_a = sum of its edits' mu, sigma_a =
+// l2 norm of their sd (model.py:618-622) as a CSR gather, then the bin
+// probabilities and their derivatives.  Tables are laid out (B, A-1, G).
+// One allele slot (g, a1): shared by k_allele (one thread per slot of the screen) and by the head of
+// k_guide_tiling_rep (the slots of the workgroup's own guides).
+// COH == 2: the edits' draws are loaded at agent scope - the allele blocks of k_param (round 5) read what the edit blocks
+// of the SAME launch have just stored from other CUs (see coh_ld).
+template <int COH = 0>
+__device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int g) {
+    const int A1 = c.A - 1;
+    const long idx = slot_off(c, a1, g);
+    const long slot = (long)g * A1 + a1;
+    const bool valid = c.amask[(long)g * c.A + a1 + 1] != 0;
+    if (c.survival) {
+        // growth of the allele over the timepoints, exp((u_g + sum_e mu_e) t_b); masked alleles get
+        // probability 0 (survival_model.py:484-488, 561-567)
+        double mu = 0.0;
+        for (int k = c.a2e_ptr[slot]; k < c.a2e_ptr[slot + 1]; ++k) mu += c.mu_t[c.a2e_idx[k]];
+        c.mu_a[idx] = mu;
+        const double full = c.u_g[g] + mu;
+        for (int b = 0; b < c.B; ++b) {
+            const double tb = c.time[b];
+            const double P = valid ? exp(full * tb) : 0.0;
+            const long o = tab_off(c, b, a1, g);
+            c.tabP[o] = P;
+            c.tabPmu[o] = tb * P;
+            c.tabPy[o] = 0.0;
+        }
+        return;
+    }
+    double mu = 0.0, var = 0.0;
+    for (int k = c.a2e_ptr[slot]; k < c.a2e_ptr[slot + 1]; ++k) {
+        const int e = c.a2e_idx[k];
+        mu += coh_ld<COH>(c.mu_t + e);
+        const double sd = exp(coh_ld<COH>(c.y_t + e));
+        var += sd * sd;
+    }
+    const double sigma = sqrt(var);
+    c.mu_a[idx] = mu;
+    c.sig_a[idx] = sigma;
+    const bool live = valid && var > 0.0;  // masked alleles: probability 0, no gradient (utils.py:56-59,73-74)
+    const double inv = live ? 1.0 / sigma : 0.0;
+    // bins are sorted by their bounds (data_class.py:948-964), so a bin's lower edge is very often the
+    // previous bin's upper edge: its Phi / phi are reused instead of evaluated twice (same values)
+    double pz = 0.0, pch = 0.0, pfh = 0.0, pufh = 0.0;
+    bool have_prev = false;
+    for (int b = 0; b < c.B; ++b) {
+        double P = 0.0, dmu = 0.0, dsig = 0.0;
+        if (live) {
+            const double zh = c.z_hi[b], zl = c.z_lo[b];
+            double ch = 1.0, cl = 0.0, fh = 0.0, fl = 0.0, ufh = 0.0, ufl = 0.0;
+            if (!isinf(zl)) {
+                if (have_prev && zl == pz) {
+                    cl = pch;
+                    fl = pfh;
+                    ufl = pufh;
+                } else {
+                    const double u = (zl - mu) * inv;
+                    cl = norm_cdf(u);
+                    fl = norm_pdf(u);
+                    ufl = u * fl;
+                }
+            }
+            if (!isinf(zh)) {
+                const double u = (zh - mu) * inv;
+                ch = norm_cdf(u);
+                fh = norm_pdf(u);
+                ufh = u * fh;
+                pz = zh;
+                pch = ch;
+                pfh = fh;
+                pufh = ufh;
+                have_prev = true;
+            }
+            P = ch - cl;
+            dmu = -(fh - fl) * inv;
+            dsig = -(ufh - ufl) * inv;
+        }
+        const long o = tab_off(c, b, a1, g);
+        c.tabP[o] = P;
+        c.tabPmu[o] = dmu;
+        c.tabPy[o] = dsig;  // d/d sigma_a here (chain to y_e in k_param)
+    }
+}
+
+
 // -------------------------------------------------------------------- k_param
 // grid = n_target_blocks + n_guide_blocks (+ the q0 blocks of the survival families with a
 // Dirichlet-over-all-guides site), 256 threads; the roles' dispatch order: see `bid` below.
@@ -1297,8 +1384,31 @@ __device__ __forceinline__ void q0_draws_and_totals(const DevArgs& c, int gb, in
 // drops the other families' code: 121 -> <= 96 VGPRs without scratch (five instead of four resident
 // waves per SIMD, so the 1 026 blocks of a 62.5k-guide shard are one round, not one round and two blocks)
 // and less than half the instructions to fetch.  KIND 0: everything.
+// Allele blocks (round 5; KIND 3, sorting, PREP; n_allele_blocks > 0): the LAST n_allele_blocks blocks of the grid do
+// k_allele's work for the step this launch prepares - one thread per live allele slot - instead of a launch of their own
+// behind this one.  They need the draws of ALL the edit blocks: every edit block counts in (after its stores of mu_t /
+// y_t - agent scope - have completed), the edit block that counts in last raises the go flags, an allele block's first
+// thread polls one of them (bounded; the edit blocks are the first blocks of the grid, i.e. resident before any allele
+// block is dispatched) and the block then reads the draws at agent scope.  The allele block that leaves last zeroes
+// counters and flags for the next launch.  Same arithmetic as k_allele: same bits.
+// The words live in DevArgs::tile_ctr (tiling: kAlleleCtrLines lines of 128 bytes; k_set_step zeroes them): line 0 the edit
+// blocks' arrivals, line 1 the allele blocks', lines 2 ... the go flags - SIXTEEN copies in lines of their own, because
+// 753 blocks polling one word kept one memory channel busy for everybody (the first form: every block of the launch ran
+// ~1.5 x longer while the allele blocks polled; scripts/stamps_kp_tiling.py).
+constexpr int kAlleleGoFlags = 16;
+constexpr int kAlleleCtrLines = 2 + kAlleleGoFlags;
+constexpr int kAlleleSpinMax = 1 << 20;  // polls (~0.5 us each) before an allele block gives up: the step's loss reports NaN
 template <bool FINISH, bool ADAM, bool PREP, int KIND = 0>
-__global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_blocks) {
+#ifndef BEAN_KP3_WAVES
+#define BEAN_KP3_WAVES 1
+#endif
+// (-DBEAN_KP3_WAVES=7 holds KIND 3 to seven waves per SIMD - 72 VGPRs, what the build before the allele blocks took by
+// itself; with the allele blocks it takes 74, i.e. 1 536 places instead of 1 792 at BASELINE config 3: A/B)
+__global__ __launch_bounds__(kParamBlock) __attribute__((amdgpu_waves_per_eu(KIND == 3 ? BEAN_KP3_WAVES : 1)))
+void k_param(DevArgs c, int n_target_blocks) {
+    // (KIND 3: what the grid holds beyond the edit blocks and the guide blocks - kAMax lanes per guide - are allele blocks)
+    const int n_allele_blocks =
+        KIND == 3 ? (int)gridDim.x - n_target_blocks - (int)(((long)c.G * kAMax + kParamBlock - 1) / kParamBlock) : 0;
     if (KIND == 1) {
         __builtin_assume(c.lpt == kLanesPerTarget);
         __builtin_assume(!c.survival);
@@ -1341,6 +1451,52 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
         __builtin_assume(c.trow_summed != 0);
         __builtin_assume(!c.surv_q0lik);
     }
+    // (dispatch order: edit blocks, c.q0_blk0 guide blocks, the allele blocks, the other guide blocks - launch_param)
+    const int allele_blk0 = n_target_blocks + c.q0_blk0;
+    if (KIND == 3 && PREP && n_allele_blocks > 0 && (int)blockIdx.x >= allele_blk0 &&
+        (int)blockIdx.x < allele_blk0 + n_allele_blocks) {
+        const long idx = (long)((int)blockIdx.x - allele_blk0) * blockDim.x + threadIdx.x;
+        const int stamp_rec = (int)gridDim.x - n_allele_blocks + ((int)blockIdx.x - allele_blk0);  // behind the guide blocks' records
+        (void)stamp_rec;
+        BEAN_STAMP_RT(stamp_rec, 0);
+        const bool in = idx < c.n_live_slots;
+        const int sl = in ? c.live_slots[idx] : 0;  // a1 * G + g
+        {
+            // data the slot's chain begins with, asked for now (the loads behind the poll then find it in the caches)
+            const int a1 = sl / c.G, g = sl - a1 * c.G;
+            const long slot = (long)g * (c.A - 1) + a1;
+            const int k0 = c.a2e_ptr[slot], k1 = c.a2e_ptr[slot + 1];
+            const int e0 = k0 < k1 ? c.a2e_idx[k0] : 0;
+            const int am = c.amask[(long)g * c.A + a1 + 1];
+            asm volatile("" ::"v"(e0), "v"(am), "v"(k1));
+        }
+        if (threadIdx.x == 0) {
+            const int* const go = c.tile_ctr + 32 * (2 + ((int)blockIdx.x & (kAlleleGoFlags - 1)));
+            int spins = 0;
+            while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                if (++spins > kAlleleSpinMax) {
+                    const StepCtr cs = *c.ctrA;
+                    atomicAdd((unsigned long long*)(c.loss_acc + ((long)cs.slot * kLossSub) * kLossWords) + 2, 1ull);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        __syncthreads();
+        asm volatile("" ::: "memory");  // (nothing below is loaded before the poll has matched)
+        BEAN_STAMP_RT(stamp_rec, 1);
+        if (in) allele_slot_tables<2>(c, sl / c.G, sl % c.G);
+        __syncthreads();
+        BEAN_STAMP_RT(stamp_rec, 7);
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(c.tile_ctr + 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == n_allele_blocks - 1) {
+                for (int k = 0; k < kAlleleCtrLines; ++k)
+                    __hip_atomic_store(c.tile_ctr + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
     // Block roles, in role order: target blocks, guide blocks, (survival q0 site) q0 blocks.  The q0
     // blocks hold the kernel's longest chain (parameter update -> gamma draws -> block sums -> the last
     // one's totals, ~15 us at BASELINE config 5 against ~10 us of an alpha_pi guide block and ~5 us of a
@@ -1349,6 +1505,7 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     // ended: k_param 33 us.  As blocks of their own that waited for a guide block's flag: 35 us.  Without a
     // q0 site the order of guide and target blocks makes no difference: measured on configs 1 and 3.)
     unsigned bid = blockIdx.x;
+    if (KIND == 3 && PREP && n_allele_blocks > 0 && (int)blockIdx.x >= allele_blk0) bid -= (unsigned)n_allele_blocks;
     if (c.q0_blocks) {
         const unsigned ntb = (unsigned)n_target_blocks, nq0 = (unsigned)c.n_gamma_blocks, ngd = (unsigned)c.q0_blk0;
         if (blockIdx.x < nq0) bid = ntb + ngd + blockIdx.x;
@@ -1437,6 +1594,8 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
     }
     if ((int)bid < n_target_blocks) {
         // ------------------------------------------------ target part
+        // (with allele blocks behind them the edit blocks head the launch's longest chain: first on their SIMDs)
+        if (KIND == 3 && PREP && n_allele_blocks > 0) __builtin_amdgcn_s_setprio(2);
         int t;
         bool active;
         double gmu = 0.0, gy = 0.0, tab_mu = 0.0, tab_y = 0.0;
@@ -1576,8 +1735,9 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
                 const double y = tgt_draw(pf[2], eps2, pf[3]);
                 c.eps_mu[t] = eps1;
                 c.eps_sd[t] = eps2;
-                c.mu_t[t] = mu;
-                c.y_t[t] = y;
+                // (KIND 3: written through - the allele blocks of this launch read them from other CUs)
+                coh_st<KIND == 3 ? 2 : 0>(c.mu_t + t, mu);
+                coh_st<KIND == 3 ? 2 : 0>(c.y_t + t, y);
                 if (c.eps_mu_out) {
                     c.eps_mu_out[t] = eps1;
                     c.eps_sd_out[t] = eps2;
@@ -1631,6 +1791,18 @@ __global__ __launch_bounds__(kParamBlock) void k_param(DevArgs c, int n_target_b
             }
         }
         BEAN_STAMP_KP(4);
+        if (KIND == 3 && PREP && n_allele_blocks > 0) {
+            // this edit block's draws are out: count in for the allele blocks
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int old = __hip_atomic_fetch_add(c.tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == n_target_blocks - 1)  // the last edit block: every draw is out
+                    for (int k = 0; k < kAlleleGoFlags; ++k)
+                        __hip_atomic_store(c.tile_ctr + 32 * (2 + k), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            BEAN_STAMP_RT(bid, 4);
+        }
     } else if (c.family == kMultiMixture) {
         const int guide_block = (int)bid - n_target_blocks;
         if (c.wide_alleles) param_guide_tiling_wide<FINISH, ADAM, PREP>(c, guide_block, s_prep, ak, loss_fin);
@@ -2739,88 +2911,7 @@ void k_guide_survival(DevArgs c) {
 
 #endif  // BEAN_AB_KERNELS
 // ------------------------------------------------------------------- k_allele
-// Tiling: per allele slot (g, a >= 1): mu_a = sum of its edits' mu, sigma_a =
-// l2 norm of their sd (model.py:618-622) as a CSR gather, then the bin
-// probabilities and their derivatives.  Tables are laid out (B, A-1, G).
-// One allele slot (g, a1): shared by k_allele (one thread per slot of the screen) and by the head of
-// k_guide_tiling_rep (the slots of the workgroup's own guides).
-__device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int g) {
-    const int A1 = c.A - 1;
-    const long idx = slot_off(c, a1, g);
-    const long slot = (long)g * A1 + a1;
-    const bool valid = c.amask[(long)g * c.A + a1 + 1] != 0;
-    if (c.survival) {
-        // growth of the allele over the timepoints, exp((u_g + sum_e mu_e) t_b); masked alleles get
-        // probability 0 (survival_model.py:484-488, 561-567)
-        double mu = 0.0;
-        for (int k = c.a2e_ptr[slot]; k < c.a2e_ptr[slot + 1]; ++k) mu += c.mu_t[c.a2e_idx[k]];
-        c.mu_a[idx] = mu;
-        const double full = c.u_g[g] + mu;
-        for (int b = 0; b < c.B; ++b) {
-            const double tb = c.time[b];
-            const double P = valid ? exp(full * tb) : 0.0;
-            const long o = tab_off(c, b, a1, g);
-            c.tabP[o] = P;
-            c.tabPmu[o] = tb * P;
-            c.tabPy[o] = 0.0;
-        }
-        return;
-    }
-    double mu = 0.0, var = 0.0;
-    for (int k = c.a2e_ptr[slot]; k < c.a2e_ptr[slot + 1]; ++k) {
-        const int e = c.a2e_idx[k];
-        mu += c.mu_t[e];
-        const double sd = exp(c.y_t[e]);
-        var += sd * sd;
-    }
-    const double sigma = sqrt(var);
-    c.mu_a[idx] = mu;
-    c.sig_a[idx] = sigma;
-    const bool live = valid && var > 0.0;  // masked alleles: probability 0, no gradient (utils.py:56-59,73-74)
-    const double inv = live ? 1.0 / sigma : 0.0;
-    // bins are sorted by their bounds (data_class.py:948-964), so a bin's lower edge is very often the
-    // previous bin's upper edge: its Phi / phi are reused instead of evaluated twice (same values)
-    double pz = 0.0, pch = 0.0, pfh = 0.0, pufh = 0.0;
-    bool have_prev = false;
-    for (int b = 0; b < c.B; ++b) {
-        double P = 0.0, dmu = 0.0, dsig = 0.0;
-        if (live) {
-            const double zh = c.z_hi[b], zl = c.z_lo[b];
-            double ch = 1.0, cl = 0.0, fh = 0.0, fl = 0.0, ufh = 0.0, ufl = 0.0;
-            if (!isinf(zl)) {
-                if (have_prev && zl == pz) {
-                    cl = pch;
-                    fl = pfh;
-                    ufl = pufh;
-                } else {
-                    const double u = (zl - mu) * inv;
-                    cl = norm_cdf(u);
-                    fl = norm_pdf(u);
-                    ufl = u * fl;
-                }
-            }
-            if (!isinf(zh)) {
-                const double u = (zh - mu) * inv;
-                ch = norm_cdf(u);
-                fh = norm_pdf(u);
-                ufh = u * fh;
-                pz = zh;
-                pch = ch;
-                pfh = fh;
-                pufh = ufh;
-                have_prev = true;
-            }
-            P = ch - cl;
-            dmu = -(fh - fl) * inv;
-            dsig = -(ufh - ufl) * inv;
-        }
-        const long o = tab_off(c, b, a1, g);
-        c.tabP[o] = P;
-        c.tabPmu[o] = dmu;
-        c.tabPy[o] = dsig;  // d/d sigma_a here (chain to y_e in k_param)
-    }
-}
-
+// (allele_slot_tables: above k_param, whose allele blocks share it)
 // One thread per slot that holds an allele (DevArgs::live_slots, built once by bean_hip_prepare: the
 // slots in (a1, g) order whose mask is set or whose edit list is not empty).  The other slots' tables are
 // zero from the start and stay zero.  At BASELINE config 3 that is 193k of 350k slots, and because the
@@ -2828,6 +2919,17 @@ __device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int
 // the launch ran every wave for half the lanes.
 __global__ __launch_bounds__(256) void k_allele(DevArgs c) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(BEAN_STAMP) && BEAN_STAMP == 5  // (records behind k_param's: edit blocks, guide blocks)
+    const long rec0 = ((long)c.T * c.lpt + kParamBlock - 1) / kParamBlock + ((long)c.G * kAMax + kParamBlock - 1) / kParamBlock;
+    BEAN_STAMP_RT(rec0 + blockIdx.x, 0);
+    if (idx < c.n_live_slots) {
+        const int s5 = c.live_slots[idx];
+        allele_slot_tables(c, s5 / c.G, s5 % c.G);
+    }
+    __syncthreads();
+    BEAN_STAMP_RT(rec0 + blockIdx.x, 7);
+    return;
+#endif
     if (idx >= c.n_live_slots) return;
     const int s = c.live_slots[idx];  // a1 * G + g
     allele_slot_tables(c, s / c.G, s % c.G);

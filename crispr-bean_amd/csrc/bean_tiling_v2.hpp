@@ -96,6 +96,14 @@ __host__ inline int tiling_rep_waves(int R, int B, bool acc) {
     return best;
 }
 
+// (Which guides a workgroup takes - round 5, measured: workgroup b takes guides [b Gw, (b + 1) Gw), and with the guides
+// ordered by allele count, heaviest first, that is already the balanced assignment: the XCD's workgroups go round its
+// 32 CUs, so the four workgroups a CU holds, b, b + 256, b + 512, b + 768, come from the four quarters of the order.
+// Mapped so that a CU's four come from ONE quarter the launch takes 124 us instead of 115; a mapping that is balanced
+// under either dispatch order 117.  And the launch is as long as its average wave, not its heaviest: screens whose
+// guides all have 1 / ~2.5 / ~4 / 7 edited alleles take 98 / 104 / 113 / 131 us - a masked allele slot costs three
+// quarters of a filled one, and neither the floor sampler nor an all-floor shortcut of the implicit gradient on the slots
+// above a wave's alleles takes anything off it: 7 % of a masked allele's draws stay above the floor.)
 template <bool ACC, bool SURV>
 // (the 32-allele build: two waves per SIMD and 251 VGPRs instead of four and 128 + ~300 spilled - 274 -> 200 us at
 // 20 000 guides with 24 slots, 464 -> 445 at 50 000 with 32; three waves per SIMD are slower than either.  The
