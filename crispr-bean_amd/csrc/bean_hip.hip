@@ -911,18 +911,16 @@ static bool param_generic_only() {
     return g;
 }
 static bool param_kind3(const DevArgs& d) {
-    return d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.tgrad && !d.n_cov && !d.lpart &&
+    return d.family == kMultiMixture && !d.wide_targets && !d.wide_alleles && !d.n_cov && !d.lpart &&
            d.trow_summed && !d.surv_q0lik && d.lpt == kLanesPerTargetNarrow;
 }
 static int param_allele_blocks(const bean_hip_ctx* c, const DevArgs& d) {
     if (param_generic_only() || !param_kind3(d) || d.survival || !c->allele_blocks || d.n_live_slots <= 0 || !d.tile_ctr) return 0;
     return (int)(((long)d.n_live_slots + kParamBlock - 1) / kParamBlock);
 }
-// what a PREP launch without exchanged gradients (the launches of bean_hip_svi_run / _resume) leaves
+// what a PREP launch leaves (with or without exchanged gradients: the same build of the kernel, the same answer)
 static bool param_prep_leaves_alleles_fresh(const bean_hip_ctx* c) {
-    DevArgs d = c->d;
-    d.tgrad = nullptr;
-    return param_allele_blocks(c, d) > 0;
+    return param_allele_blocks(c, c->d) > 0;
 }
 
 template <bool FINISH, bool ADAM, bool PREP>
@@ -2177,10 +2175,12 @@ extern "C" int bean_hip_svi_run_exchanged(bean_hip_ctx* c, uint64_t seed, uint64
                 hipGraphExec_t ge = nullptr;
                 bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (ok) {
-                    // (tiling: a graph's first guide launch runs k_allele whatever ran before the graph - the update of an
-                    // exchanged step never leaves allele tables)
+                    // (tiling: a graph's first node is a guide launch; it is captured in the state every replay enters it
+                    // with - behind a PREP launch of k_param, bean_hip_sharded_begin's or an exchanged update's - and a
+                    // replay checks that state, as launch_resume_graph does)
                     const bool fresh_was = c->alleles_fresh;
-                    c->alleles_fresh = false;
+                    c->resume_head_fresh = param_prep_leaves_alleles_fresh(c);
+                    c->alleles_fresh = c->resume_head_fresh;
                     for (uint64_t i = 0; ok && i < (2ull << k); ++i) ok = enqueue_exchanged_step(c, stream, false) == 0;
                     c->alleles_fresh = fresh_was;
                     // the capture is ended whether or not a step failed inside it (enqueue_exchanged_step closes
@@ -2204,8 +2204,7 @@ extern "C" int bean_hip_svi_run_exchanged(bean_hip_ctx* c, uint64_t seed, uint64
         }
         for (int k = (int)c->graphs_xchg.size() - 1; k >= 0; --k)
             while (left > (2ull << k)) {  // strictly more: the last step stays outside the graphs
-                HIP_OK(hipGraphLaunch(c->graphs_xchg[k], stream));
-                c->alleles_fresh = false;  // (ends with an exchanged update)
+                if (launch_resume_graph(c, c->graphs_xchg[k], stream)) return -1;  // (ends with an exchanged PREP update)
                 left -= 2ull << k;
             }
     }

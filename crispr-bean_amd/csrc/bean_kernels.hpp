@@ -1445,7 +1445,7 @@ void k_param(DevArgs c, int n_target_blocks) {
         __builtin_assume(c.family == kMultiMixture);
         __builtin_assume(!c.wide_targets);
         __builtin_assume(!c.wide_alleles);
-        __builtin_assume(c.tgrad == nullptr);
+        // (c.tgrad: either - a guide-sharded fit's exchanged update is this build too, with its allele blocks)
         __builtin_assume(c.n_cov == 0);
         __builtin_assume(c.lpart == nullptr);
         __builtin_assume(c.trow_summed != 0);
