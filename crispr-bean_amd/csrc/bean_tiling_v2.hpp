@@ -104,6 +104,33 @@ __host__ inline int tiling_rep_waves(int R, int B, bool acc) {
 // guides all have 1 / ~2.5 / ~4 / 7 edited alleles take 98 / 104 / 113 / 131 us - a masked allele slot costs three
 // quarters of a filled one, and neither the floor sampler nor an all-floor shortcut of the implicit gradient on the slots
 // above a wave's alleles takes anything off it: 7 % of a masked allele's draws stay above the floor.)
+// The rows k_guide_tiling_rep hands to k_param are sums over the replicates of a guide.  They are collected in batches:
+// a thread parks its value of row n of the batch in column n of a buffer of B dead LDS columns (tiling_rows_flush's
+// caller), and once a buffer is full - or the kernel ends - ONE barrier closes the batch and the thread of (replicate r,
+// guide j) adds up row r (and r + R, ...) of guide j over the replicates, r = 0 first (the order k_sum_trow used: same
+// bits), and stores it.  Round 3's form closed every row with a barrier of its own and let the R - 1 other replicates'
+// threads idle while replicate 0's added: 32 barriers and 32 five-term sums per thread of replicate 0 at config 3, now 7
+// barriers and <= 7 sums per thread (~750 of a wave's 11 600 instructions).  Two buffers (the e[] columns and the
+// digamma-difference columns, both dead once the likelihoods are done) alternate, so a batch is written while the
+// previous one may still be read: the barrier of batch n + 1 lies between the reads of batch n and the writes of n + 2.
+// qpack: the batch's row numbers, eight bits each.  Measured at config 3: 146.9 -> 145.0 us per step (kernel 116.0 -> 114.7);
+// as a function out of line - one call per batch - 148.1 (kernel 118.3).  Far less than 750 of 11 600 instructions would
+// give an issue-bound launch: by its counters the kernel keeps the vector pipe busy for 65 % of its cycles
+// (SQ_ACTIVE_INST_VALU x 4 / 1 024 SIMDs against GRBM_GUI_ACTIVE / 8; profiles/r05_counters_tiling.txt).
+constexpr int kTilingRowBatchMax = 8;
+__device__ __forceinline__ void tiling_rows_flush(const double* buf, int NT, int n_pend, unsigned long long qpack, int R,
+                                               int Gw, int r, int j, bool ok, double* part, long G, int g) {
+    __syncthreads();
+    if (ok) {
+        for (int k = r; k < n_pend; k += R) {
+            const double* col = buf + (long)k * NT;
+            double s = col[j];
+            for (int rr = 1; rr < R; ++rr) s += col[rr * Gw + j];
+            part[(long)((qpack >> (8 * k)) & 255ull) * G + g] = s;
+        }
+    }
+}
+
 template <bool ACC, bool SURV>
 // (the 32-allele build: two waves per SIMD and 251 VGPRs instead of four and 128 + ~300 spilled - 274 -> 200 us at
 // 20 000 guides with 24 slots, 464 -> 445 at 50 000 with 32; three waves per SIMD are slower than either.  The
@@ -131,23 +158,23 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
     // both pi sites, the Multinomial and the count likelihoods are masked by repguide_mask in tiling
     // (model.py:659,682,731; guide 941): a masked (replicate, guide) contributes nothing
     const bool on = valid && rgm;
-    const bool store = valid && r == 0;
     const bool use_bc = (c.flags & kUseBc) != 0;
-    // row q of this guide = sum over its replicates, r = 0 first.  Staged in the first column of e[] /
-    // of the digamma differences in turn - both dead once the likelihoods are done, which is before the
-    // first row exists - so one barrier per row is enough: the column written for row n + 2 is the one
-    // read for row n, and the barrier of row n + 1 lies between the two.
-    int n_rows_out = 0;
+    // row q of this guide = sum over its replicates, r = 0 first: collected in batches of up to B rows (tiling_rows_flush)
+    const int row_batch = B < kTilingRowBatchMax ? B : kTilingRowBatchMax;
+    int n_pend = 0, n_batches = 0;
+    unsigned long long qpack = 0;
+    auto rows_flush = [&]() {
+        if (n_pend == 0) return;
+        tiling_rows_flush(tls + ((n_batches & 1) ? 2 * B * NT : 0), NT, n_pend, qpack, R, Gw, r, j, valid, c.part, G, g);
+        n_pend = 0;
+        qpack = 0;
+        ++n_batches;
+    };
     auto row_out = [&](int q, double v) {
-        double* col = tls + ((n_rows_out & 1) ? 2 * B * NT : 0);
-        ++n_rows_out;
-        col[lane] = on ? v : 0.0;
-        __syncthreads();
-        if (store) {
-            double s = col[j];
-            for (int rr = 1; rr < R; ++rr) s += col[rr * Gw + j];
-            c.part[(long)q * G + g] = s;
-        }
+        double* buf = tls + ((n_batches & 1) ? 2 * B * NT : 0);
+        buf[n_pend * NT + lane] = on ? v : 0.0;
+        qpack |= (unsigned long long)q << (8 * n_pend);
+        if (++n_pend == row_batch) rows_flush();
     };
 
     // totals of the guide's counts over the conditions, both likelihoods: one batch of loads.  (The
@@ -522,6 +549,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
     }
     if (ACC) row_out(kTGnoise, gnoise);
     row_out(kTNrg, 1.0);
+    rows_flush();
     const double tot = wave_sum(on ? nll : 0.0);
     if ((lane & 63) == 0) {  // every wave of the workgroup adds its part
         loss_add(c, ctr.slot, tot);
