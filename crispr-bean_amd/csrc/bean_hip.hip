@@ -1165,8 +1165,17 @@ static void launch_guide_tiling_rep(bean_hip_ctx* c, hipStream_t stream) {
     const bool acc = (d.flags & kAcc) != 0;
     const int waves = c->tiling_rep_w;
     const int nt = 64 * waves;
-    const int gw = nt / d.R;  // guides per workgroup (R <= kTilingRepMaxR = 64, so >= 1)
-    const dim3 grid((unsigned)((d.G + gw - 1) / gw)), block(nt);
+    int gw = nt / d.R;  // guides per workgroup (R <= kTilingRepMaxR = 64, so >= 1)
+    unsigned n_wg = (unsigned)((d.G + gw - 1) / gw);
+    // which guides a workgroup takes: tiling_rep_slice, mode 1 (an XCD's workgroups take contiguous runs of the guide order,
+    // one run per quarter of it; BEAN_HIP_TILING_MAP=0: workgroup b takes slice b).  Config 3, same bits: kernel 115.2 ->
+    // 113.1 us, step 145.5 -> 144.8.  The grid is padded to a multiple of 32, the mode rides above the argument's low byte.
+    static const int map_mode = getenv("BEAN_HIP_TILING_MAP") ? atoi(getenv("BEAN_HIP_TILING_MAP")) : 1;
+    if (map_mode) {
+        n_wg = (n_wg + 31) / 32 * 32;
+        gw |= map_mode << 8;
+    }
+    const dim3 grid(n_wg), block(nt);
     const size_t lds = guide_tiling_lds(d.B, acc, (size_t)nt, false);
     const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;
     hipEvent_t e0 = nullptr, e1 = nullptr;

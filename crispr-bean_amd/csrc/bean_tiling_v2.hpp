@@ -117,6 +117,18 @@ __host__ inline int tiling_rep_waves(int R, int B, bool acc) {
 // as a function out of line - one call per batch - 148.1 (kernel 118.3).  Far less than 750 of 11 600 instructions would
 // give an issue-bound launch: by its counters the kernel keeps the vector pipe busy for 65 % of its cycles
 // (SQ_ACTIVE_INST_VALU x 4 / 1 024 SIMDs against GRBM_GUI_ACTIVE / 8; profiles/r05_counters_tiling.txt).
+// Which slice of Gw consecutive guides workgroup b of a grid of n takes.  mode 0: b.  mode 1 (n a multiple of 32): XCD
+// b & 7 takes, of each QUARTER of the guide order, one contiguous run of n / 32 slices - its j-th workgroup (j = b >> 3)
+// the slice j % (n / 32) of quarter j / (n / 32) - so that workgroups with neighbouring guides share an L2 (a workgroup's
+// 51 guides x 8 bytes do not end on a cache line) while a CU's four workgroups (j, j + 32, j + 64, j + 96 for n = 1 024)
+// still come from the four quarters of the allele-count order.
+__device__ __forceinline__ long tiling_rep_slice(int b, int n, int mode) {
+    if (mode == 0) return b;
+    const int x = b & 7, j = b >> 3, run = n >> 5;
+    const int quarter = j / run, i = j - quarter * run;
+    return (long)quarter * (n >> 2) + (long)x * run + i;
+}
+
 constexpr int kTilingRowBatchMax = 8;
 __device__ __forceinline__ void tiling_rows_flush(const double* buf, int NT, int n_pend, unsigned long long qpack, int R,
                                                int Gw, int r, int j, bool ok, double* part, long G, int g) {
@@ -136,7 +148,10 @@ template <bool ACC, bool SURV>
 // 20 000 guides with 24 slots, 464 -> 445 at 50 000 with 32; three waves per SIMD are slower than either.  The
 // 16-allele build stays at four: without its 60 spills it is 3 % faster at 20 000 guides and 32 % slower at 50 000.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BEAN_AMAX > 16 ? 2 : 4)))
-void k_guide_tiling_rep(DevArgs c, int Gw) {
+void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
+    const int Gw = Gw_mode & 255;
+    const long wg_slice = tiling_rep_slice((int)blockIdx.x, (int)gridDim.x, Gw_mode >> 8);
+    if (wg_slice * Gw >= c.G) return;  // (a padded grid's workgroups without guides; workgroup 0 always has guides)
     extern __shared__ double tls[];
     const int lane = threadIdx.x;  // thread of the workgroup: columns in LDS have NT entries
     const int NT = blockDim.x;
@@ -146,7 +161,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw) {
     const bool spare = r >= R;
     if (spare) r = R - 1;
     const int j = lane - r * Gw;
-    const long g_raw = (long)blockIdx.x * Gw + j;
+    const long g_raw = wg_slice * Gw + j;
     const bool valid = !spare && g_raw < G;
     const int g = g_raw < G ? (int)g_raw : G - 1;
     const StepCtr ctr = *c.ctrB;
