@@ -1175,6 +1175,9 @@ static void launch_guide_tiling_rep(bean_hip_ctx* c, hipStream_t stream) {
         n_wg = (n_wg + 31) / 32 * 32;
         gw |= map_mode << 8;
     }
+    // issue priority by progress (k_guide_tiling_rep's phase_prio): bit 16
+    static const int prio_mode = getenv("BEAN_HIP_TILING_PRIO") ? atoi(getenv("BEAN_HIP_TILING_PRIO")) : 1;
+    if (prio_mode) gw |= 1 << 16;
     const dim3 grid(n_wg), block(nt);
     const size_t lds = guide_tiling_lds(d.B, acc, (size_t)nt, false);
     const bool prof = c->profile && !c->profile_param && c->ev.size() < 8192;

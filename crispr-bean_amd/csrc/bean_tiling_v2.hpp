@@ -129,6 +129,28 @@ __device__ __forceinline__ long tiling_rep_slice(int b, int n, int mode) {
     return (long)quarter * (n >> 2) + (long)x * run + i;
 }
 
+// Diagnostic builds (-DBEAN_STAMP=6): every wave of k_guide_tiling_rep leaves eight stamps of the 100 MHz real-time clock
+// (scripts/stamps_tiling_rep.py): 0 start, 1 first loads + concentrations, 2 draw, 3 forward mix, 4 likelihoods,
+// 5 backward loop + rows, 6 Multinomial + Dirichlet terms + implicit gradients, 7 end.
+#if defined(BEAN_STAMP) && BEAN_STAMP == 6
+#define BEAN_STAMP_TR(slot)                                                                      \
+    do {                                                                                         \
+        unsigned long long u_;                                                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u_)::"memory");          \
+        if ((lane & 63) == 0) c.dbg[((long)blockIdx.x * (NT >> 6) + (lane >> 6)) * 8 + (slot)] = u_; \
+    } while (0)
+#else
+#define BEAN_STAMP_TR(slot) do {} while (0)
+#endif
+
+// s_setprio with a run-time level (the instruction takes an immediate)
+__device__ __forceinline__ void wave_prio(int level) {
+    if (level <= 0) __builtin_amdgcn_s_setprio(0);
+    else if (level == 1) __builtin_amdgcn_s_setprio(1);
+    else if (level == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 constexpr int kTilingRowBatchMax = 8;
 __device__ __forceinline__ void tiling_rows_flush(const double* buf, int NT, int n_pend, unsigned long long qpack, int R,
                                                int Gw, int r, int j, bool ok, double* part, long G, int g) {
@@ -150,7 +172,20 @@ template <bool ACC, bool SURV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BEAN_AMAX > 16 ? 2 : 4)))
 void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
     const int Gw = Gw_mode & 255;
-    const long wg_slice = tiling_rep_slice((int)blockIdx.x, (int)gridDim.x, Gw_mode >> 8);
+    const long wg_slice = tiling_rep_slice((int)blockIdx.x, (int)gridDim.x, (Gw_mode >> 8) & 255);
+    // Issue priority by progress (bit 16 of the argument; BEAN_HIP_TILING_PRIO=0 switches it off): the draw runs at
+    // priority 3, forward mix + likelihoods at 2, the backward loop at 1, the Dirichlet terms and implicit gradients at 0.
+    // Among equals the arbiter takes the OLDEST wave, and the workgroups are dispatched heaviest first: without this the
+    // oldest quarter of the grid has finished at 72 - 78 us of a 103 us launch while the youngest - the lightest
+    // guides - waits through its draw (36 us against 12) and runs its last phases alone; with it the quarters end at
+    // 78 - 82 / 83 - 86 / 89 - 94 / 96 - 100 us (scripts/stamps_tiling_rep.py, profiles/r05_timeline_tiling_rep.txt).
+    // Config 3: 143.5 -> 142.2 us per step.  (Measured too: 2,1,1,0: the same; 1,1,0,0 and the reverse order 0,1,2,3:
+    // nothing; one or two levels more for the youngest quarter / half of the grid on top: nothing.)
+    const bool prio_on = ((Gw_mode >> 16) & 1) != 0;
+    auto phase_prio = [&](int ph) {
+        if (prio_on) wave_prio(3 - ph);
+    };
+    phase_prio(0);
     if (wg_slice * Gw >= c.G) return;  // (a padded grid's workgroups without guides; workgroup 0 always has guides)
     extern __shared__ double tls[];
     const int lane = threadIdx.x;  // thread of the workgroup: columns in LDS have NT entries
@@ -169,6 +204,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
     double* gs = tls + B * NT + lane;        // d nll / d e[b]    at gs[b * NT]
     double* ds = tls + 2 * B * NT + lane;    // digamma diffs     at ds[b * NT]
 
+    BEAN_STAMP_TR(0);
     const bool rgm = c.rg[(long)r * G + g] != 0;
     // both pi sites, the Multinomial and the count likelihoods are masked by repguide_mask in tiling
     // (model.py:659,682,731; guide 941): a masked (replicate, guide) contributes nothing
@@ -218,6 +254,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
             n_bc += use_bc ? (double)c.Xbc[xo] : 0.0;
         }
     }
+    BEAN_STAMP_TR(1);
     const double pa0 = c.pi_a0[g];
     // ---- draw: the concentrations of the guide's Dirichlet live only until the draw is done
     double pi[kAMax];
@@ -275,6 +312,8 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
                 if (a < A) pi[a] = fmin(fmax(pi[a] * rs, kDblMin), kOneMinus);
         }
     }
+    BEAN_STAMP_TR(2);
+    phase_prio(1);
     if ((c.flags & kDumpPi) && valid) {
 #pragma unroll
         for (int a = 0; a < kAMax; ++a)
@@ -311,6 +350,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
             gs[b * NT] = 0.0;
         }
     }
+    BEAN_STAMP_TR(3);
     // ---- both Dirichlet-Multinomial terms, d nll / d e[b] accumulated in gs
     double nll = 0.0;
     {
@@ -373,6 +413,8 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
             }
         }
     }
+    BEAN_STAMP_TR(4);
+    phase_prio(2);
     // ---- back through the mixture: d loss / d pi_a and the per-allele-slot rows
     // (survival: the guide's baseline growth draw is loaded again rather than carried across the likelihoods)
     double u_b = 0.0;
@@ -488,6 +530,8 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
             row_out(kTGsig + a - 1, pea * dsg);
         }
     }
+    BEAN_STAMP_TR(5);
+    phase_prio(3);
     // ---- Multinomial on control allele counts (sorting; the survival form is the control term above)
     if (!SURV) {
         double s = 0.0;
@@ -562,6 +606,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
 #endif
             }
     }
+    BEAN_STAMP_TR(6);
     if (ACC) row_out(kTGnoise, gnoise);
     row_out(kTNrg, 1.0);
     rows_flush();
@@ -570,6 +615,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
         loss_add(c, ctr.slot, tot);
         if (blockIdx.x == 0 && lane == 0) publish_ctr(c, ctr);
     }
+    BEAN_STAMP_TR(7);
 }
 
 }  // namespace bean
