@@ -208,6 +208,24 @@ def valu_issue_roofline(config, kernel_name, kernel_ms):
     out = {"bound": "f64 VALU issue", "achieved": achieved / 1e9, "unit": "G wave-instr/s",
            "peak_datasheet": F64_VALU_DATASHEET / 1e9, "frac_datasheet": achieved / F64_VALU_DATASHEET,
            "valu_insts_per_launch": insts, "source": [os.path.basename(cfile)]}
+    # how busy the vector pipe was in the profiled launches themselves: SQ_ACTIVE_INST_VALU counts quad-cycles in which a
+    # wave executes a VALU instruction (the unit in which WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY add up to WAVE_CYCLES),
+    # GRBM_GUI_ACTIVE the launch's cycles summed over the 8 XCDs
+    step = " / step" if kernel_name == "k_svi_async" else ""
+    vals = {}
+    for i, ln in enumerate(lines):
+        if ln.startswith("bean::" + kernel_name + "<") or ln.startswith("bean::" + kernel_name + " "):
+            for l2 in lines[i + 1:i + 24]:
+                for name in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"):
+                    m = re.match(r"\s+" + name + re.escape(step) + r"\s+n=\s*\d+\s+mean=([0-9.e+]+)", l2)
+                    if m:
+                        vals.setdefault(name, float(m.group(1)))
+            if len(vals) == 2:
+                break
+    if len(vals) == 2 and vals["GRBM_GUI_ACTIVE"] > 0:
+        out["valu_busy"] = {"frac": vals["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0),
+                            "note": "SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs, in the "
+                                    "profiled (eager, counter-collecting) launches of " + os.path.basename(cfile)}
     ns = None
     if vfile:
         for ln in open(vfile):
