@@ -1402,8 +1402,9 @@ template <bool FINISH, bool ADAM, bool PREP, int KIND = 0>
 #ifndef BEAN_KP3_WAVES
 #define BEAN_KP3_WAVES 1
 #endif
-// (-DBEAN_KP3_WAVES=7 holds KIND 3 to seven waves per SIMD - 72 VGPRs, what the build before the allele blocks took by
-// itself; with the allele blocks it takes 74, i.e. 1 536 places instead of 1 792 at BASELINE config 3: A/B)
+// (-DBEAN_KP3_WAVES=7 holds KIND 3 to seven waves per SIMD, 72 VGPRs: what it takes by itself in the shipped build; an
+// intermediate form of the allele blocks took 74 - 1 536 places instead of 1 792 at BASELINE config 3 - and measured the
+// same step time held to 72 (5 spilled) or not)
 __global__ __launch_bounds__(kParamBlock) __attribute__((amdgpu_waves_per_eu(KIND == 3 ? BEAN_KP3_WAVES : 1)))
 void k_param(DevArgs c, int n_target_blocks) {
     // (KIND 3: what the grid holds beyond the edit blocks and the guide blocks - kAMax lanes per guide - are allele blocks)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# k_param's allele blocks against k_allele as a launch of its own (BEAN_HIP_ALLELE=split), and the seven-waves build of
-# k_param<..., 3> (build/variants/libbean_hip_kp7.so: bash scripts/build_variants.sh kp7:"-mllvm -disable-machine-licm -DBEAN_KP3_WAVES=7").
+# k_param's allele blocks against k_allele as a launch of its own (BEAN_HIP_ALLELE=split); optionally a build of
+# k_param<..., 3> held to seven waves per SIMD (bash scripts/build_variants.sh kp7:"-mllvm -disable-machine-licm -DBEAN_KP3_WAVES=7").
 # Same process order for every variant; ORDERS=ordered = the guides as run_inference hands them over.
 cd "$(dirname "$0")/../.."
 G=${1:-50000}; STEPS=${2:-600}
