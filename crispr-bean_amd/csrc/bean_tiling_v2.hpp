@@ -370,8 +370,34 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
             const double inv = frcp(S + kEps);
             double A0 = 0.0, lsum = 0.0, Ua = 0.0, Va = 0.0;
             bool anyfl = false;
+            int b = 0;
+#if BEAN_TL_DIAG != 3 && !defined(BEAN_TL_SINGLE_BINS) && BEAN_AMAX <= 8
+            // two conditions per pass: their lgamma / digamma differences as two chains side by side (lgamma_digamma_diff2:
+            // the same operations per chain, the same bits); the sums take the two in order.  Config 3: 142.9 -> 141.8 us per
+            // step (117 instead of 108 VGPRs, nothing spilled; -DBEAN_TL_SINGLE_BINS: one per pass).  The default build only: the
+            // 16-allele build, which spills already, loses by it (16 slots / 4 edited alleles, 20 000 guides: 211.9 against 205.4)
 #pragma unroll 1
-            for (int b = 0; b < B; ++b) {
+            for (; b + 1 < B; b += 2) {
+                const double araw0 = (es[b * NT] * sf[b] + epsB) * inv * a0 * sm[b];
+                const double araw1 = (es[(b + 1) * NT] * sf[b + 1] + epsB) * inv * a0 * sm[b + 1];
+                const bool fl0 = araw0 < kEps, fl1 = araw1 < kEps;
+                anyfl = anyfl || fl0 || fl1;
+                const double al0 = fl0 ? kEps : araw0, al1 = fl1 ? kEps : araw1;
+                const DD2 dd = lgamma_digamma_diff2(al0, (double)xp[(long)b * G], al1, (double)xp[(long)(b + 1) * G]);
+                A0 += al0;
+                lsum += dd.a.d;
+                ds[b * NT] = dd.a.dp;
+                Ua += fl0 ? 0.0 : araw0;
+                Va += fl0 ? 0.0 : dd.a.dp * araw0;
+                A0 += al1;
+                lsum += dd.b.d;
+                ds[(b + 1) * NT] = dd.b.dp;
+                Ua += fl1 ? 0.0 : araw1;
+                Va += fl1 ? 0.0 : dd.b.dp * araw1;
+            }
+#endif
+#pragma unroll 1
+            for (; b < B; ++b) {
                 const double araw = (es[b * NT] * sf[b] + epsB) * inv * a0 * sm[b];
                 const bool floored = araw < kEps;
                 anyfl = anyfl || floored;
