@@ -28,7 +28,8 @@ namespace bean {
 // VALU-bound (SQ_INSTS_VALU x 4 cycles / 1 024 SIMDs = 39 us) and its 4 689 waves still do not fit the
 // 4 096 slots of four waves per SIMD; five waves per SIMD (96 VGPRs: 52 spilled) measured 88.2 us, six
 // (80 VGPRs: 78 spilled) 96.3 us.  Two timepoints per iteration through lgamma_digamma_diff2 (the metric kernel's
-// two side-by-side chains): 85.8 against 86.2-86.5 us, with 33 instead of 11 spilled registers - not adopted.
+// two side-by-side chains): 85.8 against 86.2-86.5 us, with 33 instead of 11 spilled registers - not adopted THEN;
+// round 5, on the kernel without spills: adopted (the likelihood loop below).
 // What the launch's 66 us are (scripts/stamps_surv_guide.py, every wave's start and end on the real-time clock):
 // 4 096 waves are resident for the first 25 us; the four waves of a SIMD finish one after another (25, 37, 45,
 // 53 us: the oldest wave issues first), and the 593 waves that are left start on the SIMDs that free up first and
@@ -284,8 +285,44 @@ void k_guide_survival_wave(DevArgs c) {
             }
             double lsum = 0.0, Wa = 0.0;
             double S_0 = 0.0, S_1 = 0.0, S_t = 0.0, t_0 = 0.0, t_1 = 0.0, t_t = 0.0;
+            int b = 0;
+#ifndef BEAN_SURV_SINGLE_BINS
+            // two timepoints per pass: their lgamma / digamma differences side by side (lgamma_digamma_diff2, the same
+            // operations per chain); every sum takes the two in order - same bits.  Round 3 measured this form at 128 VGPRs
+            // + 33 spilled (no gain); after round 4's register diet it is 127 VGPRs + 4 spilled and config 5 steps in
+            // 80.1 - 81.2 us against 82.2 (-DBEAN_SURV_SINGLE_BINS: one per pass)
+            auto acc_bin = [&](double p0, double p1, double sfb, double tb, double km, double araw, bool floored, const DD& db) {
+                lsum += db.d;
+                const double ga = floored ? 0.0 : d0.dp - db.dp;
+                Wa += ga * araw;
+                const double cb = ga * km * sfb;
+                const double tp1 = tb * p1;
+                S_1 += cb * p1;
+                t_1 += sfb * p1;
+                S_t += cb * tp1;
+                t_t += sfb * tp1;
+                if (MIX) {
+                    S_0 += cb * p0;
+                    t_0 += sfb * p0;
+                }
+            };
 #pragma unroll 1
-            for (int b = 0; b < B; ++b) {
+            for (; b + 1 < B; b += 2) {
+                const double p0a = MIX ? p0s[b * 64] : 0.0, p1a = p1s[b * 64];
+                const double p0b = MIX ? p0s[(b + 1) * 64] : 0.0, p1b = p1s[(b + 1) * 64];
+                const double sfa = sf[b], sfbb = sf[b + 1], ta = c_tm[b], tbb = c_tm[b + 1];
+                const double kma = ai * c_sm[b], kmb = ai * c_sm[b + 1];
+                const double arawa = alpha_raw(w0, p0a, w1, p1a, sfa, epsB, kma);
+                const double arawb = alpha_raw(w0, p0b, w1, p1b, sfbb, epsB, kmb);
+                const bool fla = arawa < kEps, flb = arawb < kEps;
+                const DD2 dd = lgamma_digamma_diff2(fla ? kEps : arawa, (double)xp[(long)b * G], flb ? kEps : arawb,
+                                                    (double)xp[(long)(b + 1) * G]);
+                acc_bin(p0a, p1a, sfa, ta, kma, arawa, fla, dd.a);
+                acc_bin(p0b, p1b, sfbb, tbb, kmb, arawb, flb, dd.b);
+            }
+#endif
+#pragma unroll 1
+            for (; b < B; ++b) {
                 const double p0 = MIX ? p0s[b * 64] : 0.0, p1 = p1s[b * 64];
                 const double sfb = sf[b], tb = c_tm[b];
                 const double km = ai * c_sm[b];
