@@ -289,8 +289,9 @@ void k_guide_survival_wave(DevArgs c) {
 #ifndef BEAN_SURV_SINGLE_BINS
             // two timepoints per pass: their lgamma / digamma differences side by side (lgamma_digamma_diff2, the same
             // operations per chain); every sum takes the two in order - same bits.  Round 3 measured this form at 128 VGPRs
-            // + 33 spilled (no gain); after round 4's register diet it is 127 VGPRs + 4 spilled and config 5 steps in
-            // 80.1 - 81.2 us against 82.2 (-DBEAN_SURV_SINGLE_BINS: one per pass)
+            // + 33 spilled (no gain); after round 4's register diet, and with the growth columns read again behind the chains
+            // instead of carried across them, it is 115 - 117 VGPRs, nothing spilled, and config 5 steps in 80.5 - 80.9 us
+            // against 82.7 - 83.4 (kernel 59.5 against 62 - 65; -DBEAN_SURV_SINGLE_BINS: one per pass)
             auto acc_bin = [&](double p0, double p1, double sfb, double tb, double km, double araw, bool floored, const DD& db) {
                 lsum += db.d;
                 const double ga = floored ? 0.0 : d0.dp - db.dp;
@@ -308,17 +309,21 @@ void k_guide_survival_wave(DevArgs c) {
             };
 #pragma unroll 1
             for (; b + 1 < B; b += 2) {
-                const double p0a = MIX ? p0s[b * 64] : 0.0, p1a = p1s[b * 64];
-                const double p0b = MIX ? p0s[(b + 1) * 64] : 0.0, p1b = p1s[(b + 1) * 64];
-                const double sfa = sf[b], sfbb = sf[b + 1], ta = c_tm[b], tbb = c_tm[b + 1];
-                const double kma = ai * c_sm[b], kmb = ai * c_sm[b + 1];
-                const double arawa = alpha_raw(w0, p0a, w1, p1a, sfa, epsB, kma);
-                const double arawb = alpha_raw(w0, p0b, w1, p1b, sfbb, epsB, kmb);
+                double arawa, arawb;
+                {
+                    const double p0a = MIX ? p0s[b * 64] : 0.0, p1a = p1s[b * 64];
+                    const double p0b = MIX ? p0s[(b + 1) * 64] : 0.0, p1b = p1s[(b + 1) * 64];
+                    arawa = alpha_raw(w0, p0a, w1, p1a, sf[b], epsB, ai * c_sm[b]);
+                    arawb = alpha_raw(w0, p0b, w1, p1b, sf[b + 1], epsB, ai * c_sm[b + 1]);
+                }
                 const bool fla = arawa < kEps, flb = arawb < kEps;
                 const DD2 dd = lgamma_digamma_diff2(fla ? kEps : arawa, (double)xp[(long)b * G], flb ? kEps : arawb,
                                                     (double)xp[(long)(b + 1) * G]);
-                acc_bin(p0a, p1a, sfa, ta, kma, arawa, fla, dd.a);
-                acc_bin(p0b, p1b, sfbb, tbb, kmb, arawb, flb, dd.b);
+                // (the columns are read AGAIN behind the two chains - LDS reads - instead of carried across them: the
+                // barrier makes them new values to the compiler; carried, they were four spilled registers)
+                asm volatile("" ::: "memory");
+                acc_bin(MIX ? p0s[b * 64] : 0.0, p1s[b * 64], sf[b], c_tm[b], ai * c_sm[b], arawa, fla, dd.a);
+                acc_bin(MIX ? p0s[(b + 1) * 64] : 0.0, p1s[(b + 1) * 64], sf[b + 1], c_tm[b + 1], ai * c_sm[b + 1], arawb, flb, dd.b);
             }
 #endif
 #pragma unroll 1
