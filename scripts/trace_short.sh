@@ -20,6 +20,14 @@ for s, e in list(zip(starts, ends))[-3:]:
     span = (int(grp[-1]["End_Timestamp"]) - t0) / 1e3
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in grp) / 1e3
     print(f"call with {n_guide} steps: span {span:.1f} us, kernels busy {busy:.1f} us, gaps {span - busy:.1f} us")
+    n_async = sum("k_svi_async" in r["Kernel_Name"] for r in grp)
+    if n_async:  # (round 5: the call is k_async_head, ONE k_svi_async launch of all its steps, k_loss_finalize)
+        prev = t0
+        for r in grp:
+            st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            name = r["Kernel_Name"].split("(")[0][-40:]
+            print(f"   +{(st - prev) / 1e3:6.1f} gap  {(en - st) / 1e3:7.1f} us  {name}")
+            prev = en
     if n_guide == 20:
         prev = t0
         for r in grp:
