@@ -916,6 +916,7 @@ static bool param_kind3(const DevArgs& d) {
 }
 static int param_allele_blocks(const bean_hip_ctx* c, const DevArgs& d) {
     if (param_generic_only() || !param_kind3(d) || d.survival || !c->allele_blocks || d.n_live_slots <= 0 || !d.tile_ctr) return 0;
+    if (d.T <= 0) return 0;  // (no edit block would ever raise the go flags)
     return (int)(((long)d.n_live_slots + kParamBlock - 1) / kParamBlock);
 }
 // what a PREP launch leaves (with or without exchanged gradients: the same build of the kernel, the same answer)
