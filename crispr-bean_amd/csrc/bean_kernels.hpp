@@ -1595,8 +1595,8 @@ void k_param(DevArgs c, int n_target_blocks) {
     }
     if ((int)bid < n_target_blocks) {
         // ------------------------------------------------ target part
-        // (with allele blocks behind them the edit blocks head the launch's longest chain: first on their SIMDs)
-        if (KIND == 3 && PREP && n_allele_blocks > 0) __builtin_amdgcn_s_setprio(2);
+        // (the edit blocks head the launch's longest chain when allele blocks follow; a raised issue priority for them -
+        // s_setprio 2 - measured nothing: 142.1 against 142.1 us per step)
         int t;
         bool active;
         double gmu = 0.0, gy = 0.0, tab_mu = 0.0, tab_y = 0.0;
