@@ -451,9 +451,19 @@ extern "C" int bean_hip_create(const bean_hip_shape* s, bean_hip_ctx** out) {
         if (c->tiling_rep) c->tiling_wave = false;
         // BEAN_HIP_TILING_W (1, 2 or 4; experiments only) overrides the number of waves per workgroup
         const int w_env = getenv("BEAN_HIP_TILING_W") ? atoi(getenv("BEAN_HIP_TILING_W")) : 0;
+        long n_simd = 0;
+        {
+            int dev = 0, n_cu = 0;
+            if (hipGetDevice(&dev) == hipSuccess &&
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+                n_simd = 4l * n_cu;
+            else
+                (void)hipGetLastError();
+        }
         c->tiling_rep_w = (w_env == 1 || w_env == 2 || w_env == 4)
                               ? w_env
-                              : tiling_rep_waves(s->n_reps, s->n_condits, (s->flags & BEAN_FLAG_SCALE_BY_ACC) != 0);
+                              : tiling_rep_waves(s->n_reps, s->n_condits, (s->flags & BEAN_FLAG_SCALE_BY_ACC) != 0,
+                                                 (long)s->n_guides, n_simd);
         if (s->n_condits > 16) c->tiling_rep_w = 1;  // LDS: (3 B + ...) x 64 W doubles per workgroup
     }
     d.wide_alleles = c->tiling_wide ? 1 : 0;

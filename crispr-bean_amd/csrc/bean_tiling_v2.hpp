@@ -78,7 +78,15 @@ constexpr int kTilingRepMaxR = 64;  // more replicates than that: the wave form 
 // wave slots its LDS lets the kernel use (160 KB per CU; with many conditions or the accessibility columns a
 // 256-thread workgroup no longer fits four times); the smaller on a tie.  Measured at config 3 (B = 5): W = 2
 // 188.6 us per step, W = 4 183.1.
-__host__ inline int tiling_rep_waves(int R, int B, bool acc) {
+// A screen (or one rank's shard of it) small enough to give every SIMD of the device at most one single-wave workgroup
+// takes W = 1: such a launch is as long as one wave's dependency chain, and a wave alone in its workgroup waits for no
+// other wave at the row barriers (BASELINE config 3 cut in eight, 6 250 guides: 85.5 us per step at W = 1, 87.2 at 2, 91.5
+// at 4; at 12 500 guides - 1 042 single-wave workgroups for 1 024 SIMDs - 92.6 / 94.5 / 93.5: the rule below again).
+__host__ inline int tiling_rep_waves(int R, int B, bool acc, long G = 0, long n_simd = 0) {
+    if (G > 0 && n_simd > 0 && R <= 64) {
+        const long gw1 = 64 / R;  // guides per single-wave workgroup
+        if ((G + gw1 - 1) / gw1 <= n_simd) return 1;
+    }
     int best = 1;
     double best_score = 0.0;
     for (int w = 1; w <= 4; w *= 2) {

@@ -41,7 +41,7 @@ pickle.dump(out, open(sys.argv[1], "wb"))
 def _run(tmp_path, tag, env_extra):
     path = str(tmp_path / f"{tag}.pkl")
     env = dict(os.environ, **env_extra)
-    for k in ("BEAN_HIP_TILING_MAP", "BEAN_HIP_TILING_PRIO"):
+    for k in ("BEAN_HIP_TILING_MAP", "BEAN_HIP_TILING_PRIO", "BEAN_HIP_TILING_W"):
         if k not in env_extra:
             env.pop(k, None)
     res = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT), path], env=env, capture_output=True, text=True,
@@ -51,12 +51,21 @@ def _run(tmp_path, tag, env_extra):
         return pickle.load(f)
 
 
-def test_slice_map_and_priority_change_nothing(tmp_path):
+@pytest.mark.parametrize("waves", ["auto", "4"])
+def test_slice_map_and_priority_change_nothing(tmp_path, waves):
+    """waves: the library's choice (screens this small give every SIMD at most one single-wave workgroup: W = 1) and four
+    waves per workgroup forced (what BASELINE config 3 runs with) - the same bits, too."""
     import numpy as np
     import torch
 
-    a = _run(tmp_path, "default", {})
-    b = _run(tmp_path, "plain", {"BEAN_HIP_TILING_MAP": "0", "BEAN_HIP_TILING_PRIO": "0"})
+    w = {} if waves == "auto" else {"BEAN_HIP_TILING_W": waves}
+    a = _run(tmp_path, "default" + waves, dict(w))
+    b = _run(tmp_path, "plain" + waves, dict(w, BEAN_HIP_TILING_MAP="0", BEAN_HIP_TILING_PRIO="0"))
+    if waves != "auto":
+        ref = _run(tmp_path, "auto_ref", {})
+        for name in a:
+            for k in a[name][0]:
+                assert torch.equal(a[name][0][k], ref[name][0][k]), (name, k, "W = 4 against the library's choice")
     assert a.keys() == b.keys()
     for name in a:
         pa, la = a[name]
