@@ -540,6 +540,30 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
         if (a < A) {
             double sa = 0.0, dm = 0.0, dsg = 0.0;
             if (a < Aw) {
+#ifndef BEAN_TL_PLAIN_BWD
+                // the table entries of condition b + 1 are asked for before those of b are used: same sums.  Config 3
+                // 142.3 -> 141.6 us per step, cut in eight 86.0 -> 85.4 (an earlier state of the kernel: nothing)
+                long o = (long)(a - 1) * G + g;
+                const long ob = (long)A1 * G;
+                double tp = c.tabP[o], tm = c.tabPmu[o], ty = SURV ? 0.0 : c.tabPy[o];
+#pragma unroll 1
+                for (int b = 0; b < B; ++b) {
+                    double np = 0.0, nm = 0.0, ny = 0.0;
+                    if (b + 1 < B) {
+                        o += ob;
+                        np = c.tabP[o];
+                        nm = c.tabPmu[o];
+                        if (!SURV) ny = c.tabPy[o];
+                    }
+                    const double ge = gs[b * NT];
+                    sa += ge * tp;
+                    dm += ge * tm;
+                    if (!SURV) dsg += ge * ty;
+                    tp = np;
+                    tm = nm;
+                    ty = ny;
+                }
+#else
 #pragma unroll 1
                 for (int b = 0; b < B; ++b) {
                     const long o = ((long)b * A1 + (a - 1)) * G + g;
@@ -548,6 +572,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
                     dm += ge * c.tabPmu[o];
                     if (!SURV) dsg += ge * c.tabPy[o];
                 }
+#endif
             }
             double pea = pi[a];
             if (ACC) {
