@@ -348,6 +348,31 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
             }
             pe[0] = 1.0 - sum;
         }
+#if !defined(BEAN_TL_PLAIN_FWD) && BEAN_AMAX <= 8
+        {
+            // the table entries of condition b + 1 are asked for before those of b are used - these are the kernel's cold
+            // round trips to the allele tables, five in a row on every wave's chain: same sums.  An eighth of config 3
+            // (6 250 guides, one wave per SIMD): 85.6 -> 80.1 us per step, the kernel 69.9 -> 63.6; the whole screen
+            // 142.5 -> 140.8.  (The default build; 119 VGPRs.)
+            double tp[kAMax], tn[kAMax];
+#pragma unroll
+            for (int a = 1; a < kAMax; ++a) tp[a] = a < Aw ? c.tabP[(long)(a - 1) * G + g] : 0.0;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+#pragma unroll
+                for (int a = 1; a < kAMax; ++a)
+                    tn[a] = (a < Aw && b + 1 < B) ? c.tabP[((long)(b + 1) * A1 + (a - 1)) * G + g] : 0.0;
+                double v = pe[0] * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
+#pragma unroll
+                for (int a = 1; a < kAMax; ++a)
+                    if (a < Aw) v += pe[a] * tp[a];
+                es[b * NT] = v;
+                gs[b * NT] = 0.0;
+#pragma unroll
+                for (int a = 1; a < kAMax; ++a) tp[a] = tn[a];
+            }
+        }
+#else
 #pragma unroll 1
         for (int b = 0; b < B; ++b) {
             double v = pe[0] * (SURV ? exp(u * uniform_ld(c.time, b)) : uniform_ld(c.P0, b));
@@ -357,6 +382,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
             es[b * NT] = v;
             gs[b * NT] = 0.0;
         }
+#endif
     }
     BEAN_STAMP_TR(3);
     // ---- both Dirichlet-Multinomial terms, d nll / d e[b] accumulated in gs
