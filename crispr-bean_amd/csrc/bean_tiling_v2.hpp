@@ -243,12 +243,30 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
     double n_x = 0.0, n_bc = 0.0;
     {
         float xv[2][kBMax];
+        // (no branch between the loads - X_bcmatch is read through X's pointer where it is not used, and dropped - so that
+        // all 2 kBMax are in flight together: with the branch the compiler waited for every pair before it asked for the
+        // next, eight round trips in a row at the head of every wave)
+        // (the default build; the 16-condition builds keep the loads under the branch - twice the registers in flight)
+#if BEAN_BMAX <= 8
+        const float* const xbc = use_bc ? c.Xbc : c.X;
+#pragma unroll
+        for (int b = 0; b < kBMax; ++b) {
+            const long xo = ((long)r * B + (b < B ? b : B - 1)) * G + g;
+            xv[0][b] = c.X[xo];
+            xv[1][b] = xbc[xo];
+        }
+        if (!use_bc) {
+#pragma unroll
+            for (int b = 0; b < kBMax; ++b) xv[1][b] = 0.f;
+        }
+#else
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
             const long xo = ((long)r * B + (b < B ? b : B - 1)) * G + g;
             xv[0][b] = c.X[xo];
             xv[1][b] = use_bc ? c.Xbc[xo] : 0.f;
         }
+#endif
 #pragma unroll
         for (int b = 0; b < kBMax; ++b) {
             if (b < B) {
@@ -273,6 +291,26 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
     int Aw = 1;
     {
         double alpha[kAMax], Ssum = 0.0;
+        // (mask bytes and parameters of all slots are asked for together, slots beyond A on the last one's address: a load
+        // under `am ? ... :` was a round trip of its own behind the mask byte's - sixteen in a row)
+        // (the default build; with 16 or 32 slots the values in flight would be spilled)
+#if BEAN_AMAX <= 8
+        uint8_t amb[kAMax];
+        float apu[kAMax];
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {
+            const long o = (long)g * A + (a < A ? a : A - 1);
+            amb[a] = c.amask[o];
+            apu[a] = c.p[4][o];
+        }
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {
+            const bool am = a < A && amb[a] != 0;
+            if (__any(am)) Aw = a + 1;
+            alpha[a] = a < A ? (am ? (double)expf(apu[a]) : kEps) : 0.0;
+            Ssum += alpha[a];
+        }
+#else
 #pragma unroll
         for (int a = 0; a < kAMax; ++a) {
             const bool am = a < A && c.amask[(long)g * A + a] != 0;
@@ -280,6 +318,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
             alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)g * A + a]) : kEps) : 0.0;
             Ssum += alpha[a];
         }
+#endif
         const double rsq = frcp(Ssum) * pa0;
         if (c.pi_in) {
 #pragma unroll
@@ -566,7 +605,7 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
         if (a < A) {
             double sa = 0.0, dm = 0.0, dsg = 0.0;
             if (a < Aw) {
-#ifndef BEAN_TL_PLAIN_BWD
+#if !defined(BEAN_TL_PLAIN_BWD) && BEAN_AMAX <= 8
                 // the table entries of condition b + 1 are asked for before those of b are used: same sums.  Config 3
                 // 142.3 -> 141.6 us per step, cut in eight 86.0 -> 85.4 (an earlier state of the kernel: nothing)
                 long o = (long)(a - 1) * G + g;
@@ -652,12 +691,29 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
         int ge = g;
         asm volatile("" : "+v"(ge));
         double alpha[kAMax], Ssum = 0.0;
+#if BEAN_AMAX <= 8
+        uint8_t amb[kAMax];
+        float apu[kAMax];
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {  // (all asked for together, as before the draw)
+            const long o = (long)ge * A + (a < A ? a : A - 1);
+            amb[a] = c.amask[o];
+            apu[a] = c.p[4][o];
+        }
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) {
+            const bool am = a < A && amb[a] != 0;
+            alpha[a] = a < A ? (am ? (double)expf(apu[a]) : kEps) : 0.0;
+            Ssum += alpha[a];
+        }
+#else
 #pragma unroll
         for (int a = 0; a < kAMax; ++a) {
             const bool am = a < A && c.amask[(long)ge * A + a] != 0;
             alpha[a] = a < A ? (am ? (double)expf(c.p[4][(long)ge * A + a]) : kEps) : 0.0;
             Ssum += alpha[a];
         }
+#endif
         const double pa0e = c.pi_a0[ge];  // (loaded again behind the barrier, not carried: see above)
         const double rsq = frcp(Ssum) * pa0e;
         // model-side floored concentration c_p (model.py:640-651) for - d log p / d pi
@@ -678,6 +734,17 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
             }
         }
         const double dgS_t = c.dgq_t[(long)kAMax * G + ge];  // digamma(sum c_q), tabulated by k_param
+        // (digamma(c_q a) of every slot asked for now: asked for in front of its call, each was a cold round trip that the
+        // call began by waiting for)
+        // (the default build; with 16 or 32 slots they would be spilled across the calls)
+#if BEAN_AMAX <= 8
+        double dgq_a[kAMax];
+#pragma unroll
+        for (int a = 0; a < kAMax; ++a) dgq_a[a] = c.dgq_t[(long)(a < A ? a : A - 1) * G + ge];
+#define BEAN_TL_DGQ(a_) dgq_a[a_]
+#else
+#define BEAN_TL_DGQ(a_) c.dgq_t[(long)(a_) * G + ge]
+#endif
 #pragma unroll
         for (int a = 0; a < kAMax; ++a)
             if (a < A) {
@@ -687,10 +754,11 @@ void k_guide_tiling_rep(DevArgs c, int Gw_mode) {
                 row_out(kTPath + a, (pi[a] + cqa) * (gpi[a] - proj));
 #else
                 row_out(kTPath + a,
-                        dirichlet_grad_one_pre(pi[a], cqa, total, c.dgq_t[(long)a * G + ge], dgS_t) * (gpi[a] - proj));
+                        dirichlet_grad_one_pre(pi[a], cqa, total, BEAN_TL_DGQ(a), dgS_t) * (gpi[a] - proj));
 #endif
             }
     }
+#undef BEAN_TL_DGQ
     BEAN_STAMP_TR(6);
     if (ACC) row_out(kTGnoise, gnoise);
     row_out(kTNrg, 1.0);
