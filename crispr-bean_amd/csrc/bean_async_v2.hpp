@@ -257,10 +257,14 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
     tile = rfl_i(tile);
     int t0, nt;  // the tile's first target and their number (as guide_wave2_tile finds them)
     {
+        // (the two lookups ride on lanes 0 and 1 of ONE load - a uniform value's load is waited for where it is made
+        // scalar, so one after the other they were two round trips at the head of the tile's chain; the same for the
+        // target offsets and the boundary counters below)
         const int gf = tile * 64 - c.g_sh > 0 ? tile * 64 - c.g_sh : 0;
         const int gl = tile * 64 + 63 - c.g_sh < c.G ? tile * 64 + 63 - c.g_sh : c.G - 1;
-        t0 = __builtin_amdgcn_readfirstlane(c.g2t[gf]);
-        nt = __builtin_amdgcn_readfirstlane(c.g2t[gl]) - t0 + 1;
+        const int gv = c.g2t[threadIdx.x == 0 ? gf : gl];
+        t0 = __builtin_amdgcn_readlane(gv, 0);
+        nt = __builtin_amdgcn_readlane(gv, 1) - t0 + 1;
     }
     StepCtr ctr;
     ctr.step = step;
@@ -272,7 +276,12 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
     extern __shared__ double tabs[];
     const int lane = threadIdx.x, R = c.R, G = c.G, B = c.B;
     const int t1 = t0 + nt - 1;
-    const int tof0 = c.toff[t0], tof1 = c.toff[t1 + 1];
+    int tof0, tof1;
+    {
+        const int tv = c.toff[lane == 0 ? t0 : t1 + 1];
+        tof0 = __builtin_amdgcn_readlane(tv, 0);
+        tof1 = __builtin_amdgcn_readlane(tv, 1);
+    }
     const unsigned long long s_prep = ctr.step + 1;
     AdamCoef ak;
     ak.step_size = ctr.step_size;
@@ -296,19 +305,18 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
     };
     if (part & 1) {
     int own_left = left_str ? 0 : 1, own_right = right_str ? 0 : 1;
-    if (lane == 0) {
-        // a target that straddles two tiles goes to the tile that completes second (one counter per boundary)
-        int* const bl = c.bnd_ctr + (left_str ? tile - 1 : tile);
-        int* const br = c.bnd_ctr + tile;
-        int ol = 0, orr = 0;
+    {
+        // a target that straddles two tiles goes to the tile that completes second (one counter per boundary):
+        // lane 0 counts in at the left boundary, lane 1 at the right one - one atomic instruction
         // (running counters, as the tiles': two arrivals per boundary and step, the odd one is the second)
-        if (left_str) ol = __hip_atomic_fetch_add(bl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (right_str) orr = __hip_atomic_fetch_add(br, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int* const bp = c.bnd_ctr + (lane == 0 ? (left_str ? tile - 1 : tile) : tile);
+        int old = 0;
+        if ((lane == 0 && left_str) || (lane == 1 && right_str))
+            old = __hip_atomic_fetch_add(bp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ol = __builtin_amdgcn_readlane(old, 0), orr = __builtin_amdgcn_readlane(old, 1);
         if (left_str && (ol & 1)) own_left = 1;
         if (right_str && (orr & 1)) own_right = 1;
     }
-    own_left = __builtin_amdgcn_readfirstlane(own_left);
-    own_right = __builtin_amdgcn_readfirstlane(own_right);
     BEAN_ASYNC_TF(0);
     const int ta = own_left ? t0 : t0 + 1, tb = own_right ? t1 : t1 - 1;  // this wave's targets, ta > tb: none
     double* hmu = tabs;  // drawn mu / y of the targets, hmu[t - ta] (<= 64 targets per tile)
@@ -457,30 +465,25 @@ __device__ BEAN_ASYNC_INLINE void async_finish_tile(const DevArgs* cp, unsigned 
     }
     BEAN_ASYNC_TF(3);
     // ---- loss: the R waves' parts of this tile + this wave's prior / entropy terms, integer atomics
+    // the R waves' loss parts of this tile (with the targets): lane r asks for replicate r's three words - one round trip
+    // for the wave - and the words join this wave's own terms in the integer sums below (integers: any order).  (One lane
+    // asking for all of them had become 3 R loads in a row, each waited for before the next: the compiler keeps a
+    // uniform lane's values in scalar registers, and a readfirstlane waits for its load.)
+    if (part & 1) {
+        for (int r0 = 0; r0 < R; r0 += 64) {
+            if (r0 + lane < R) {
+                const long long* o = c.lpart + 3 * (long)(((tile >> 3) * R + r0 + lane) * 8 + (tile & 7));
+                loss_hi += __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                loss_lo += __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                loss_bad += __hip_atomic_load(o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     loss_hi = wave_sum_i64(loss_hi);
     loss_lo = wave_sum_i64(loss_lo);
     loss_bad = wave_sum_i64(loss_bad);
     if (lane == 0) {
         long long a = 0, b = 0, d = 0;
-        for (int r0 = 0; r0 < ((part & 1) ? R : 0); r0 += 8) {  // (the R waves' parts: with the targets)
-            long long w[8][3];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                w[u][0] = w[u][1] = w[u][2] = 0;
-                if (r0 + u < R) {
-                    const long long* o = c.lpart + 3 * (long)(((tile >> 3) * R + r0 + u) * 8 + (tile & 7));
-                    w[u][0] = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w[u][1] = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w[u][2] = __hip_atomic_load(o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                a += w[u][0];
-                b += w[u][1];
-                d += w[u][2];
-            }
-        }
         a += loss_hi;
         b += loss_lo;
         d += loss_bad;
