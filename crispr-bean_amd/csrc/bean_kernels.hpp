@@ -872,13 +872,40 @@ __device__ __forceinline__ void target_grad_sums(const DevArgs& c, int t, bool a
         double a = 0.0, b = 0.0;
         if (t < c.T) {
             const double sd = c.survival ? 0.0 : exp(c.y_t[t]);  // survival: no sd latent
-            for (int k = c.e2a_ptr[t] + lg; k < c.e2a_ptr[t + 1]; k += lpt) {
-                const int slot = c.e2a_idx[k];
-                const int a1 = slot % A1, gs = slot / A1;
-                const long o = slot_off(c, a1, gs);
-                a += trow_sum(c, q_gmu + a1, gs);
-                // d sigma_a / d y_e = sd_e^2 / sigma_a
-                if (!c.survival) b += trow_sum(c, q_gsig + a1, gs) * sd * sd / c.sig_a[o];
+            // four slots of the lane at a time: their indices asked for together, then their rows together, then the
+            // additions in the order of the plain loop (same bits).  One slot per pass was two dependent round trips per
+            // slot - index, then rows - and an edit's lane has three or four slots: this loop is the head of the launch's
+            // longest chain (edit blocks -> allele blocks)
+            const int k1 = c.e2a_ptr[t + 1];
+            for (int kb = c.e2a_ptr[t] + lg; kb < k1; kb += 4 * lpt) {
+                int sl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u * lpt;
+                    sl[u] = k < k1 ? c.e2a_idx[k] : -1;
+                }
+                double xa[4], xb[4], sg[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xa[u] = 0.0;
+                    xb[u] = 0.0;
+                    sg[u] = 1.0;
+                    if (sl[u] >= 0) {
+                        const int a1 = sl[u] % A1, gs = sl[u] / A1;
+                        xa[u] = trow_sum(c, q_gmu + a1, gs);
+                        if (!c.survival) {
+                            xb[u] = trow_sum(c, q_gsig + a1, gs);
+                            sg[u] = c.sig_a[slot_off(c, a1, gs)];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (sl[u] >= 0) {
+                        a += xa[u];
+                        // d sigma_a / d y_e = sd_e^2 / sigma_a
+                        if (!c.survival) b += xb[u] * sd * sd / sg[u];
+                    }
             }
         }
         group_allsum(lpt, a, b);
@@ -1321,11 +1348,33 @@ __device__ __forceinline__ void allele_slot_tables(const DevArgs& c, int a1, int
         return;
     }
     double mu = 0.0, var = 0.0;
-    for (int k = c.a2e_ptr[slot]; k < c.a2e_ptr[slot + 1]; ++k) {
-        const int e = c.a2e_idx[k];
-        mu += coh_ld<COH>(c.mu_t + e);
-        const double sd = exp(coh_ld<COH>(c.y_t + e));
-        var += sd * sd;
+    {
+        // four edits of the allele at a time: their indices asked for together, then their draws together, then the sums
+        // in the plain loop's order (same bits; an allele has two edits on average, and one per pass was two dependent
+        // round trips each - at agent scope in k_param's allele blocks)
+        const int k1 = c.a2e_ptr[slot + 1];
+        for (int kb = c.a2e_ptr[slot]; kb < k1; kb += 4) {
+            int ei[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ei[u] = kb + u < k1 ? c.a2e_idx[kb + u] : -1;
+            double xm[4], xy[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xm[u] = 0.0;
+                xy[u] = 0.0;
+                if (ei[u] >= 0) {
+                    xm[u] = coh_ld<COH>(c.mu_t + ei[u]);
+                    xy[u] = coh_ld<COH>(c.y_t + ei[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ei[u] >= 0) {
+                    mu += xm[u];
+                    const double sd = exp(xy[u]);
+                    var += sd * sd;
+                }
+        }
     }
     const double sigma = sqrt(var);
     c.mu_a[idx] = mu;
