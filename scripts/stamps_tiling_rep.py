@@ -23,7 +23,9 @@ data, ids = parallel.order_by_alleles(data)
 eng = engine.HipSVI("MultiMixtureNormal", data.to("cuda:0"), num_steps=100, guide_ids=ids)
 eng.run(20, graph_chunk=0)
 torch.cuda.synchronize()
-W = 4
+# waves per workgroup as the library chooses them (tiling_rep_waves): 1 where every SIMD gets at most one single-wave
+# workgroup, else 4 at R = 5 (STAMP_W overrides, with BEAN_HIP_TILING_W)
+W = int(os.environ.get("STAMP_W", "1" if (G + (64 // R) - 1) // (64 // R) <= 1024 else "4"))
 Gw = 64 * W // R
 n_wg = (G + Gw - 1) // Gw
 mode = int(os.environ.get("BEAN_HIP_TILING_MAP", "1"))
